@@ -1,0 +1,114 @@
+/* vis_hip.h - C ABI of libvis_hip.so, the MI355X (gfx950) compute library behind
+ * the Inspector/Auditor "image -> defect report" step.
+ *
+ * The reference (Aditya-Somasi/Vision-Inspection-System) has no FFI of its own:
+ * its hot path is one remote call,
+ *     client.chat.completions.create(model=, messages=, temperature=, max_tokens=)
+ *     (src/agents/vlm_inspector.py:105-111, src/agents/vlm_auditor.py:117-129,:152-158)
+ * and everything the remote service does for that call (image patch embedding,
+ * ViT, merger, LLM prefill, greedy decode) is what these entry points compute
+ * locally.  The arithmetic each entry point replaces is cited against the
+ * model definition the service runs (TF = transformers/models/qwen2_vl).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *    stated otherwise; bf16 tensors are raw uint16 bit patterns;
+ *  - no allocation, no global state, no synchronisation: kernels are enqueued
+ *    on `stream` (a hipStream_t passed as void*) and may be captured in a hipGraph;
+ *  - return value: 0 = enqueued, 1 = argument/shape/alignment precondition
+ *    violated (nothing launched), 2 = HIP launch error.
+ */
+#ifndef VIS_HIP_H
+#define VIS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vis_stream_t; /* hipStream_t */
+
+#define VIS_OK 0
+#define VIS_ERR_ARG 1
+#define VIS_ERR_LAUNCH 2
+
+/* activation selectors for vis_gemm_bf16 / vis_gemv_bf16 */
+#define VIS_ACT_NONE 0
+#define VIS_ACT_QUICKGELU 1 /* x * sigmoid(1.702 x)      ViT MLP (hidden_act="quick_gelu")   */
+#define VIS_ACT_GELU_ERF 2  /* 0.5 x (1 + erf(x/sqrt2))  merger nn.GELU(), TF modeling:284   */
+#define VIS_ACT_SWIGLU 3    /* silu(gate) * up over a 16-row interleaved gate/up weight       */
+
+int vis_abi_version(void);
+
+/* K2  C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) + R[M,N]      (bf16 in/out, f32 accumulate)
+ * Replaces nn.Linear / Conv3d-as-GEMM in TF modeling_qwen2_vl.py:251-274 (patch embed),
+ * :281-286 (merger), :296-298 (ViT MLP), :349-350,:421 (ViT qkv/proj), :459-466 (LLM MLP),
+ * :501-504,:555 (LLM q/k/v/o).  K % 64 == 0, N % 4 == 0, lda/ldw % 8 == 0.
+ * VIS_ACT_SWIGLU: W rows are [gate 16 | up 16] interleaved, output has N/2 columns. */
+int vis_gemm_bf16(const void* A, const void* W, const void* bias, const void* R, void* C,
+                  int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act, vis_stream_t stream);
+
+/* K3  y = w * bf16(x * rsqrt(mean(x^2) + eps))          TF modeling_qwen2_vl.py:96-110  */
+int vis_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int N, int ldx, int ldy,
+                     float eps, vis_stream_t stream);
+
+/* K5  y = (x - mean) * rsqrt(var + eps) * w + b         TF modeling_qwen2_vl.py:281,:428-429 */
+int vis_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int N,
+                       int ldx, int ldy, float eps, vis_stream_t stream);
+
+/* K4  rotary embedding + head split (+ KV-cache write, + V transpose).
+ * qkv[S, (Hq+2Hkv)*HD] packed projections; cos/sin [S, HD] f32 rows (M-RoPE sections already
+ * selected per channel, TF modeling_qwen2_vl.py:180-222; ViT 2-D rope :225-236).
+ * q -> [Hq][S][HD]; k,v -> [Hkv][k_tokens][HD] rows k_pos0.. (v may be NULL);
+ * vt -> [Hkv][HD][vt_ld] keys contiguous (may be NULL).  HD in {128, 80}. */
+int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void* q, void* k, void* v,
+                       void* vt, int S, int ld_qkv, int Hq, int Hkv, int HD, int k_tokens, int k_pos0,
+                       int vt_ld, vis_stream_t stream);
+
+/* K6/K7  flash-style prefill attention over a host-built work list of
+ * {q0, qn<=128, k0, k1} int4 tiles (device memory): ViT varlen segments (cu_seqlens,
+ * TF modeling_qwen2_vl.py:356-423) and LLM causal GQA prefill (:508-556).
+ * O[Sq][ldo], column head*HD + d.  softmax(QK^T * scale) V, f32 softmax. */
+int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
+                     int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
+                     float scale, vis_stream_t stream);
+
+/* K10  y[N] = act(W[N,K] x[K] + bias) + R, optional fused RMSNorm of x (norm_w != NULL).
+ * out_f32 != 0 writes float logits (lm_head).  One generated token streams every weight once. */
+int vis_gemv_bf16(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,
+                  void* y, int N, int K, int ldw, int act, int out_f32, float eps, vis_stream_t stream);
+
+/* K4 (decode)  rotate q,k of one packed qkv row with cos/sin row *step_ptr and append k,v to
+ * the cache at slot slot_base + *step_ptr.  step_ptr is a device int (graph-replayable). */
+int vis_decode_rope_kv(const void* qkv, const void* cos_t, const void* sin_t, const void* step_ptr,
+                       void* q_out, void* k_cache, void* v_cache, int Hq, int Hkv, int HD,
+                       int cache_tokens, int slot_base, vis_stream_t stream);
+
+/* K11  GQA attention of the new token over slot_base + *step_ptr + 1 cached keys, split over
+ * the context (part_o [Hq][nsplit][128] f32, part_ml [Hq][nsplit][2] f32 workspaces). */
+int vis_decode_attn(const void* q, const void* k_cache, const void* v_cache, const void* step_ptr,
+                    void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int cache_tokens,
+                    int slot_base, int nsplit, float scale, vis_stream_t stream);
+
+/* K12  greedy pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
+ * torch.argmax), then *step += 1.  ws_val/ws_idx: 256 floats / 256 ints of workspace. */
+int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* tokens, int max_tokens,
+                   void* cur_token, void* step_ptr, vis_stream_t stream);
+
+/* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
+ * out[row0 + p][ld_out] in the merge-group order of
+ * TF image_processing_pil_qwen2_vl.py:156-190; mean/stdv are HOST pointers to 3 floats. */
+int vis_patchify_u8(const void* img, void* out, int H, int W, int ld_out, int row0, const float* mean,
+                    const float* stdv, vis_stream_t stream);
+
+/* K12  out[i][:] = table[ids[i]][:] (embedding lookup, ids int32 on device). */
+int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D, int n_table,
+                    vis_stream_t stream);
+
+/* K12  dst[idx[i]][:] = src[i][:] (image-token scatter, TF modeling_qwen2_vl.py:1144-1200). */
+int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
+                     vis_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIS_HIP_H */

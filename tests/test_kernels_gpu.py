@@ -1,0 +1,370 @@
+"""Per-kernel numerics: every C-ABI entry point vs a plain PyTorch fp32 reference of the same op.
+
+Tolerances (stated per test): inputs are bf16, accumulation is f32, outputs are
+rounded to bf16 once, so the bound is a few bf16 ulps of the output magnitude.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from vision_inspection_system_amd import hip as h
+    h.load()
+    return h
+
+
+def _randn(shape, device, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.bfloat16).to(device)
+
+
+def _assert_close(got, ref, atol, rtol, what):
+    got = got.float().cpu()
+    ref = ref.float().cpu()
+    err = (got - ref).abs()
+    bound = atol + rtol * ref.abs()
+    bad = err > bound
+    if bad.any():
+        idx = torch.nonzero(bad)[0].tolist()
+        raise AssertionError(
+            f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance; first at {idx}: "
+            f"got {got[tuple(idx)].item():.6f} ref {ref[tuple(idx)].item():.6f}; max err {err.max().item():.6f}")
+
+
+# ----------------------------------------------------------------------------- K2 GEMM
+GEMM_SHAPES = [
+    (128, 128, 64), (256, 256, 128), (100, 72, 64), (333, 960, 320), (1, 128, 64),
+    (2249, 512, 256), (130, 4608, 3584), (257, 1280, 5120),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_plain(hip, device, M, N, K):
+    a = _randn((M, K), device, 1)
+    w = _randn((N, K), device, 2, 1.0 / math.sqrt(K))
+    out = hip.gemm(a, w)
+    ref = a.float() @ w.float().t()
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what=f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_layout(hip, device):
+    # A = I, asymmetric W: catches a transposed accumulator map
+    K = 128
+    a = torch.eye(K, dtype=torch.bfloat16, device=device)
+    w = (torch.arange(256 * K, device=device).reshape(256, K) % 251).to(torch.bfloat16)
+    out = hip.gemm(a, w)
+    assert torch.equal(out.float(), w.float().t())
+
+
+@pytest.mark.parametrize("act", ["quickgelu", "gelu"])
+def test_gemm_bias_act(hip, device, act):
+    M, N, K = 300, 640, 320
+    a = _randn((M, K), device, 3)
+    w = _randn((N, K), device, 4, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 5)
+    code = hip.ACT_QUICKGELU if act == "quickgelu" else hip.ACT_GELU_ERF
+    out = hip.gemm(a, w, bias=b, act=code)
+    x = a.float() @ w.float().t() + b.float()
+    ref = x * torch.sigmoid(1.702 * x) if act == "quickgelu" else torch.nn.functional.gelu(x)
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what=f"gemm+bias+{act}")
+
+
+def test_gemm_bias_residual(hip, device):
+    M, N, K = 200, 256, 704
+    a = _randn((M, K), device, 6)
+    w = _randn((N, K), device, 7, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 8)
+    r = _randn((M, N), device, 9)
+    out = hip.gemm(a, w, bias=b, residual=r)
+    ref = a.float() @ w.float().t() + b.float() + r.float()
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="gemm+bias+residual")
+
+
+def test_gemm_swiglu(hip, device):
+    M, K, I = 150, 256, 704
+    a = _randn((M, K), device, 10)
+    wg = _randn((I, K), device, 11, 1.0 / math.sqrt(K))
+    wu = _randn((I, K), device, 12, 1.0 / math.sqrt(K))
+    from vision_inspection_system_amd.weights import interleave_gate_up
+    wgu = interleave_gate_up(wg, wu)
+    out = hip.gemm(a, wgu, act=hip.ACT_SWIGLU)
+    g = a.float() @ wg.float().t()
+    u = a.float() @ wu.float().t()
+    ref = torch.nn.functional.silu(g) * u
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="gemm swiglu")
+
+
+def test_gemm_rejects_bad_k(hip, device):
+    a = _randn((16, 40), device, 1)
+    w = _randn((16, 40), device, 2)
+    with pytest.raises(hip.HipLibraryError):
+        hip.gemm(a, w)
+
+
+# ----------------------------------------------------------------------------- K3 / K5 norms
+@pytest.mark.parametrize("rows,N", [(1, 256), (7, 3584), (2249, 3584), (33, 1280)])
+def test_rmsnorm(hip, device, rows, N):
+    x = _randn((rows, N), device, 20, 3.0)
+    w = _randn((N,), device, 21)
+    out = hip.rmsnorm(x, w, 1e-6)
+    xf = x.float()
+    normed = (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float()
+    ref = w.float() * normed
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="rmsnorm")
+
+
+@pytest.mark.parametrize("rows,N", [(5, 320), (4900, 1280), (3, 5120)])
+def test_layernorm(hip, device, rows, N):
+    x = _randn((rows, N), device, 22, 2.0) + 0.5
+    w = _randn((N,), device, 23)
+    b = _randn((N,), device, 24)
+    out = hip.layernorm(x, w, b, 1e-6)
+    ref = torch.nn.functional.layer_norm(x.float(), (N,), w.float(), b.float(), 1e-6)
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="layernorm")
+
+
+# ----------------------------------------------------------------------------- K4 rope/split
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,HD", [(70, 4, 2, 128), (2249, 28, 4, 128), (100, 4, 4, 80), (4900, 16, 16, 80)])
+def test_qkv_rope_split(hip, device, S, Hq, Hkv, HD):
+    qkv = _randn((S, (Hq + 2 * Hkv) * HD), device, 30)
+    g = torch.Generator().manual_seed(31)
+    ang = torch.rand((S, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), dim=-1)
+    cos, sin = emb.cos().to(device), emb.sin().to(device)
+    T = S + 5
+    pos0 = 3
+    ld = ((S + 63) // 64) * 64
+    q = torch.zeros((Hq, S, HD), dtype=torch.bfloat16, device=device)
+    k = torch.zeros((Hkv, T, HD), dtype=torch.bfloat16, device=device)
+    v = torch.zeros((Hkv, T, HD), dtype=torch.bfloat16, device=device)
+    vt = torch.full((Hkv, HD, ld), 7.0, dtype=torch.bfloat16, device=device)
+    hip.qkv_rope_split(qkv, cos, sin, q, k, v, vt, Hq, Hkv, HD, k_pos0=pos0)
+    x = qkv.float().reshape(S, Hq + 2 * Hkv, HD)
+    c, s_ = cos[:, None, :], sin[:, None, :]
+    qr = x[:, :Hq] * c + _rotate_half(x[:, :Hq]) * s_
+    kr = x[:, Hq:Hq + Hkv] * c + _rotate_half(x[:, Hq:Hq + Hkv]) * s_
+    vr = x[:, Hq + Hkv:]
+    _assert_close(q, qr.permute(1, 0, 2), atol=2e-2, rtol=1e-2, what="rope q")
+    _assert_close(k[:, pos0:pos0 + S], kr.permute(1, 0, 2), atol=2e-2, rtol=1e-2, what="rope k")
+    assert torch.equal(v[:, pos0:pos0 + S].float().cpu(), vr.permute(1, 0, 2).cpu())
+    assert torch.equal(vt[:, :, :S].float().cpu(), vr.permute(1, 2, 0).cpu())
+    assert float(vt[:, :, S:ld].float().abs().max().cpu()) == 0.0 if ld > S else True
+    assert float(k[:, :pos0].float().abs().max().cpu()) == 0.0
+
+
+# ----------------------------------------------------------------------------- K6 / K7 attention
+def _attn_ref(q, k, v, segments, causal, scale):
+    """q [Hq,S,D], k/v [Hkv,S,D] float -> [S, Hq*D]"""
+    Hq, S, D = q.shape
+    Hkv = k.shape[0]
+    out = torch.zeros((S, Hq, D))
+    for (s, e) in segments:
+        for h in range(Hq):
+            kk, vv = k[h // (Hq // Hkv), s:e], v[h // (Hq // Hkv), s:e]
+            sc = (q[h, s:e] @ kk.t()) * scale
+            if causal:
+                n = e - s
+                sc = sc.masked_fill(torch.triu(torch.ones(n, n, dtype=torch.bool), 1), float("-inf"))
+            out[s:e, h] = torch.softmax(sc, dim=-1) @ vv
+    return out.reshape(S, Hq * D)
+
+
+ATTN_CASES = [
+    # S, Hq, Hkv, HD, causal, segments
+    (64, 2, 1, 128, True, None),
+    (200, 4, 2, 128, True, None),
+    (2249, 28, 4, 128, True, None),
+    (150, 2, 2, 128, False, None),
+    (100, 2, 2, 80, False, None),
+    (4900, 16, 16, 80, False, None),
+    (356, 4, 4, 80, False, [(0, 100), (100, 356)]),       # two images, unaligned boundary
+    (320, 4, 4, 80, False, [(i * 64, (i + 1) * 64) for i in range(5)]),  # Qwen2.5-VL style windows
+]
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,HD,causal,segments", ATTN_CASES)
+def test_attn_prefill(hip, device, S, Hq, Hkv, HD, causal, segments):
+    segments = segments or [(0, S)]
+    q = _randn((Hq, S, HD), device, 40)
+    k = _randn((Hkv, S, HD), device, 41)
+    v = _randn((Hkv, S, HD), device, 42)
+    ld = ((S + 63) // 64) * 64
+    vt = torch.zeros((Hkv, HD, ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v.permute(0, 2, 1)
+    out = torch.zeros((S, Hq * HD), dtype=torch.bfloat16, device=device)
+    work = hip.make_attn_work(segments, causal, device)
+    scale = HD ** -0.5
+    hip.attn_prefill(q, k, vt, out, work, causal, scale)
+    if S > 1024:  # reference on two heads (each with its own kv head) to keep CPU time down
+        heads = [0, Hq - 1]
+        group = Hq // Hkv
+        ref = torch.cat([_attn_ref(q[h:h + 1].float().cpu(), k[h // group:h // group + 1].float().cpu(),
+                                   v[h // group:h // group + 1].float().cpu(), segments, causal, scale)
+                         for h in heads], dim=1)
+        got = torch.cat([out[:, h * HD:(h + 1) * HD] for h in heads], dim=1)
+    else:
+        ref = _attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), segments, causal, scale)
+        got = out
+    # P is rounded to bf16 before P*V: error ~ 2^-8 relative on O(1) outputs
+    _assert_close(got, ref, atol=2e-2, rtol=2e-2, what=f"attn S={S} HD={HD} causal={causal}")
+
+
+def test_attn_prefill_spiked_max(hip, device):
+    """Force the online-softmax rescale branch: one key with a huge score late in the sequence."""
+    S, H, HD = 300, 2, 128
+    q = _randn((H, S, HD), device, 50, 0.5)
+    k = _randn((H, S, HD), device, 51, 0.5)
+    v = _randn((H, S, HD), device, 52)
+    k[:, 257] = q[:, 299] * 8.0  # key 257 dominates for query 299 (third KV tile)
+    ld = 320
+    vt = torch.zeros((H, HD, ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v.permute(0, 2, 1)
+    out = torch.zeros((S, H * HD), dtype=torch.bfloat16, device=device)
+    work = hip.make_attn_work([(0, S)], True, device)
+    hip.attn_prefill(q, k, vt, out, work, True, HD ** -0.5)
+    ref = _attn_ref(q.float().cpu(), k.float().cpu(), v.float().cpu(), [(0, S)], True, HD ** -0.5)
+    _assert_close(out, ref, atol=2e-2, rtol=2e-2, what="attn spiked max")
+
+
+# ----------------------------------------------------------------------------- K10 GEMV
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1000, 704)])
+def test_gemv_plain(hip, device, N, K):
+    x = _randn((K,), device, 60)
+    w = _randn((N, K), device, 61, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 62)
+    r = _randn((N,), device, 63)
+    out = torch.empty((N,), dtype=torch.bfloat16, device=device)
+    hip.gemv(x, w, out, bias=b, residual=r)
+    ref = w.float() @ x.float() + b.float() + r.float()
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="gemv")
+
+
+def test_gemv_fused_rmsnorm_f32_out(hip, device):
+    N, K = 1536, 3584
+    x = _randn((K,), device, 64, 2.0)
+    nw = _randn((K,), device, 65)
+    w = _randn((N, K), device, 66, 1.0 / math.sqrt(K))
+    out = torch.empty((N,), dtype=torch.float32, device=device)
+    hip.gemv(x, w, out, norm_w=nw, eps=1e-6)
+    xf = x.float()
+    xn = (xf * torch.rsqrt(xf.pow(2).mean() + 1e-6)).to(torch.bfloat16).float() * nw.float()
+    xn = xn.to(torch.bfloat16).float()
+    ref = w.float() @ xn
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="gemv fused rmsnorm")
+
+
+def test_gemv_swiglu(hip, device):
+    K, I = 256, 704
+    x = _randn((K,), device, 67)
+    wg = _randn((I, K), device, 68, 1.0 / math.sqrt(K))
+    wu = _randn((I, K), device, 69, 1.0 / math.sqrt(K))
+    from vision_inspection_system_amd.weights import interleave_gate_up
+    wgu = interleave_gate_up(wg, wu)
+    out = torch.empty((I,), dtype=torch.bfloat16, device=device)
+    hip.gemv(x, wgu, out, act=hip.ACT_SWIGLU)
+    ref = torch.nn.functional.silu(wg.float() @ x.float()) * (wu.float() @ x.float())
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="gemv swiglu")
+
+
+# ----------------------------------------------------------------------------- K4/K11 decode attention
+@pytest.mark.parametrize("Hq,Hkv,ctx0,steps", [(2, 1, 37, 3), (28, 4, 2249, 2)])
+def test_decode_rope_and_attention(hip, device, Hq, Hkv, ctx0, steps):
+    HD = 128
+    T = ctx0 + 16
+    kc = torch.zeros((Hkv, T, HD), dtype=torch.bfloat16, device=device)
+    vc = torch.zeros((Hkv, T, HD), dtype=torch.bfloat16, device=device)
+    kc[:, :ctx0] = _randn((Hkv, ctx0, HD), device, 70)
+    vc[:, :ctx0] = _randn((Hkv, ctx0, HD), device, 71)
+    g = torch.Generator().manual_seed(72)
+    ang = torch.rand((8, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos_t, sin_t = emb.cos().to(device), emb.sin().to(device)
+    step = torch.zeros(1, dtype=torch.int32, device=device)
+    nsplit = 8
+    part_o = torch.empty(Hq * nsplit * HD, dtype=torch.float32, device=device)
+    part_ml = torch.empty(Hq * nsplit * 2, dtype=torch.float32, device=device)
+    q_out = torch.empty((Hq, HD), dtype=torch.bfloat16, device=device)
+    out = torch.empty((Hq * HD,), dtype=torch.bfloat16, device=device)
+    kref, vref = kc.float().cpu().clone(), vc.float().cpu().clone()
+    for t in range(steps):
+        qkv = _randn(((Hq + 2 * Hkv) * HD,), device, 80 + t)
+        hip.decode_rope_kv(qkv, cos_t, sin_t, step, q_out, kc, vc, Hq, Hkv, HD, ctx0)
+        hip.decode_attn(q_out, kc, vc, step, part_o, part_ml, out, Hq, Hkv, HD, ctx0, nsplit, HD ** -0.5)
+        x = qkv.float().cpu().reshape(Hq + 2 * Hkv, HD)
+        c, s_ = emb[t].cos(), emb[t].sin()
+        qr = (x[:Hq] * c + _rotate_half(x[:Hq]) * s_).to(torch.bfloat16).float()
+        kr = (x[Hq:Hq + Hkv] * c + _rotate_half(x[Hq:Hq + Hkv]) * s_).to(torch.bfloat16).float()
+        kref[:, ctx0 + t] = kr
+        vref[:, ctx0 + t] = x[Hq + Hkv:]
+        n = ctx0 + t + 1
+        ref = torch.zeros(Hq, HD)
+        for h in range(Hq):
+            kv = h // (Hq // Hkv)
+            p = torch.softmax((kref[kv, :n] @ qr[h]) * HD ** -0.5, dim=0)
+            ref[h] = p @ vref[kv, :n]
+        _assert_close(q_out, qr, atol=2e-2, rtol=1e-2, what="decode rope q")
+        _assert_close(out.reshape(Hq, HD), ref, atol=2e-2, rtol=2e-2, what=f"decode attn step {t}")
+        step += 1
+    _assert_close(kc[:, :ctx0 + steps], kref[:, :ctx0 + steps], atol=2e-2, rtol=1e-2, what="kv cache k")
+
+
+# ----------------------------------------------------------------------------- K12 glue
+def test_argmax_and_step(hip, device):
+    V = 152064
+    g = torch.Generator().manual_seed(90)
+    logits = torch.randn(V, generator=g).to(device)
+    logits[77777] = 50.0
+    logits[99999] = 50.0  # tie: first index wins, like torch.argmax
+    ws_v = torch.empty(256, dtype=torch.float32, device=device)
+    ws_i = torch.empty(256, dtype=torch.int32, device=device)
+    tokens = torch.full((4,), -1, dtype=torch.int32, device=device)
+    cur = torch.zeros(1, dtype=torch.int32, device=device)
+    step = torch.zeros(1, dtype=torch.int32, device=device)
+    hip.argmax(logits, ws_v, ws_i, tokens, cur, step)
+    logits[5] = 60.0
+    hip.argmax(logits, ws_v, ws_i, tokens, cur, step)
+    assert tokens.cpu().tolist() == [77777, 5, -1, -1]
+    assert int(cur.cpu()) == 5 and int(step.cpu()) == 2
+
+
+def test_gather_scatter_rows(hip, device):
+    table = _randn((512, 256), device, 91)
+    ids = torch.tensor([5, 0, 511, 17, 5], dtype=torch.int32, device=device)
+    out = torch.empty((5, 256), dtype=torch.bfloat16, device=device)
+    hip.gather_rows(table, ids, out)
+    assert torch.equal(out.cpu(), table.cpu()[ids.cpu().long()])
+    dst = torch.zeros((9, 256), dtype=torch.bfloat16, device=device)
+    idx = torch.tensor([8, 2, 3], dtype=torch.int32, device=device)
+    hip.scatter_rows(out[:3].contiguous(), idx, dst)
+    assert torch.equal(dst.cpu()[[8, 2, 3]], out.cpu()[:3])
+    assert float(dst.cpu()[[0, 1, 4, 5, 6, 7]].float().abs().max()) == 0.0
+
+
+def test_patchify_matches_reference_layout(hip, device):
+    import numpy as np
+    H, W = 56, 84
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    mean = (0.48145466, 0.4578275, 0.40821073)
+    std = (0.26862954, 0.26130258, 0.27577711)
+    out = torch.full((24, 1216), 9.0, dtype=torch.bfloat16, device=device)
+    hip.patchify(torch.from_numpy(img).to(device), out, 0, mean, std)
+    # numpy restatement of the patch layout (channel-first, 2x2 merge groups, temporal x2)
+    x = (img.astype(np.float32) / 255.0 - np.array(mean, np.float32)) / np.array(std, np.float32)
+    x = x.transpose(2, 0, 1)
+    gh, gw = H // 14, W // 14
+    p = x.reshape(3, gh // 2, 2, 14, gw // 2, 2, 14).transpose(1, 4, 2, 5, 0, 3, 6)
+    p = np.broadcast_to(p[:, :, :, :, :, None], (*p.shape[:5], 2, 14, 14)).reshape(gh * gw, 1176)
+    got = out.float().cpu().numpy()
+    assert np.abs(got[:, :1176] - p).max() < 2e-2
+    assert np.abs(got[:, 1176:]).max() == 0.0

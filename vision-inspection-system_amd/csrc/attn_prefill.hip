@@ -1,0 +1,321 @@
+// K6 + K7: flash-style prefill attention for gfx950 (MI355X), one kernel for
+//  * the ViT: non-causal, varlen segments (cu_seqlens), head_dim 80
+//    (TF:models/qwen2_vl/modeling_qwen2_vl.py:356-423; Qwen2.5-VL windows are
+//    just shorter segments), and
+//  * the LLM: causal GQA prefill, head_dim 128 (TF:...:508-556, :318-340).
+//
+// Work decomposition: the host passes a work list of {q0, qn<=128, k0, k1}
+// tiles (one workgroup each, x heads on grid.y): query rows [q0,q0+qn) attend
+// keys [k0,k1) (and key <= query when causal).  A work item never straddles a
+// segment, so cu_seqlens, windows and plain causal prefill are all the same
+// kernel.
+//
+// Per workgroup: 256 threads = 4 waves, each wave owns 32 query rows (two
+// 16-row blocks) and walks KV tiles of 64 keys that the whole workgroup stages
+// through LDS (double-buffered, register staged, one barrier per tile).
+//
+// MFMA formulation (v_mfma_f32_16x16x32_bf16, f32 accumulate, f32 softmax):
+//  * scores are computed TRANSPOSED,  S^T[key][q] = K * Q^T  (A = K rows from
+//    LDS via ds_read_b128, B = Q^T held in registers for the whole kernel), so
+//    the accumulator has the query on the lane (col) and 4 keys per register
+//    group: the row max/sum is 16 in-lane ops + two xor-shuffles (16, 32).
+//  * the exponentiated tile is already the A operand of P*V: two S^T blocks
+//    (32 keys) pack in-lane into one bf16x8 fragment; the k-slot order this
+//    implies (slot (h,j) <-> key 16*(j>>2) + 4h + (j&3)) is applied to the B
+//    operand instead, which is read from a V^T tile ([d][key], keys
+//    contiguous) with two ds_read_b64 per fragment.  No cross-lane movement of
+//    P and no transposed LDS read are needed.
+//  * K tile: 256-B rows, 16-B chunk index XOR (row & 15)   -> conflict-free b128
+//    (head_dim 80: 208-B padded rows, zero-filled d 80..95);
+//    V^T tile: 128-B rows, 8-B slot index XOR (d & 14)     -> conflict-free b64.
+// Online softmax in the log2 domain with a finite -1e30 sentinel (no inf-inf).
+// Output O[s][head*HD + d] is staged through LDS and written as whole 16-B
+// chunks so the following projection GEMM reads a plain row-major matrix.
+#include "common.hip.h"
+
+struct AttnArgs {
+  const bf16_t* Q;   // [Hq][Sq][HD]
+  const bf16_t* K;   // [Hkv][k_tokens][HD]
+  const bf16_t* Vt;  // [Hkv][HD][vt_ld]
+  bf16_t* O;         // [Sq][ldo]
+  const int4* work;  // [grid.x] {q0, qn, k0, k1}
+  int Sq, k_tokens, vt_ld, ldo, group;
+  float scale_log2;
+};
+
+#define ATT_NEG (-1.0e30f)
+
+template <int HD, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
+  constexpr int DKS = (HD + 31) / 32;           // QK^T k-steps over d: 4 / 3
+  constexpr int ND = HD / 16;                   // P*V output blocks over d: 8 / 5
+  constexpr int KCH = HD / 8;                   // valid 16-B chunks per K row: 16 / 10
+  constexpr int KROW = (HD == 128) ? 256 : 208; // LDS bytes per K row
+  constexpr int K_BYTES = 64 * KROW;            // 16384 / 13312
+  constexpr int V_BYTES = HD * 128;             // 16384 / 10240
+  constexpr int BUF = K_BYTES + V_BYTES;
+  constexpr int K_ITERS = (64 * KCH + 255) / 256;  // 4 / 3
+  constexpr int V_ITERS = (HD * 8 + 255) / 256;    // 4 / 3
+  constexpr int OROW = HD * 2 + 16;             // staging row bytes for the O tile
+  static_assert(2 * BUF >= 4 * 32 * OROW, "O staging must fit in the KV buffers");
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, h = lane >> 4;
+  const int head = blockIdx.y, hkv = head / p.group;
+  const int4 wk = p.work[blockIdx.x];
+  const int q0 = wk.x, qn = wk.y, k0 = wk.z;
+  const int k1 = CAUSAL ? min(wk.w, q0 + qn) : wk.w;
+  const int kt_begin = k0 & ~63;
+  const int nt = (k1 - kt_begin + 63) >> 6;
+  const int wq0 = q0 + wave * 32;  // first query row of this wave
+
+  const bf16_t* Kh = p.K + (size_t)hkv * p.k_tokens * HD;
+  const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
+
+  // ---- Q^T fragments (B operand), kept in registers
+  bf16x8 qf[2][DKS];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = min(wq0 + qb * 16 + l15, p.Sq - 1);
+    const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
+#pragma unroll
+    for (int ds = 0; ds < DKS; ++ds) {
+      const int d = ds * 32 + 8 * h;
+      u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
+      if (d < HD) raw = *(const u32x4*)(qp + d);
+      qf[qb][ds] = __builtin_bit_cast(bf16x8, raw);
+    }
+  }
+
+  // zero the d-padding chunks of both K buffers once (head_dim 80 only)
+  if (HD != 128) {
+    for (int it = tid; it < 2 * 64 * 2; it += 256) {
+      const int b = it >> 7, row = (it >> 1) & 63, c = KCH + (it & 1);
+      *(u32x4*)(lds + b * BUF + row * KROW + c * 16) = (u32x4){0u, 0u, 0u, 0u};
+    }
+  }
+
+  u32x4 kreg[K_ITERS], vreg[V_ITERS];
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < K_ITERS; ++i) {
+      const int it = tid + i * 256;
+      if (it < 64 * KCH) {
+        const int row = it / KCH, c = it - row * KCH;
+        const int key = min(kt + row, p.k_tokens - 1);
+        kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + c * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITERS; ++i) {
+      const int it = tid + i * 256;
+      if (it < HD * 8) {
+        const int d = it >> 3, c = it & 7;
+        vreg[i] = *(const u32x4*)(Vh + (size_t)d * p.vt_ld + kt + c * 8);
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* kb = lds + buf * BUF;
+    char* vb = kb + K_BYTES;
+#pragma unroll
+    for (int i = 0; i < K_ITERS; ++i) {
+      const int it = tid + i * 256;
+      if (it < 64 * KCH) {
+        const int row = it / KCH, c = it - row * KCH;
+        const int pc = (HD == 128) ? (c ^ (row & 15)) : c;
+        *(u32x4*)(kb + row * KROW + pc * 16) = kreg[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < V_ITERS; ++i) {
+      const int it = tid + i * 256;
+      if (it < HD * 8) {
+        const int d = it >> 3, c = it & 7;
+        *(u32x4*)(vb + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vreg[i];
+      }
+    }
+  };
+
+  f32x4 oacc[2][ND];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int nb = 0; nb < ND; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrow[2] = {ATT_NEG, ATT_NEG};
+  float lrow[2] = {0.f, 0.f};
+
+  if (nt > 0) {
+    load_tile(kt_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int kt = kt_begin + t * 64;
+    const bool more = (t + 1 < nt);
+    if (more) load_tile(kt + 64);
+
+    const bool active = !CAUSAL || (kt <= wq0 + 31);
+    if (active) {
+      const char* kb = lds + cur * BUF;
+      const char* vb = kb + K_BYTES;
+      // ---- S^T = K * Q^T
+      f32x4 sacc[4][2];
+#pragma unroll
+      for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) sacc[kbk][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < DKS; ++ds) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk) {
+          const int row = kbk * 16 + l15;
+          const int c = ds * 4 + h;
+          const int pc = (HD == 128) ? (c ^ l15) : c;
+          kf[kbk] = *(const bf16x8*)(kb + row * KROW + pc * 16);
+        }
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], sacc[kbk][qb], 0, 0, 0);
+      }
+
+      // ---- online softmax (query on the lane, keys in registers)
+      const bool need_mask = (kt < k0) || (kt + 64 > k1) || (CAUSAL && (kt + 63 > wq0));
+      float alpha[2];
+      bf16x8 pf[2][2];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int q = wq0 + qb * 16 + l15;
+        float mx = ATT_NEG;
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float s = sacc[kbk][qb][r] * p.scale_log2;
+            if (need_mask) {
+              const int key = kt + kbk * 16 + 4 * h + r;
+              const bool ok = (key >= k0) && (key < k1) && (!CAUSAL || key <= q);
+              s = ok ? s : ATT_NEG;
+            }
+            sacc[kbk][qb][r] = s;
+            mx = fmaxf(mx, s);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrow[qb], mx);
+        alpha[qb] = exp2f(mrow[qb] - mnew);
+        mrow[qb] = mnew;
+        float ls = 0.f;
+        float pv[4][4];
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = exp2f(sacc[kbk][qb][r] - mnew);
+            pv[kbk][r] = e;
+            ls += e;
+          }
+        lrow[qb] = lrow[qb] * alpha[qb] + ls;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 pk;
+          pk[0] = pack2bf(pv[2 * ks][0], pv[2 * ks][1]);
+          pk[1] = pack2bf(pv[2 * ks][2], pv[2 * ks][3]);
+          pk[2] = pack2bf(pv[2 * ks + 1][0], pv[2 * ks + 1][1]);
+          pk[3] = pack2bf(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
+          pf[ks][qb] = __builtin_bit_cast(bf16x8, pk);
+        }
+      }
+
+      // ---- rescale O (rows 4h+r of each q-block) when any running max moved
+      const bool resc = !__all((alpha[0] == 1.0f) && (alpha[1] == 1.0f));
+      if (resc) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(alpha[qb], 4 * h + r, 64);
+#pragma unroll
+            for (int nb = 0; nb < ND; ++nb) oacc[qb][nb][r] *= a;
+          }
+      }
+
+      // ---- O += P * V  (B operand from the V^T tile, permuted k-slots)
+      const int vsw = l15 & 14;
+#pragma unroll
+      for (int nb = 0; nb < ND; ++nb) {
+        const char* vrow = vb + (nb * 16 + l15) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const u32x2 lo = *(const u32x2*)(vrow + (((8 * ks + h) ^ vsw) << 3));
+          const u32x2 hi = *(const u32x2*)(vrow + (((8 * ks + 4 + h) ^ vsw) << 3));
+          const u32x4 vv = (u32x4){lo[0], lo[1], hi[0], hi[1]};
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+#pragma unroll
+          for (int qb = 0; qb < 2; ++qb)
+            oacc[qb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], vf, oacc[qb][nb], 0, 0, 0);
+        }
+      }
+    }
+
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- normalise, stage the wave's 32 x HD tile in LDS, store whole chunks
+  char* ost = lds + wave * 32 * OROW;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    float l = lrow[qb];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float a = __shfl(inv, 4 * h + r, 64);
+      const int row = qb * 16 + 4 * h + r;
+#pragma unroll
+      for (int nb = 0; nb < ND; ++nb)
+        *(bf16_t*)(ost + row * OROW + (nb * 16 + l15) * 2) = f2bf(oacc[qb][nb][r] * a);
+    }
+  }
+  __syncthreads();
+  for (int it = lane; it < 32 * KCH; it += 64) {
+    const int row = it / KCH, c = it - row * KCH;
+    const int q = wq0 + row;
+    if (q < q0 + qn) {
+      const u32x4 o = *(const u32x4*)(ost + row * OROW + c * 16);
+      *(u32x4*)(p.O + (size_t)q * p.ldo + head * HD + c * 8) = o;
+    }
+  }
+}
+
+extern "C" int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, const void* work,
+                                int n_work, int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo,
+                                int causal, float scale, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  if (HD != 128 && HD != 80) return VIS_ERR_ARG;
+  if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * HD) return VIS_ERR_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
+  AttnArgs p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.work = (const int4*)work;
+  p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  const dim3 grid(n_work, Hq), block(256);
+  if (HD == 128) {
+    if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, stream, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((attn_prefill_kernel<80, true>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((attn_prefill_kernel<80, false>), grid, block, 0, stream, p);
+  }
+  return vis_check_launch();
+}

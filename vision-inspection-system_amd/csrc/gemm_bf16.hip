@@ -1,0 +1,223 @@
+// K2: bf16 GEMM family for the Qwen2-VL prefill path on gfx950 (MI355X).
+//
+//   C[M,N] = act(A[M,K] * W[N,K]^T + bias[N]) + R[M,N]
+//
+// A is the row-major activation matrix, W is an nn.Linear weight ([out,in],
+// K-contiguous), so both MFMA operands are K-contiguous rows ("NT" GEMM) and
+// both are fetched with ds_read_b128.  Replaces the torch ops behind
+// TF:models/qwen2_vl/modeling_qwen2_vl.py:251-274 (patch-embed conv == GEMM),
+// :281-286 (merger), :296-298 (ViT MLP), :349-350 (ViT qkv/proj),
+// :459-466 (LLM MLP incl. SwiGLU), :501-504 (LLM q/k/v/o).
+//
+// Design (CDNA4):
+//  * 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave a 64x64
+//    output tile = 4x4 MFMA 16x16x32 bf16 tiles with f32 accumulators.
+//  * global -> LDS with global_load_lds_dwordx4 (16 B/lane, no VGPR staging).
+//    The LDS image is lane-linear, so the bank-conflict swizzle is applied on
+//    the per-lane SOURCE address: physical 16-B chunk c of row r holds logical
+//    chunk c ^ (r & 7); the ds_read applies the same XOR.  That makes every
+//    ds_read_b128 16-lane group hit 16 distinct 16-B slots (conflict-free).
+//  * double-buffered LDS (2 x 32 KiB) -> 2 workgroups per CU.
+//  * the MFMA is issued with W as the A operand and the activations as the B
+//    operand, so the accumulator holds 4 consecutive output COLUMNS per lane
+//    (D[row=n][col=m]) and the epilogue stores 8 contiguous bytes per lane.
+//  * fused epilogues: bias, QuickGELU, erf-GELU, residual add, SwiGLU over a
+//    gate/up weight interleaved in 16-row groups.
+//  * 1-D grid with a bijective XCD remap; all M-tiles that share one W panel
+//    are adjacent inside one XCD so the panel is read from HBM once.
+#include "common.hip.h"
+
+#define GEMM_BM 128
+#define GEMM_BN 128
+#define GEMM_BK 64
+
+enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_SWIGLU = 3 };
+
+struct GemmArgs {
+  const bf16_t* A;
+  const bf16_t* W;
+  const bf16_t* bias;  // [N] or null
+  const bf16_t* R;     // [M, ldr] residual or null
+  bf16_t* C;
+  int M, N, K;
+  int lda, ldw, ldc, ldr;
+  int act;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  if (act == ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  return x;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * (GEMM_BM + GEMM_BN) * GEMM_BK * 2];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
+
+  // ---- staging addresses: 4 A chunks + 4 W chunks of 16 B per thread per K-step
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 3;
+    const int ch = (c & 7) ^ (row & 7);  // logical chunk stored at this physical slot
+    const int am = min(m0 + row, p.M - 1);
+    const int wr = min(n0 + row, p.N - 1);
+    a_src[i] = p.A + (size_t)am * p.lda + ch * 8;
+    w_src[i] = p.W + (size_t)wr * p.ldw + ch * 8;
+  }
+  const int wave_base = (tid & ~63) * 16;
+  constexpr int A_BYTES = GEMM_BM * GEMM_BK * 2;  // 16 KiB
+  constexpr int BUF_BYTES = (GEMM_BM + GEMM_BN) * GEMM_BK * 2;
+
+  auto stage = [&](int buf) {
+    char* base = lds + buf * BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)a_src[i],
+          (__attribute__((address_space(3))) void*)(base + i * 4096 + wave_base), 16, 0, 0);
+      a_src[i] += GEMM_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)w_src[i],
+          (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096 + wave_base), 16, 0, 0);
+      w_src[i] += GEMM_BK;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane LDS read offsets (bytes) for k-substep 0/1; row&7 == lane&7
+  const int sw = lane & 7;
+  const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
+  const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
+  const int a_rd = wm * 64 * 128;            // + i*16*128
+  const int w_rd = A_BYTES + wn * 64 * 128;  // + j*16*128
+
+  const int nk = p.K / GEMM_BK;
+  stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* base = lds + cur * BUF_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int rd = ks ? rd1 : rd0;
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();  // also drains the in-flight global_load_lds (vmcnt(0))
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds D[n = 4h + r][m = l15] for r = 0..3
+  const bool swiglu = (p.act == ACT_SWIGLU);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + wm * 64 + i * 16 + l15;
+    if (m >= p.M) continue;
+    if (swiglu) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * h;  // gate row index in the interleaved weight
+        if (n >= p.N) continue;
+        const int oc = ((n0 + wn * 64) >> 1) + (j >> 1) * 16 + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[i][j][r], u = acc[i][j + 1][r];
+          v[r] = g / (1.0f + __expf(-g)) * u;
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + oc) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * h;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (p.bias) {
+          const u32x2 b = *(const u32x2*)(p.bias + n);
+          v[0] += __uint_as_float(b[0] << 16);
+          v[1] += __uint_as_float(b[0] & 0xffff0000u);
+          v[2] += __uint_as_float(b[1] << 16);
+          v[3] += __uint_as_float(b[1] & 0xffff0000u);
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
+        }
+        if (p.R) {
+          const u32x2 rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
+          v[0] += __uint_as_float(rr[0] << 16);
+          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rr[1] << 16);
+          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// C-ABI launcher (declared in include/vis_hip.h)
+extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, const void* R, void* C,
+                             int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
+                             hipStream_t stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % GEMM_BK != 0 || N % 4 != 0) return VIS_ERR_ARG;
+  if (lda % 8 != 0 || ldw % 8 != 0 || ldc % 4 != 0 || (R && ldr % 4 != 0)) return VIS_ERR_ARG;
+  if (act < ACT_NONE || act > ACT_SWIGLU) return VIS_ERR_ARG;
+  if (act == ACT_SWIGLU && (N % 32 != 0 || bias || R)) return VIS_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 7) return VIS_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)W) & 15) return VIS_ERR_ARG;
+  GemmArgs p;
+  p.A = (const bf16_t*)A;
+  p.W = (const bf16_t*)W;
+  p.bias = (const bf16_t*)bias;
+  p.R = (const bf16_t*)R;
+  p.C = (bf16_t*)C;
+  p.M = M; p.N = N; p.K = K;
+  p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+  p.act = act;
+  p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+  p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  const int nwg = p.tiles_m * p.tiles_n;
+  hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(nwg), dim3(256), 0, stream, p);
+  return vis_check_launch();
+}

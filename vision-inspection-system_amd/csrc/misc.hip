@@ -1,0 +1,116 @@
+// K1 front half and K12 glue for gfx950: patch extraction (u8 frame -> normalised
+// bf16 patch rows), embedding row gather, image-token row scatter.
+// All HBM-bound row movers; 16-byte accesses per lane.
+#include "common.hip.h"
+
+// ---------------------------------------------------------------------------
+// vis_patchify_u8: the resized RGB frame [H][W][3] u8 (H, W multiples of 28)
+// becomes pixel_values rows in exactly the layout of
+// TF:models/qwen2_vl/image_processing_pil_qwen2_vl.py:156-190 (patchify):
+//   row  p = ((gh/2)*(GW/2) + gw/2)*4 + (gh%2)*2 + (gw%2)      (2x2 merge groups)
+//   col  f = ((c*2 + t)*14 + ph)*14 + pw, t = temporal copy (both frames equal)
+// with rescale 1/255 and CLIP mean/std normalisation fused in, rounded to bf16,
+// and the row zero-padded from 1176 to ld_out (a multiple of the GEMM K-step)
+// so the patch-embed conv (TF:...modeling_qwen2_vl.py:251-274) is one K2 GEMM.
+struct PatchArgs {
+  const uint8_t* img;
+  bf16_t* out;
+  int H, W, ld_out, row0;
+  float mean[3], istd[3];
+};
+
+__global__ __launch_bounds__(256) void patchify_u8_kernel(PatchArgs p) {
+  constexpr int P = 14, F = 3 * 2 * P * P;  // 1176
+  const int GW = p.W / P;
+  const int chunks = p.ld_out >> 3;
+  const int np = (p.H / P) * GW;
+  const long long total = (long long)np * chunks;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int patch = (int)(it / chunks), ch = (int)(it - (long long)patch * chunks);
+    const int grp = patch >> 2, mh = (patch >> 1) & 1, mw = patch & 1;
+    const int gh = (grp / (GW >> 1)) * 2 + mh, gw = (grp % (GW >> 1)) * 2 + mw;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = ch * 8 + e;
+      float v = 0.f;
+      if (f < F) {
+        const int c = f / (2 * P * P);
+        const int rem = f - c * (2 * P * P);
+        const int pp = rem % (P * P);  // temporal index dropped: both frames are the same image
+        const int ph = pp / P, pw = pp - ph * P;
+        const int y = gh * P + ph, x = gw * P + pw;
+        const float u = (float)p.img[((size_t)y * p.W + x) * 3 + c];
+        v = (u * (1.0f / 255.0f) - p.mean[c]) * p.istd[c];
+      }
+      o[e] = v;
+    }
+    *(u32x4*)(p.out + (size_t)(p.row0 + patch) * p.ld_out + ch * 8) = pack8(o);
+  }
+}
+
+extern "C" int vis_patchify_u8(const void* img, void* out, int H, int W, int ld_out, int row0, const float* mean,
+                               const float* stdv, hipStream_t stream) {
+  if (!img || !out || !mean || !stdv || H <= 0 || W <= 0) return VIS_ERR_ARG;
+  if (H % 28 != 0 || W % 28 != 0 || ld_out % 8 != 0 || ld_out < 1176 || row0 < 0) return VIS_ERR_ARG;
+  if ((uintptr_t)out & 15) return VIS_ERR_ARG;
+  PatchArgs p;
+  p.img = (const uint8_t*)img; p.out = (bf16_t*)out; p.H = H; p.W = W; p.ld_out = ld_out; p.row0 = row0;
+  for (int c = 0; c < 3; ++c) {
+    if (!(stdv[c] > 0.f)) return VIS_ERR_ARG;
+    p.mean[c] = mean[c];
+    p.istd[c] = 1.0f / stdv[c];
+  }
+  const long long total = (long long)(H / 14) * (W / 14) * (ld_out / 8);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(patchify_u8_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  return vis_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// vis_gather_rows:  out[i][:] = table[ids[i]][:]       (embedding lookup; ids on device)
+// vis_scatter_rows: dst[idx[i]][:] = src[i][:]         (masked_scatter of the merger output
+//                   into the text embeddings, TF:...modeling_qwen2_vl.py:1144-1200)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ table,
+                                                          const int* __restrict__ ids, bf16_t* __restrict__ out,
+                                                          int n, int D, int n_table) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int id = ids[row];
+  id = id < 0 ? 0 : (id >= n_table ? n_table - 1 : id);
+  const bf16_t* src = table + (size_t)id * D;
+  bf16_t* dst = out + (size_t)row * D;
+  for (int c = lane; c < (D >> 3); c += 64) *(u32x4*)(dst + c * 8) = *(const u32x4*)(src + c * 8);
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ src,
+                                                           const int* __restrict__ idx, bf16_t* __restrict__ dst,
+                                                           int n, int D, int n_dst) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  const int t = idx[row];
+  if (t < 0 || t >= n_dst) return;
+  const bf16_t* s = src + (size_t)row * D;
+  bf16_t* d = dst + (size_t)t * D;
+  for (int c = lane; c < (D >> 3); c += 64) *(u32x4*)(d + c * 8) = *(const u32x4*)(s + c * 8);
+}
+
+extern "C" int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D, int n_table,
+                               hipStream_t stream) {
+  if (!table || !ids || !out || n <= 0 || D <= 0 || D % 8 != 0 || n_table <= 0) return VIS_ERR_ARG;
+  if (((uintptr_t)table | (uintptr_t)out) & 15) return VIS_ERR_ARG;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const bf16_t*)table,
+                     (const int*)ids, (bf16_t*)out, n, D, n_table);
+  return vis_check_launch();
+}
+
+extern "C" int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
+                                hipStream_t stream) {
+  if (!src || !idx || !dst || n <= 0 || D <= 0 || D % 8 != 0 || n_dst <= 0) return VIS_ERR_ARG;
+  if (((uintptr_t)src | (uintptr_t)dst) & 15) return VIS_ERR_ARG;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const bf16_t*)src,
+                     (const int*)idx, (bf16_t*)dst, n, D, n_dst);
+  return vis_check_launch();
+}
+
+extern "C" int vis_abi_version(void) { return 1; }

@@ -1,0 +1,108 @@
+// K3 RMSNorm (TF:models/qwen2_vl/modeling_qwen2_vl.py:96-110) and K5 LayerNorm
+// (ViT norm1/norm2 :428-429, merger ln_q :281) for gfx950.
+//
+// HBM-bound row kernels: one 64-lane wave per row, 16-byte (8 x bf16) loads,
+// the row is held in registers between the reduction and the normalise pass
+// so each element is read from HBM exactly once.  f32 statistics, bf16 I/O.
+// Algorithmic bytes: 2*N*2 B per row (+ the affine vectors, L2-resident).
+#include "common.hip.h"
+
+#define NORM_MAX_CHUNKS 10  // per lane: supports N <= 64*8*10 = 5120
+
+template <bool LAYERNORM>
+__global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict__ x,
+                                                        const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b,
+                                                        bf16_t* __restrict__ y, int rows, int N,
+                                                        int ldx, int ldy, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = N >> 3;  // 16-byte chunks per row
+  const bf16_t* xr = x + (size_t)row * ldx;
+  float v[NORM_MAX_CHUNKS][8];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      const u32x4 raw = *(const u32x4*)(xr + c * 8);
+      unpack8(raw, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s += v[i][e];
+        ss += v[i][e] * v[i][e];
+      }
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const float inv_n = 1.0f / (float)N;
+  float mean = 0.f, rstd;
+  if (LAYERNORM) {
+    mean = s * inv_n;
+    // two-pass variance from registers (no cancellation)
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mean;
+          d2 += d * d;
+        }
+      }
+    }
+    d2 = wave_sum(d2);
+    rstd = rsqrtf(d2 * inv_n + eps);
+  } else {
+    rstd = rsqrtf(ss * inv_n + eps);
+  }
+  bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float wv[8], o[8];
+      unpack8(*(const u32x4*)(w + c * 8), wv);
+      if (LAYERNORM) {
+        float bv[8];
+        unpack8(*(const u32x4*)(b + c * 8), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      } else {
+        // HF rounds the normalised value to the input dtype before the weight multiply
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[i][e] * rstd)) * wv[e];
+      }
+      *(u32x4*)(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
+static int norm_launch(bool ln, const void* x, const void* w, const void* b, void* y, int rows, int N,
+                       int ldx, int ldy, float eps, hipStream_t stream) {
+  if (!x || !w || !y || rows <= 0 || N <= 0) return VIS_ERR_ARG;
+  if (N % 8 != 0 || N > 64 * 8 * NORM_MAX_CHUNKS || ldx % 8 != 0 || ldy % 8 != 0) return VIS_ERR_ARG;
+  if (ln && !b) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)b) & 15) return VIS_ERR_ARG;
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (ln)
+    hipLaunchKernelGGL(norm_rows_kernel<true>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w,
+                       (const bf16_t*)b, (bf16_t*)y, rows, N, ldx, ldy, eps);
+  else
+    hipLaunchKernelGGL(norm_rows_kernel<false>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w,
+                       (const bf16_t*)nullptr, (bf16_t*)y, rows, N, ldx, ldy, eps);
+  return vis_check_launch();
+}
+
+extern "C" int vis_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int N, int ldx, int ldy,
+                                float eps, hipStream_t stream) {
+  return norm_launch(false, x, w, nullptr, y, rows, N, ldx, ldy, eps, stream);
+}
+
+extern "C" int vis_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int N,
+                                  int ldx, int ldy, float eps, hipStream_t stream) {
+  return norm_launch(true, x, w, b, y, rows, N, ldx, ldy, eps, stream);
+}

@@ -1,0 +1,183 @@
+// K4: rotary embedding + head split (+ KV-cache write, + V transpose) for gfx950.
+//
+// One kernel serves both towers:
+//  * LLM M-RoPE  (TF:models/qwen2_vl/modeling_qwen2_vl.py:180-222): the host
+//    builds the per-token cos/sin rows [S, head_dim] f32 with the (t,h,w)
+//    section already selected per channel (exactly what
+//    apply_multimodal_rotary_pos_emb assembles from cos.split(mrope_section*2));
+//  * ViT 2-D RoPE (TF:...:225-236): cos/sin rows [N, 80] f32 from (h,w) ids.
+// In both cases  out = x*cos + rotate_half(x)*sin  over the full head_dim,
+// computed in f32 and rounded to bf16 once.
+//
+// Input  : packed projection rows  qkv[S, (Hq+2*Hkv)*HD]  (bias already added
+//          by the GEMM epilogue).
+// Outputs: Q  [Hq ][S][HD]                     (rotated, head-major for attention)
+//          K  [Hkv][k_tokens][HD] at row k_pos0+s (rotated; the LLM passes its
+//             KV-cache layer here so prefill writes the cache in place)
+//          V  [Hkv][k_tokens][HD] at row k_pos0+s (optional row-major copy: KV cache)
+//          Vt [Hkv][HD][vt_ld]   (optional; keys contiguous - the PV operand
+//             layout of the prefill attention kernel; pad columns zeroed)
+// HBM-bound: every qkv element is read once and written once (V twice).
+#include "common.hip.h"
+
+struct RopeArgs {
+  const bf16_t* qkv;
+  const float* cosv;
+  const float* sinv;
+  bf16_t* q;
+  bf16_t* k;
+  bf16_t* v;
+  bf16_t* vt;
+  int S, ld_qkv, Hq, Hkv;
+  int k_tokens;  // rows per head in k/v outputs
+  int k_pos0;    // first row written in k/v outputs
+  int vt_ld;     // row stride of Vt (multiple of 64, >= round_up(S, 64))
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p) {
+  constexpr int HALF = HD / 2;
+  constexpr int PC = HD / 16;  // pair-chunks per (token, head): 8 dims + their rotate_half partners
+  constexpr int CH = HD / 8;   // 16-byte chunks per (token, head)
+  constexpr int VT_LD = 64 + 8;
+  __shared__ __attribute__((aligned(16))) bf16_t tile[HD * VT_LD];
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.x * 64;
+  const int head = blockIdx.y;
+  const int ntok = min(64, p.S - s0);
+
+  if (head < p.Hq + p.Hkv) {
+    const bool is_q = head < p.Hq;
+    const int hh = is_q ? head : head - p.Hq;
+    for (int it = tid; it < 64 * PC; it += 256) {
+      const int t = it / PC, pc = it - t * PC;
+      if (t >= ntok) continue;
+      const int s = s0 + t;
+      const int d0 = pc * 8;
+      const bf16_t* src = p.qkv + (size_t)s * p.ld_qkv + head * HD;
+      float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
+      unpack8(*(const u32x4*)(src + d0), a);
+      unpack8(*(const u32x4*)(src + HALF + d0), b);
+      const float* cr = p.cosv + (size_t)s * HD;
+      const float* sr = p.sinv + (size_t)s * HD;
+#pragma unroll
+      for (int e = 0; e < 8; e += 4) {
+        *(f32x4*)(ca + e) = *(const f32x4*)(cr + d0 + e);
+        *(f32x4*)(sa + e) = *(const f32x4*)(sr + d0 + e);
+        *(f32x4*)(cb + e) = *(const f32x4*)(cr + HALF + d0 + e);
+        *(f32x4*)(sb + e) = *(const f32x4*)(sr + HALF + d0 + e);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        oa[e] = a[e] * ca[e] - b[e] * sa[e];  // first half: rotate_half gives -x2
+        ob[e] = b[e] * cb[e] + a[e] * sb[e];  // second half: rotate_half gives +x1
+      }
+      bf16_t* dst = is_q ? p.q + ((size_t)hh * p.S + s) * HD
+                         : p.k + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD;
+      *(u32x4*)(dst + d0) = pack8(oa);
+      *(u32x4*)(dst + HALF + d0) = pack8(ob);
+    }
+  } else {
+    const int hh = head - p.Hq - p.Hkv;
+    for (int it = tid; it < 64 * CH; it += 256) {
+      const int t = it / CH, c = it - t * CH;
+      u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
+      if (t < ntok) {
+        const int s = s0 + t;
+        raw = *(const u32x4*)(p.qkv + (size_t)s * p.ld_qkv + head * HD + c * 8);
+        if (p.v) *(u32x4*)(p.v + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD + c * 8) = raw;
+      }
+      if (p.vt) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          tile[(c * 8 + 2 * e) * VT_LD + t] = (bf16_t)(raw[e] & 0xffffu);
+          tile[(c * 8 + 2 * e + 1) * VT_LD + t] = (bf16_t)(raw[e] >> 16);
+        }
+      }
+    }
+    if (p.vt) {
+      __syncthreads();
+      for (int it = tid; it < HD * 8; it += 256) {
+        const int d = it >> 3, c = it & 7;
+        const u32x4 o = *(const u32x4*)(tile + d * VT_LD + c * 8);
+        *(u32x4*)(p.vt + ((size_t)hh * HD + d) * p.vt_ld + s0 + c * 8) = o;
+      }
+    }
+  }
+}
+
+extern "C" int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void* q, void* k,
+                                  void* v, void* vt, int S, int ld_qkv, int Hq, int Hkv, int HD,
+                                  int k_tokens, int k_pos0, int vt_ld, hipStream_t stream) {
+  if (!qkv || !cosv || !sinv || !q || !k || S <= 0 || Hq <= 0 || Hkv <= 0) return VIS_ERR_ARG;
+  if (HD != 128 && HD != 80) return VIS_ERR_ARG;
+  if (ld_qkv % 8 != 0 || ld_qkv < (Hq + 2 * Hkv) * HD) return VIS_ERR_ARG;
+  if (k_pos0 < 0 || k_pos0 + S > k_tokens) return VIS_ERR_ARG;
+  if (vt && (vt_ld % 64 != 0 || vt_ld < ((S + 63) / 64) * 64)) return VIS_ERR_ARG;
+  if (((uintptr_t)qkv | (uintptr_t)cosv | (uintptr_t)sinv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v |
+       (uintptr_t)vt) & 15)
+    return VIS_ERR_ARG;
+  RopeArgs p;
+  p.qkv = (const bf16_t*)qkv; p.cosv = (const float*)cosv; p.sinv = (const float*)sinv;
+  p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.v = (bf16_t*)v; p.vt = (bf16_t*)vt;
+  p.S = S; p.ld_qkv = ld_qkv; p.Hq = Hq; p.Hkv = Hkv;
+  p.k_tokens = k_tokens; p.k_pos0 = k_pos0; p.vt_ld = vt_ld;
+  const dim3 grid((S + 63) / 64, Hq + 2 * Hkv), block(256);
+  if (HD == 128)
+    hipLaunchKernelGGL(qkv_rope_split_kernel<128>, grid, block, 0, stream, p);
+  else
+    hipLaunchKernelGGL(qkv_rope_split_kernel<80>, grid, block, 0, stream, p);
+  return vis_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Decode step: one new token per sequence.  Rotates q and k of the packed
+// projection row, writes q (f32-accurate bf16) to q_out[Hq][HD] and appends the
+// rotated k and the v row to the KV cache at slot  slot_base + *step.
+// The position comes from DEVICE memory so the launch can sit in a hipGraph
+// that is replayed for every generated token.
+// cos/sin tables: [max_new_tokens][HD] f32, row *step.
+__global__ __launch_bounds__(256) void decode_rope_kv_kernel(const bf16_t* __restrict__ qkv,
+                                                             const float* __restrict__ cos_t,
+                                                             const float* __restrict__ sin_t,
+                                                             const int* __restrict__ step_ptr,
+                                                             bf16_t* __restrict__ q_out,
+                                                             bf16_t* __restrict__ k_cache,
+                                                             bf16_t* __restrict__ v_cache, int Hq, int Hkv,
+                                                             int cache_tokens, int slot_base) {
+  constexpr int HD = 128, HALF = 64;
+  const int step = *step_ptr;
+  const int slot = slot_base + step;
+  if (slot >= cache_tokens) return;
+  const float* cr = cos_t + (size_t)step * HD;
+  const float* sr = sin_t + (size_t)step * HD;
+  const int nrot = (Hq + Hkv) * HALF;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrot + Hkv * HD; i += gridDim.x * blockDim.x) {
+    if (i < nrot) {
+      const int head = i / HALF, d = i - head * HALF;
+      const float a = bf2f(qkv[head * HD + d]), b = bf2f(qkv[head * HD + HALF + d]);
+      const float oa = a * cr[d] - b * sr[d];
+      const float ob = b * cr[HALF + d] + a * sr[HALF + d];
+      bf16_t* dst = head < Hq ? q_out + head * HD
+                              : k_cache + ((size_t)(head - Hq) * cache_tokens + slot) * HD;
+      dst[d] = f2bf(oa);
+      dst[HALF + d] = f2bf(ob);
+    } else {
+      const int j = i - nrot;
+      const int hh = j / HD, d = j - hh * HD;
+      v_cache[((size_t)hh * cache_tokens + slot) * HD + d] = qkv[(Hq + Hkv + hh) * HD + d];
+    }
+  }
+}
+
+extern "C" int vis_decode_rope_kv(const void* qkv, const void* cos_t, const void* sin_t, const void* step_ptr,
+                                  void* q_out, void* k_cache, void* v_cache, int Hq, int Hkv, int HD,
+                                  int cache_tokens, int slot_base, hipStream_t stream) {
+  if (!qkv || !cos_t || !sin_t || !step_ptr || !q_out || !k_cache || !v_cache) return VIS_ERR_ARG;
+  if (HD != 128 || Hq <= 0 || Hkv <= 0 || slot_base < 0 || slot_base >= cache_tokens) return VIS_ERR_ARG;
+  const int total = (Hq + Hkv) * 64 + Hkv * 128;
+  hipLaunchKernelGGL(decode_rope_kv_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
+                     (const bf16_t*)qkv, (const float*)cos_t, (const float*)sin_t, (const int*)step_ptr,
+                     (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, Hq, Hkv, cache_tokens, slot_base);
+  return vis_check_launch();
+}

@@ -1,0 +1,287 @@
+"""ctypes binding of ``csrc/libvis_hip.so`` (C ABI: ``include/vis_hip.h``).
+
+PyTorch-ROCm is plumbing here: it owns device memory and the HIP stream; every
+arithmetic op of the hot path is one of the ``vis_*`` entry points below.  There
+is deliberately NO fallback: if the shared library is missing or an entry point
+reports an error, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libvis_hip.so")
+
+ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
+
+# name -> argtypes; every entry point returns int. 'p' = pointer, 'i' = int, 'f' = float
+_SIGS = {
+    "vis_abi_version": "",
+    "vis_gemm_bf16": "ppppp" + "iiiiiiii" + "p",
+    "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
+    "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
+    "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
+    "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
+    "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
+    "vis_decode_rope_kv": "ppppppp" + "iiiii" + "p",
+    "vis_decode_attn": "ppppppp" + "iiiiii" + "f" + "p",
+    "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "p",
+    "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
+    "vis_gather_rows": "ppp" + "iii" + "p",
+    "vis_scatter_rows": "ppp" + "iii" + "p",
+}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float}
+
+
+class HipLibraryError(RuntimeError):
+    """The gfx950 extension is missing or an entry point rejected its arguments."""
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def exported_symbols() -> list:
+    return list(_SIGS)
+
+
+def load() -> ctypes.CDLL:
+    """Load libvis_hip.so (once).  Raises HipLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `make -C {_CSRC}` (or __graft_entry__.build()); "
+            "this package has no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError here means header and library disagree
+        fn.restype = ctypes.c_int
+        fn.argtypes = [_CT[c] for c in sig]
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, name: str) -> None:
+    if rc != 0:
+        why = {1: "argument/shape/alignment precondition violated", 2: "HIP launch error"}.get(rc, "unknown")
+        raise HipLibraryError(f"{name} failed with status {rc} ({why})")
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("device tensor required (no CPU path exists)")
+    return t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _bf16(t: torch.Tensor, name: str) -> None:
+    if t.dtype != torch.bfloat16:
+        raise HipLibraryError(f"{name}: bf16 tensor required, got {t.dtype}")
+
+
+# --------------------------------------------------------------------------- K2
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M,N(/2)] = act(a[M,K] @ w[N,K].T + bias) + residual."""
+    _bf16(a, "gemm a"); _bf16(w, "gemm w")
+    M, K = a.shape
+    N, K2 = w.shape
+    if K != K2 or a.stride(1) != 1 or w.stride(1) != 1:
+        raise HipLibraryError(f"gemm: bad operand shapes/strides {tuple(a.shape)} x {tuple(w.shape)}")
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.bfloat16, device=a.device)
+    if out.shape != (M, n_out) or out.stride(1) != 1:
+        raise HipLibraryError("gemm: bad output shape")
+    if residual is not None and (residual.shape != (M, N) or residual.stride(1) != 1):
+        raise HipLibraryError("gemm: bad residual shape")
+    if bias is not None and bias.numel() != N:
+        raise HipLibraryError("gemm: bad bias shape")
+    rc = load().vis_gemm_bf16(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), M, N, K,
+                              a.stride(0), w.stride(0), out.stride(0),
+                              residual.stride(0) if residual is not None else 0, act, _stream())
+    _check(rc, "vis_gemm_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- K3 / K5
+def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16(x, "rmsnorm x")
+    rows, N = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    rc = load().vis_rmsnorm_bf16(_ptr(x), _ptr(w), _ptr(out), rows, N, x.stride(0), out.stride(0), eps, _stream())
+    _check(rc, "vis_rmsnorm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _bf16(x, "layernorm x")
+    rows, N = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    rc = load().vis_layernorm_bf16(_ptr(x), _ptr(w), _ptr(b), _ptr(out), rows, N, x.stride(0), out.stride(0),
+                                   eps, _stream())
+    _check(rc, "vis_layernorm_bf16")
+    return out
+
+
+# --------------------------------------------------------------------------- K4
+def qkv_rope_split(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, q: torch.Tensor,
+                   k: torch.Tensor, v: Optional[torch.Tensor], vt: Optional[torch.Tensor],
+                   n_q: int, n_kv: int, head_dim: int, k_pos0: int = 0) -> None:
+    """qkv [S, (Hq+2Hkv)*HD] -> q [Hq,S,HD], k/v [Hkv,T,HD] rows k_pos0.., vt [Hkv,HD,ld]."""
+    _bf16(qkv, "qkv")
+    S = qkv.shape[0]
+    if cos.dtype != torch.float32 or cos.shape != (S, head_dim) or sin.shape != (S, head_dim):
+        raise HipLibraryError("qkv_rope_split: cos/sin must be f32 [S, head_dim]")
+    if not (cos.is_contiguous() and sin.is_contiguous() and q.is_contiguous() and k.is_contiguous()):
+        raise HipLibraryError("qkv_rope_split: contiguous tensors required")
+    if q.shape != (n_q, S, head_dim) or k.shape[0] != n_kv or k.shape[2] != head_dim:
+        raise HipLibraryError("qkv_rope_split: bad q/k shapes")
+    if v is not None and (v.shape != k.shape or not v.is_contiguous()):
+        raise HipLibraryError("qkv_rope_split: bad v shape")
+    vt_ld = 0
+    if vt is not None:
+        if vt.shape[0] != n_kv or vt.shape[1] != head_dim or not vt.is_contiguous():
+            raise HipLibraryError("qkv_rope_split: bad vt shape")
+        vt_ld = vt.shape[2]
+    rc = load().vis_qkv_rope_split(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(q), _ptr(k), _ptr(v), _ptr(vt),
+                                   S, qkv.stride(0), n_q, n_kv, head_dim, k.shape[1], k_pos0, vt_ld, _stream())
+    _check(rc, "vis_qkv_rope_split")
+
+
+# --------------------------------------------------------------------------- K6 / K7
+def make_attn_work(segments, causal: bool, device, block_q: int = 128) -> torch.Tensor:
+    """Work list for attn_prefill: segments = [(start, end)] of independent token ranges.
+
+    Each item {q0, qn, k0, k1}: queries [q0, q0+qn) attend keys [k0, k1) (and key <= query
+    when causal).  Heavy (late) causal tiles are listed first so they are dispatched first.
+    """
+    items = []
+    for (s, e) in segments:
+        for q0 in range(s, e, block_q):
+            items.append((q0, min(block_q, e - q0), s, e))
+    if causal:
+        items.sort(key=lambda it: -(it[0] + it[1]))
+    return torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+
+
+def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
+                 causal: bool, scale: float) -> torch.Tensor:
+    """q [Hq,S,HD], k [Hkv,T,HD], vt [Hkv,HD,ld] -> out [S, Hq*HD]."""
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
+    Hq, S, HD = q.shape
+    Hkv, T, _ = k.shape
+    if not (q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()):
+        raise HipLibraryError("attn_prefill: contiguous tensors required")
+    if vt.shape[0] != Hkv or vt.shape[1] != HD or out.shape[0] != S or out.stride(1) != 1:
+        raise HipLibraryError("attn_prefill: bad shapes")
+    if work.dtype != torch.int32 or work.dim() != 2 or work.shape[1] != 4 or not work.is_contiguous():
+        raise HipLibraryError("attn_prefill: work must be int32 [n,4]")
+    rc = load().vis_attn_prefill(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
+                                 S, T, vt.shape[2], out.stride(0), 1 if causal else 0, scale, _stream())
+    _check(rc, "vis_attn_prefill")
+    return out
+
+
+# --------------------------------------------------------------------------- K10 / K11 / K12
+def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
+    _bf16(x, "gemv x"); _bf16(w, "gemv w")
+    N, K = w.shape
+    if x.numel() != K or w.stride(1) != 1:
+        raise HipLibraryError("gemv: bad shapes")
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if out.numel() != n_out or out.dtype not in (torch.bfloat16, torch.float32):
+        raise HipLibraryError("gemv: bad output")
+    rc = load().vis_gemv_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(out), N, K,
+                              w.stride(0), act, 1 if out.dtype == torch.float32 else 0, eps, _stream())
+    _check(rc, "vis_gemv_bf16")
+    return out
+
+
+def decode_rope_kv(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, step: torch.Tensor,
+                   q_out: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int,
+                   head_dim: int, slot_base: int) -> None:
+    if step.dtype != torch.int32 or cos_t.dtype != torch.float32:
+        raise HipLibraryError("decode_rope_kv: step int32 / cos f32 required")
+    if k_cache.shape[0] != n_kv or k_cache.shape[2] != head_dim or not k_cache.is_contiguous():
+        raise HipLibraryError("decode_rope_kv: bad cache shape")
+    rc = load().vis_decode_rope_kv(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(step), _ptr(q_out), _ptr(k_cache),
+                                   _ptr(v_cache), n_q, n_kv, head_dim, k_cache.shape[1], slot_base, _stream())
+    _check(rc, "vis_decode_rope_kv")
+
+
+def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, step: torch.Tensor,
+                part_o: torch.Tensor, part_ml: torch.Tensor, out: torch.Tensor, n_q: int, n_kv: int,
+                head_dim: int, slot_base: int, nsplit: int, scale: float) -> torch.Tensor:
+    if part_o.dtype != torch.float32 or part_o.numel() < n_q * nsplit * head_dim or part_ml.numel() < n_q * nsplit * 2:
+        raise HipLibraryError("decode_attn: workspace too small")
+    rc = load().vis_decode_attn(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(part_o), _ptr(part_ml),
+                                _ptr(out), n_q, n_kv, head_dim, k_cache.shape[1], slot_base, nsplit, scale,
+                                _stream())
+    _check(rc, "vis_decode_attn")
+    return out
+
+
+def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tokens: torch.Tensor,
+           cur_token: torch.Tensor, step: torch.Tensor) -> None:
+    if logits.dtype != torch.float32 or tokens.dtype != torch.int32 or cur_token.dtype != torch.int32:
+        raise HipLibraryError("argmax: f32 logits / int32 tokens required")
+    if ws_val.numel() < 256 or ws_idx.numel() < 256:
+        raise HipLibraryError("argmax: workspace too small")
+    rc = load().vis_argmax_f32(_ptr(logits), logits.numel(), _ptr(ws_val), _ptr(ws_idx), _ptr(tokens),
+                               tokens.numel(), _ptr(cur_token), _ptr(step), _stream())
+    _check(rc, "vis_argmax_f32")
+
+
+_MEAN = (ctypes.c_float * 3)()
+_STD = (ctypes.c_float * 3)()
+
+
+def patchify(img_u8: torch.Tensor, out: torch.Tensor, row0: int, mean, std) -> None:
+    """img_u8 [H,W,3] uint8 (device) -> out[row0 + p, :] normalised bf16 patch rows."""
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or img_u8.shape[2] != 3 or not img_u8.is_contiguous():
+        raise HipLibraryError("patchify: uint8 [H,W,3] contiguous required")
+    H, W, _ = img_u8.shape
+    n = (H // 14) * (W // 14)
+    if row0 + n > out.shape[0]:
+        raise HipLibraryError("patchify: output too small")
+    for i in range(3):
+        _MEAN[i] = mean[i]
+        _STD[i] = std[i]
+    rc = load().vis_patchify_u8(_ptr(img_u8), _ptr(out), H, W, out.stride(0), row0,
+                                ctypes.cast(_MEAN, ctypes.c_void_p), ctypes.cast(_STD, ctypes.c_void_p), _stream())
+    _check(rc, "vis_patchify_u8")
+
+
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    if ids.dtype != torch.int32 or not table.is_contiguous() or not out.is_contiguous():
+        raise HipLibraryError("gather_rows: int32 ids and contiguous tensors required")
+    rc = load().vis_gather_rows(_ptr(table), _ptr(ids), _ptr(out), ids.numel(), table.shape[1], table.shape[0],
+                                _stream())
+    _check(rc, "vis_gather_rows")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    if idx.dtype != torch.int32 or not src.is_contiguous() or not dst.is_contiguous():
+        raise HipLibraryError("scatter_rows: int32 idx and contiguous tensors required")
+    rc = load().vis_scatter_rows(_ptr(src), _ptr(idx), _ptr(dst), idx.numel(), src.shape[1], dst.shape[0],
+                                 _stream())
+    _check(rc, "vis_scatter_rows")
+    return dst
