@@ -32,11 +32,14 @@ struct GemvArgs {
   float eps;
 };
 
+// NB: __builtin_bit_cast(bf16x2, v[i]) on a vector ELEMENT is miscompiled by hipcc 7.2 (always
+// element 0); extract the bf16 pairs with shufflevector from a whole-vector bit_cast instead.
 __device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float acc) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, w[i]), __builtin_bit_cast(bf16x2, x[i]), acc,
-                                          false);
+  const bf16x8 wv = __builtin_bit_cast(bf16x8, w), xv = __builtin_bit_cast(bf16x8, x);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 0, 1), __builtin_shufflevector(xv, xv, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 2, 3), __builtin_shufflevector(xv, xv, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 4, 5), __builtin_shufflevector(xv, xv, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(wv, wv, 6, 7), __builtin_shufflevector(xv, xv, 6, 7), acc, false);
   return acc;
 }
 
@@ -98,8 +101,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
       u32x4 wa[4], wb[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        wa[u] = __builtin_nontemporal_load((const u32x4*)(w0 + (c + 64 * u) * 8));
-        wb[u] = __builtin_nontemporal_load((const u32x4*)(w1 + (c + 64 * u) * 8));
+        wa[u] = *(const u32x4*)(w0 + (c + 64 * u) * 8);
+        wb[u] = *(const u32x4*)(w1 + (c + 64 * u) * 8);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
       }
     }
     for (; c < nch; c += 64) {
-      const u32x4 wa = __builtin_nontemporal_load((const u32x4*)(w0 + c * 8));
-      const u32x4 wb = __builtin_nontemporal_load((const u32x4*)(w1 + c * 8));
+      const u32x4 wa = *(const u32x4*)(w0 + c * 8);
+      const u32x4 wb = *(const u32x4*)(w1 + c * 8);
       const u32x4 xv = *(const u32x4*)(xs + c * 8);
       a0 = dot8(wa, xv, a0);
       a1 = dot8(wb, xv, a1);
