@@ -283,7 +283,7 @@ def embed_inputs(cfg: RefConfig, sd, input_ids: Sequence[int], image_embeds: Opt
 def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[int],
              pixel_values: Optional[torch.Tensor], grids, max_new_tokens: int,
              eos_ids: Sequence[int] = (), taps: Optional[dict] = None):
-    """Greedy decode.  Returns (tokens, first-step logits [vocab])."""
+    """Greedy decode.  Returns (tokens, per-step logits list [vocab] - entry t produced token t)."""
     img = vision_forward(cfg, sd, pixel_values, grids, taps) if pixel_values is not None else None
     x = embed_inputs(cfg, sd, input_ids, img)
     pos3, next_pos = rope_index(cfg, input_ids, grids or [])
@@ -296,9 +296,10 @@ def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[in
     if taps is not None:
         taps["final_norm_last"] = h[-1].clone()
     logits = h[-1] @ sd["lm_head.weight"].t()
-    first_logits = logits.clone()
     out: List[int] = []
+    all_logits: List[torch.Tensor] = []
     for t in range(max_new_tokens):
+        all_logits.append(logits.clone())
         tok = int(torch.argmax(logits))
         out.append(tok)
         if tok in eos_ids or t + 1 == max_new_tokens:
@@ -307,4 +308,4 @@ def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[in
         c, s = mrope_cos_sin(cfg, p)
         h = text_forward(cfg, sd, sd["model.embed_tokens.weight"][tok][None, :], c, s, cache)
         logits = h[-1] @ sd["lm_head.weight"].t()
-    return out, first_logits
+    return out, all_logits

@@ -1,0 +1,97 @@
+"""End-to-end parity on MI355X: HIP engine (bf16 kernels through the C ABI) vs the fp32 oracle and
+vs the transformers-recorded golden vectors, tiny kernel-compatible config.
+
+Stated tolerance (north_star: "within a stated float tolerance on the logits"): first-step logits
+within 6e-2 absolute (logit scale here is ~3, i.e. 2 % of range: bf16 activations through ~10
+GEMM stages), image embeddings within 5e-2.  Greedy tokens must equal the oracle's up to the
+first step whose oracle top-2 margin is below 2x that tolerance (a genuine near-tie)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, oracle_inputs, ref_config
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 6e-2
+
+
+@pytest.fixture(scope="module")
+def setup(device):
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, decode_splits=4)
+    return cfg, sd, eng
+
+
+def _check_tokens(toks, ref_toks, ref_logits):
+    for i, (a, b) in enumerate(zip(toks, ref_toks)):
+        if a != b:
+            top2 = torch.topk(ref_logits[i], 2).values
+            margin = float(top2[0] - top2[1])
+            assert margin < 2 * LOGIT_TOL, f"token {i}: got {a}, oracle {b}, oracle margin {margin:.4f} is not a near-tie"
+            return i
+    return len(ref_toks)
+
+
+@pytest.mark.parametrize("case,frames", [("a", ["frame_a"]), ("b", ["frame_b1", "frame_b2"])])
+def test_engine_matches_oracle_and_golden(setup, device, case, frames):
+    from oracle import qwen2vl_ref as R
+    cfg, sd, eng = setup
+    g = load_golden()
+    fr = [g[n] for n in frames]
+    ids = g[f"ids_{case}"].tolist()
+    dev_frames = [torch.from_numpy(f).to(device) for f in fr]
+    taps = {}
+    eng.prefill(ids, dev_frames, taps=taps)
+    eng.decode(15, use_graph=False)
+    toks = eng.generated(16)
+    img = taps["image_embeds"].float().cpu().numpy()
+    logits = taps["first_logits"].float().cpu().numpy()
+    # vs transformers-recorded vectors
+    assert np.abs(img - g[f"{case}_image_embeds"]).max() < 5e-2
+    assert np.abs(logits - g[f"{case}_first_logits"]).max() < LOGIT_TOL
+    # vs the oracle run here on the same inputs
+    pv, grids = oracle_inputs(fr)
+    ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, pv, grids, 16)
+    assert np.abs(logits - ref_logits[0].numpy()).max() < LOGIT_TOL
+    agreed = _check_tokens(toks, ref_toks, ref_logits)
+    assert agreed >= 4, f"only {agreed} leading tokens agree: {toks} vs {ref_toks}"
+
+
+def test_graph_replay_equals_eager(setup, device):
+    cfg, sd, eng = setup
+    g = load_golden()
+    ids = g["ids_a"].tolist()
+    fr = [torch.from_numpy(g["frame_a"]).to(device)]
+    eager = eng.generate(ids, fr, max_new_tokens=12, ignore_eos=True, use_graph=False)
+    graph = eng.generate(ids, fr, max_new_tokens=12, ignore_eos=True, use_graph=True)
+    again = eng.generate(ids, fr, max_new_tokens=12, ignore_eos=True, use_graph=True)
+    assert eager == graph == again and len(graph) == 12
+
+
+def test_text_only_prompt_and_eos(setup, device):
+    from oracle import qwen2vl_ref as R
+    cfg, sd, eng = setup
+    ids = [256, 72, 105, 33]
+    toks = eng.generate(ids, [], max_new_tokens=8, ignore_eos=True)
+    ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, None, [], 8)
+    assert _check_tokens(toks, ref_toks, ref_logits) >= 3
+    # EOS truncation: declare the 3rd generated token to be EOS
+    import dataclasses
+    eng.cfg = dataclasses.replace(cfg, eos_ids=(toks[2],))
+    try:
+        out = eng.generate(ids, [], max_new_tokens=8, check_every=2)
+        assert out == toks[:2]
+    finally:
+        eng.cfg = cfg
+
+
+def test_prompt_validation(setup):
+    cfg, sd, eng = setup
+    with pytest.raises(ValueError):
+        eng.prefill([cfg.vocab + 5], [])
+    with pytest.raises(ValueError):
+        eng.prefill([256, cfg.image_token_id, 10], [])  # image token without an image

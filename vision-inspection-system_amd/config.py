@@ -1,0 +1,234 @@
+"""Configuration surface of the local MI355X backend.
+
+Two things live here:
+
+1. ``Qwen2VLConfig`` - the architecture constants of the Inspector model
+   (Qwen2-VL-7B-Instruct ``config.json`` values) plus a tiny
+   kernel-compatible variant used by the parity tests.
+2. The reference's *model surface* (boundary B4): the ``Config`` field names of
+   ``utils/config.py:42-76,:184`` (``vlm_inspector_model`` ...) read from the same
+   environment variables, and the ``config/models.yaml:5-18`` schema
+   (``inspector/auditor: {model_id, temperature, max_tokens, description, provider}``).
+   A new ``provider`` value, ``"mi355x"``, selects this backend and ``model_id`` may
+   then be a local model directory (or ``synthetic:<name>`` for seeded random weights).
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import dataclass, field, asdict
+from typing import Any, Dict, Optional, Tuple
+
+LOCAL_PROVIDER = "mi355x"
+
+
+@dataclass(frozen=True)
+class Qwen2VLConfig:
+    name: str = "qwen2-vl-7b"
+    # text decoder
+    hidden: int = 3584
+    layers: int = 28
+    heads: int = 28
+    kv_heads: int = 4
+    intermediate: int = 18944
+    vocab: int = 152064
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: Tuple[int, int, int] = (16, 24, 24)
+    # vision tower
+    v_depth: int = 32
+    v_embed: int = 1280
+    v_heads: int = 16
+    v_mlp: int = 5120
+    patch: int = 14
+    temporal: int = 2
+    merge: int = 2
+    min_pixels: int = 56 * 56
+    max_pixels: int = 28 * 28 * 1280
+    # special tokens
+    image_token_id: int = 151655
+    vision_start_id: int = 151652
+    vision_end_id: int = 151653
+    eos_ids: Tuple[int, ...] = (151645, 151643)
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def v_head_dim(self) -> int:
+        return self.v_embed // self.v_heads
+
+    @property
+    def patch_dim(self) -> int:
+        return 3 * self.temporal * self.patch * self.patch
+
+    def validate_for_kernels(self) -> None:
+        """The gfx950 kernels are specialised; refuse shapes they do not cover."""
+        problems = []
+        if self.head_dim != 128:
+            problems.append(f"LLM head_dim must be 128, got {self.head_dim}")
+        if self.v_head_dim != 80:
+            problems.append(f"ViT head_dim must be 80, got {self.v_head_dim}")
+        if self.heads % self.kv_heads or self.heads // self.kv_heads > 8:
+            problems.append("heads/kv_heads must be an integer <= 8")
+        for nm, v in (("hidden", self.hidden), ("intermediate", self.intermediate), ("v_embed", self.v_embed),
+                      ("v_mlp", self.v_mlp), ("merger", self.v_embed * self.merge ** 2)):
+            if v % 64:
+                problems.append(f"{nm}={v} must be a multiple of 64 (GEMM K-step)")
+        if self.intermediate % 16 or self.vocab % 4:
+            problems.append("intermediate % 16 and vocab % 4 required")
+        if sum(self.mrope_section) * 2 != self.head_dim:
+            problems.append("mrope_section must sum to head_dim/2")
+        if self.hidden > 5120 or self.v_embed > 5120:
+            problems.append("norm kernels support rows up to 5120")
+        if problems:
+            raise ValueError("unsupported model shape for the gfx950 kernels: " + "; ".join(problems))
+
+    @classmethod
+    def qwen2_vl_7b(cls) -> "Qwen2VLConfig":
+        return cls()
+
+    @classmethod
+    def tiny(cls) -> "Qwen2VLConfig":
+        """Smallest shape every kernel specialisation accepts (parity tests, smoke)."""
+        return cls(name="qwen2-vl-tiny", hidden=256, layers=2, heads=2, kv_heads=1, intermediate=704, vocab=512,
+                   v_depth=2, v_embed=320, v_heads=4, v_mlp=1280, image_token_id=500, vision_start_id=501,
+                   vision_end_id=502, eos_ids=(503,))
+
+    @classmethod
+    def from_hf_dir(cls, path: str) -> "Qwen2VLConfig":
+        """Read a local HuggingFace ``config.json`` (Qwen2-VL layout, flat or nested text_config)."""
+        with open(os.path.join(path, "config.json")) as f:
+            c = json.load(f)
+        t = c.get("text_config", c)
+        v = c.get("vision_config", {})
+        rope = t.get("rope_scaling") or t.get("rope_parameters") or c.get("rope_scaling") or {}
+        eos = c.get("eos_token_id", t.get("eos_token_id", 151645))
+        eos_ids = tuple(eos) if isinstance(eos, (list, tuple)) else (int(eos),)
+        if 151643 not in eos_ids and t.get("vocab_size", 0) > 151643:
+            eos_ids = eos_ids + (151643,)
+        return cls(
+            name=os.path.basename(os.path.normpath(path)),
+            hidden=t["hidden_size"], layers=t["num_hidden_layers"], heads=t["num_attention_heads"],
+            kv_heads=t["num_key_value_heads"], intermediate=t["intermediate_size"], vocab=t["vocab_size"],
+            rms_eps=t.get("rms_norm_eps", 1e-6), rope_theta=t.get("rope_theta", rope.get("rope_theta", 1e6)),
+            mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))),
+            v_depth=v.get("depth", 32), v_embed=v.get("embed_dim", 1280), v_heads=v.get("num_heads", 16),
+            v_mlp=int(v.get("embed_dim", 1280) * v.get("mlp_ratio", 4)), patch=v.get("patch_size", 14),
+            temporal=v.get("temporal_patch_size", 2), merge=v.get("spatial_merge_size", 2),
+            image_token_id=c.get("image_token_id", 151655), vision_start_id=c.get("vision_start_token_id", 151652),
+            vision_end_id=c.get("vision_end_token_id", 151653), eos_ids=eos_ids)
+
+
+# ----------------------------------------------------------------------------- B4: reference Config surface
+@dataclass
+class AgentModelSettings:
+    """One block of config/models.yaml (config/models.yaml:5-18)."""
+    model_id: str
+    temperature: float
+    max_tokens: int
+    description: str = ""
+    provider: str = "huggingface"
+
+
+def _env(name: str, default, cast):
+    v = os.environ.get(name)
+    if v is None or v == "":
+        return default
+    return cast(v)
+
+
+@dataclass
+class Config:
+    """Subset of the reference's pydantic ``Config`` that the hot path reads (utils/config.py:42-76,:184).
+
+    Field names and environment aliases are the reference's; defaults are the reference's defaults.
+    """
+    vlm_inspector_model: str = "Qwen/Qwen2.5-VL-7B-Instruct"
+    vlm_inspector_temperature: float = 0.1
+    vlm_inspector_max_tokens: int = 2048
+    vlm_inspector_provider: str = "huggingface"
+    vlm_auditor_model: str = "Qwen/Qwen2.5-VL-7B-Instruct"
+    vlm_auditor_temperature: float = 0.2
+    vlm_auditor_max_tokens: int = 2048
+    vlm_auditor_provider: str = "huggingface"
+    max_image_dimension: int = 2048
+    log_level: str = "INFO"
+    max_defects_auto: int = 2
+    high_criticality_requires_review: bool = True
+    huggingface_api_key: Optional[str] = None
+    groq_api_key: Optional[str] = None
+
+    @classmethod
+    def from_env(cls) -> "Config":
+        c = cls()
+        c.vlm_inspector_model = _env("VLM_INSPECTOR_MODEL", c.vlm_inspector_model, str)
+        c.vlm_inspector_temperature = _env("VLM_INSPECTOR_TEMPERATURE", c.vlm_inspector_temperature, float)
+        c.vlm_inspector_max_tokens = _env("VLM_INSPECTOR_MAX_TOKENS", c.vlm_inspector_max_tokens, int)
+        c.vlm_inspector_provider = _env("VLM_INSPECTOR_PROVIDER", c.vlm_inspector_provider, str)
+        c.vlm_auditor_model = _env("VLM_AUDITOR_MODEL", c.vlm_auditor_model, str)
+        c.vlm_auditor_temperature = _env("VLM_AUDITOR_TEMPERATURE", c.vlm_auditor_temperature, float)
+        c.vlm_auditor_max_tokens = _env("VLM_AUDITOR_MAX_TOKENS", c.vlm_auditor_max_tokens, int)
+        c.vlm_auditor_provider = _env("VLM_AUDITOR_PROVIDER", c.vlm_auditor_provider, str)
+        c.max_image_dimension = _env("MAX_IMAGE_DIMENSION", c.max_image_dimension, int)
+        c.log_level = _env("LOG_LEVEL", c.log_level, str)
+        c.max_defects_auto = _env("MAX_DEFECTS_AUTO", c.max_defects_auto, int)
+        c.huggingface_api_key = _env("HUGGINGFACE_API_KEY", None, str)
+        c.groq_api_key = _env("GROQ_API_KEY", None, str)
+        return c
+
+    def apply_models_yaml(self, path: str) -> "Config":
+        """Overlay a ``config/models.yaml`` file (the reference ships one but never loads it)."""
+        for role, block in load_models_yaml(path).items():
+            if role not in ("inspector", "auditor"):
+                continue
+            setattr(self, f"vlm_{role}_model", block.model_id)
+            setattr(self, f"vlm_{role}_temperature", block.temperature)
+            setattr(self, f"vlm_{role}_max_tokens", block.max_tokens)
+            setattr(self, f"vlm_{role}_provider", block.provider)
+        return self
+
+
+def load_models_yaml(path: str) -> Dict[str, AgentModelSettings]:
+    """Parse the reference's models.yaml schema; unknown top-level keys (``groq:`` ...) are ignored."""
+    import yaml
+    with open(path) as f:
+        raw = yaml.safe_load(f) or {}
+    out: Dict[str, AgentModelSettings] = {}
+    for role in ("inspector", "auditor", "explainer"):
+        b = raw.get(role)
+        if not isinstance(b, dict):
+            continue
+        out[role] = AgentModelSettings(model_id=str(b["model_id"]), temperature=float(b.get("temperature", 0.1)),
+                                       max_tokens=int(b.get("max_tokens", 1024)),
+                                       description=str(b.get("description", "")),
+                                       provider=str(b.get("provider", "huggingface")))
+    return out
+
+
+_config: Optional[Config] = None
+
+
+def get_config() -> Config:
+    """Process-global settings object, like the reference's ``utils.config.config`` singleton (:350).
+
+    If the host application (the reference) is importable its own ``config`` object wins, so a
+    drop-in deployment keeps one source of truth.
+    """
+    global _config
+    if _config is None:
+        try:  # pragma: no cover - only inside the reference application
+            from utils.config import config as host_config  # type: ignore
+            _config = host_config
+        except Exception:
+            _config = Config.from_env()
+            yaml_path = os.environ.get("VIS_MODELS_YAML")
+            if yaml_path:
+                _config.apply_models_yaml(yaml_path)
+    return _config
+
+
+def set_config(cfg) -> None:
+    global _config
+    _config = cfg

@@ -1,0 +1,336 @@
+"""Qwen2-VL inference engine on MI355X: image frames + token ids -> generated token ids.
+
+This is the local replacement of what the reference's remote endpoint does for one
+``chat.completions.create`` call (src/agents/vlm_inspector.py:105-111).  The control flow is
+Python; every arithmetic op is a gfx950 HIP kernel reached through ``hip.py`` (C ABI in
+include/vis_hip.h).  PyTorch only allocates device memory, provides the HIP stream and
+captures the per-token decode step into a hipGraph (``torch.cuda.CUDAGraph``).
+
+Stages (kernel ids as in SURVEY.md section 8a):
+  vision : K1 patchify+GEMM, then 32 x [K5 LN, K2 qkv GEMM, K4 2-D rope/split, K6 varlen attention,
+           K2 proj(+res), K5 LN, K2 fc1(+QuickGELU), K2 fc2(+res)], merger (K5, K2+GELU, K2)
+  prefill: K12 embed gather + image scatter, 28 x [K3, K2 qkv(+bias), K4 M-RoPE/split/KV write,
+           K7 causal GQA attention, K2 o(+res), K3, K2 gate/up(+SwiGLU), K2 down(+res)], K10 lm_head, K12 argmax
+  decode : per token, one hipGraph replay of 28 x [K10 qkv(+RMSNorm,+bias), K4 rope+KV append,
+           K11 attention, K10 o(+res), K10 gate/up(+RMSNorm,+SwiGLU), K10 down(+res)], K10 lm_head, K12 argmax
+"""
+from __future__ import annotations
+
+import threading
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import hip
+from .config import Qwen2VLConfig
+from .image_processing import CLIP_MEAN, CLIP_STD
+from .weights import DeviceWeights, PATCH_K_PAD
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- host-side position math
+def vision_pos_hw(grids: Sequence[Tuple[int, int, int]], merge: int) -> np.ndarray:
+    """(h, w) index of every patch, 2x2-merge-block order (TF vision_utils.get_vision_position_ids)."""
+    out = []
+    for (t, h, w) in grids:
+        hp = np.broadcast_to(np.arange(h)[:, None], (h, w))
+        wp = np.broadcast_to(np.arange(w)[None, :], (h, w))
+        shape = (h // merge, merge, w // merge, merge)
+        hp = hp.reshape(shape).transpose(0, 2, 1, 3).reshape(-1)
+        wp = wp.reshape(shape).transpose(0, 2, 1, 3).reshape(-1)
+        out.append(np.tile(np.stack([hp, wp], axis=-1), (t, 1)))
+    return np.concatenate(out, axis=0)
+
+
+def vision_cos_sin(cfg: Qwen2VLConfig, grids) -> Tuple[np.ndarray, np.ndarray]:
+    """cos/sin rows [N, 80] f32 of the ViT 2-D rotary embedding (TF modeling_qwen2_vl.py:239-248,:719-722)."""
+    dim = cfg.v_head_dim // 2
+    inv_freq = (1.0 / (10000.0 ** (np.arange(0, dim, 2, dtype=np.float32) / np.float32(dim)))).astype(np.float32)
+    pos = vision_pos_hw(grids, cfg.merge).astype(np.float32)
+    freqs = (pos[:, :, None] * inv_freq[None, None, :]).reshape(pos.shape[0], -1)
+    emb = np.concatenate([freqs, freqs], axis=-1)
+    return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
+
+
+def rope_index(cfg: Qwen2VLConfig, input_ids: Sequence[int], grids) -> Tuple[np.ndarray, int]:
+    """M-RoPE position ids [3, S] of one sequence and the next text position
+    (TF modeling_qwen2_vl.py:914-1016: text runs count up on all 3 axes, an image block uses
+    (t, h, w) over the merged grid and advances the text position by max(h, w) / merge)."""
+    ids = np.asarray(list(input_ids))
+    is_img = ids == cfg.image_token_id
+    pos: List[np.ndarray] = []
+    cur, i, g, n = 0, 0, 0, len(ids)
+    while i < n:
+        if is_img[i]:
+            if g >= len(grids):
+                raise ValueError("more image-token runs than images")
+            t, h, w = grids[g]
+            g += 1
+            lh, lw = h // cfg.merge, w // cfg.merge
+            cnt = t * lh * lw
+            if i + cnt > n or not is_img[i:i + cnt].all():
+                raise ValueError("image-token run does not match the image grid")
+            tt = np.repeat(np.arange(t), lh * lw)
+            hh = np.tile(np.repeat(np.arange(lh), lw), t)
+            ww = np.tile(np.arange(lw), t * lh)
+            pos.append(np.stack([tt, hh, ww]) + cur)
+            cur += max(h, w) // cfg.merge
+            i += cnt
+        else:
+            j = i
+            while j < n and not is_img[j]:
+                j += 1
+            pos.append(np.broadcast_to(np.arange(j - i)[None, :], (3, j - i)) + cur)
+            cur += j - i
+            i = j
+    if g != len(grids):
+        raise ValueError("fewer image-token runs than images")
+    p = np.concatenate(pos, axis=1).astype(np.int64)
+    return p, int(p.max()) + 1
+
+
+def mrope_cos_sin(cfg: Qwen2VLConfig, pos3: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """pos3 [3, S] -> cos/sin rows [S, head_dim] f32 with the (t,h,w) sections already selected per
+    channel (TF modeling_qwen2_vl.py:156-170 + the cos.split(mrope_section*2) selection of :212-217)."""
+    D = cfg.head_dim
+    inv_freq = (1.0 / (np.float32(cfg.rope_theta) ** (np.arange(0, D, 2, dtype=np.float32) / np.float32(D))))
+    inv_freq = inv_freq.astype(np.float32)
+    axis = np.concatenate([np.full(s, i % 3) for i, s in enumerate(cfg.mrope_section)])  # [D/2]
+    sel = pos3.astype(np.float32)[axis, :].T                                             # [S, D/2]
+    freqs = sel * inv_freq[None, :]
+    emb = np.concatenate([freqs, freqs], axis=-1)
+    return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------- engine
+class Qwen2VLEngine:
+    """One model replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
+
+    def __init__(self, cfg: Qwen2VLConfig, weights: DeviceWeights, device, max_ctx: int = 4096,
+                 decode_splits: int = 16):
+        cfg.validate_for_kernels()
+        hip.load()  # fail loudly when the gfx950 library is missing: there is no other path
+        if not torch.cuda.is_available():
+            raise hip.HipLibraryError("Qwen2VLEngine needs a ROCm GPU (no CPU fallback exists)")
+        self.cfg, self.w, self.device = cfg, weights, torch.device(device)
+        self.max_ctx = _round_up(max_ctx, 64)
+        self.nsplit = decode_splits
+        self.lock = threading.Lock()
+        dev, bf = self.device, torch.bfloat16
+        L, Hkv, Hq, D, H = cfg.layers, cfg.kv_heads, cfg.heads, cfg.head_dim, cfg.hidden
+        self.kcache = torch.zeros((L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
+        self.vcache = torch.zeros((L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
+        self.cos_t = torch.zeros((self.max_ctx, D), dtype=torch.float32, device=dev)
+        self.sin_t = torch.zeros((self.max_ctx, D), dtype=torch.float32, device=dev)
+        # decode-step state (device resident so the step is one replayable graph)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.cur_token = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tokens = torch.zeros(self.max_ctx, dtype=torch.int32, device=dev)
+        self.ws_val = torch.empty(256, dtype=torch.float32, device=dev)
+        self.ws_idx = torch.empty(256, dtype=torch.int32, device=dev)
+        self.logits = torch.empty(cfg.vocab, dtype=torch.float32, device=dev)
+        nq = (Hq + 2 * Hkv) * D
+        self.d_x = torch.empty((1, H), dtype=bf, device=dev)
+        self.d_x2 = torch.empty((1, H), dtype=bf, device=dev)
+        self.d_qkv = torch.empty(nq, dtype=bf, device=dev)
+        self.d_q = torch.empty((Hq, D), dtype=bf, device=dev)
+        self.d_attn = torch.empty(Hq * D, dtype=bf, device=dev)
+        self.d_act = torch.empty(cfg.intermediate, dtype=bf, device=dev)
+        self.part_o = torch.empty(Hq * self.nsplit * D, dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty(Hq * self.nsplit * 2, dtype=torch.float32, device=dev)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.prompt_len = 0
+        self.last_first_logits: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ vision tower
+    def vision_forward(self, frames: Sequence[torch.Tensor]) -> torch.Tensor:
+        """frames: uint8 device tensors [H, W, 3] (H, W multiples of 28) -> [n_image_tokens, hidden] bf16."""
+        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        grids = [(1, f.shape[0] // cfg.patch, f.shape[1] // cfg.patch) for f in frames]
+        counts = [g[1] * g[2] for g in grids]
+        N = sum(counts)
+        E, Hh, D = cfg.v_embed, cfg.v_heads, cfg.v_head_dim
+        kp = w.patch_w.shape[1]
+        patches = torch.empty((N, kp), dtype=bf, device=dev)
+        row0 = 0
+        for f, c in zip(frames, counts):
+            hip.patchify(f, patches, row0, CLIP_MEAN, CLIP_STD)
+            row0 += c
+        x = hip.gemm(patches, w.patch_w)
+        key = tuple(grids)
+        if key not in self._vis_rope_cache:
+            c, s = vision_cos_sin(cfg, grids)
+            self._vis_rope_cache[key] = (torch.from_numpy(c).to(dev), torch.from_numpy(s).to(dev))
+            if len(self._vis_rope_cache) > 16:
+                self._vis_rope_cache.pop(next(iter(self._vis_rope_cache)))
+        cos, sin = self._vis_rope_cache[key]
+        segs, s0 = [], 0
+        for c in counts:
+            segs.append((s0, s0 + c))
+            s0 += c
+        work = hip.make_attn_work(segs, False, dev)
+        ld = _round_up(N, 64)
+        y = torch.empty((N, E), dtype=bf, device=dev)
+        qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
+        q = torch.empty((Hh, N, D), dtype=bf, device=dev)
+        k = torch.empty((Hh, N, D), dtype=bf, device=dev)
+        vt = torch.empty((Hh, D, ld), dtype=bf, device=dev)
+        att = torch.empty((N, E), dtype=bf, device=dev)
+        hmid = torch.empty((N, cfg.v_mlp), dtype=bf, device=dev)
+        scale = D ** -0.5
+        for b in w.vit:
+            hip.layernorm(x, b.ln1_w, b.ln1_b, 1e-6, out=y)
+            hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
+            hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
+            hip.attn_prefill(q, k, vt, att, work, False, scale)
+            hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
+            hip.layernorm(x, b.ln2_w, b.ln2_b, 1e-6, out=y)
+            hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid)
+            hip.gemm(hmid, b.fc2_w, bias=b.fc2_b, residual=x, out=x)
+        hip.layernorm(x, w.merger_ln_w, w.merger_ln_b, 1e-6, out=y)
+        m = cfg.merge ** 2
+        z = hip.gemm(y.view(N // m, E * m), w.merger_fc0_w, bias=w.merger_fc0_b, act=hip.ACT_GELU_ERF)
+        return hip.gemm(z, w.merger_fc2_w, bias=w.merger_fc2_b)
+
+    # ------------------------------------------------------------------ prefill
+    def prefill(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (),
+                ids_dev: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> None:
+        """Run the prompt through the LLM, fill the KV cache and pick the first token (greedy)."""
+        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        S = len(input_ids)
+        if S < 1 or S + 1 > self.max_ctx:
+            raise ValueError(f"prompt of {S} tokens does not fit the context of {self.max_ctx}")
+        ids_np = np.asarray(list(input_ids), dtype=np.int64)
+        if ids_np.min() < 0 or ids_np.max() >= cfg.vocab:
+            raise ValueError("token id out of range")
+        grids = [(1, f.shape[0] // cfg.patch, f.shape[1] // cfg.patch) for f in frames]
+        pos3, next_pos = rope_index(cfg, ids_np, grids)
+        cos_np, sin_np = mrope_cos_sin(cfg, pos3)
+        # decode rows: slot S + t carries rope position next_pos + t on all three axes
+        n_dec = self.max_ctx - S
+        dpos = np.broadcast_to((next_pos + np.arange(n_dec))[None, :], (3, n_dec))
+        dcos, dsin = mrope_cos_sin(cfg, dpos)
+        self.cos_t.copy_(torch.from_numpy(np.concatenate([cos_np, dcos])), non_blocking=True)
+        self.sin_t.copy_(torch.from_numpy(np.concatenate([sin_np, dsin])), non_blocking=True)
+        if ids_dev is None:
+            ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
+        H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
+        x = torch.empty((S, H), dtype=bf, device=dev)
+        hip.gather_rows(w.embed, ids_dev, x)
+        if len(frames):
+            img = self.vision_forward(frames)
+            idx = np.nonzero(ids_np == cfg.image_token_id)[0].astype(np.int32)
+            if idx.shape[0] != img.shape[0]:
+                raise ValueError(f"image tokens ({idx.shape[0]}) and image features ({img.shape[0]}) do not match")
+            hip.scatter_rows(img, torch.from_numpy(idx).to(dev), x)
+            if taps is not None:
+                taps["image_embeds"] = img
+        cos, sin = self.cos_t[:S], self.sin_t[:S]
+        work = hip.make_attn_work([(0, S)], True, dev)
+        ld = _round_up(S, 64)
+        nq = (Hq + 2 * Hkv) * D
+        y = torch.empty((S, H), dtype=bf, device=dev)
+        qkv = torch.empty((S, nq), dtype=bf, device=dev)
+        q = torch.empty((Hq, S, D), dtype=bf, device=dev)
+        vt = torch.empty((Hkv, D, ld), dtype=bf, device=dev)
+        att = torch.empty((S, Hq * D), dtype=bf, device=dev)
+        act = torch.empty((S, cfg.intermediate), dtype=bf, device=dev)
+        scale = D ** -0.5
+        for li, lw in enumerate(w.llm):
+            hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
+            hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
+            hip.qkv_rope_split(qkv, cos, sin, q, self.kcache[li], self.vcache[li], vt, Hq, Hkv, D, k_pos0=0)
+            hip.attn_prefill(q, self.kcache[li], vt, att, work, True, scale)
+            hip.gemm(att, lw.o_w, residual=x, out=x)
+            hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
+            hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
+            hip.gemm(act, lw.down_w, residual=x, out=x)
+            if taps is not None and li == 0:
+                taps["layer0"] = x.clone()
+        # first token: final norm fused into the lm_head GEMV of the last position only
+        hip.gemv(x[S - 1], w.lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+        if taps is not None:
+            taps["first_logits"] = self.logits.clone()
+        self.step.fill_(S - 1)
+        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step)
+        self.prompt_len = S
+
+    # ------------------------------------------------------------------ decode
+    def _decode_step(self) -> None:
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        scale = D ** -0.5
+        hip.gather_rows(w.embed, self.cur_token, self.d_x)
+        x, x2 = self.d_x, self.d_x2
+        for li, lw in enumerate(w.llm):
+            hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+            hip.decode_rope_kv(self.d_qkv, self.cos_t, self.sin_t, self.step, self.d_q, self.kcache[li],
+                               self.vcache[li], Hq, Hkv, D, 0)
+            hip.decode_attn(self.d_q, self.kcache[li], self.vcache[li], self.step, self.part_o, self.part_ml,
+                            self.d_attn, Hq, Hkv, D, 0, self.nsplit, scale)
+            hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
+            hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
+            hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])
+        hip.gemv(x[0], w.lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step)
+
+    def _ensure_graph(self) -> None:
+        if self._graph is not None:
+            return
+        # warm the kernels outside capture, then restore the counters the warm-up advanced
+        saved = (self.step.clone(), self.cur_token.clone())
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._decode_step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.step.copy_(saved[0])
+        self.cur_token.copy_(saved[1])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_step()
+        # capture does not execute; state is unchanged
+        self._graph = g
+
+    def decode(self, n_steps: int, use_graph: bool = True) -> None:
+        """Generate n_steps further tokens (each replays the captured step)."""
+        if self.prompt_len + n_steps + 1 > self.max_ctx:
+            raise ValueError("decode would overflow the KV cache")
+        if use_graph:
+            self._ensure_graph()
+            for _ in range(n_steps):
+                self._graph.replay()
+        else:
+            for _ in range(n_steps):
+                self._decode_step()
+
+    def generated(self, n: int) -> List[int]:
+        s = self.prompt_len - 1
+        return self.tokens[s:s + n].cpu().tolist()
+
+    def generate(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (), max_new_tokens: int = 128,
+                 ignore_eos: bool = False, use_graph: bool = True, check_every: int = 16) -> List[int]:
+        """Greedy generation.  EOS is checked on the host every ``check_every`` tokens so the decode
+        loop itself never synchronises; output is truncated at the first EOS (exclusive)."""
+        max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
+        self.prefill(input_ids, frames)
+        done, eos = 1, set(self.cfg.eos_ids)
+        while done < max_new_tokens:
+            if not ignore_eos:
+                toks = self.generated(done)
+                if any(t in eos for t in toks):
+                    break
+            n = min(check_every if not ignore_eos else max_new_tokens, max_new_tokens - done)
+            self.decode(n, use_graph=use_graph)
+            done += n
+        toks = self.generated(done)
+        if not ignore_eos:
+            for i, t in enumerate(toks):
+                if t in eos:
+                    return toks[:i]
+        return toks

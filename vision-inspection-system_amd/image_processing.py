@@ -1,0 +1,97 @@
+"""Host-side image handling on both sides of the boundary.
+
+* ``encode_image_optimized`` mirrors the reference's request-side step a3
+  (src/agents/vlm_inspector.py:46-88, auditor copy src/agents/vlm_auditor.py:85-108):
+  thumbnail (LANCZOS) -> RGB -> JPEG q85 (q60 above 5 MB, error above 10 MB) -> base64 data URI.
+* ``decode_data_uri`` + ``resize_for_model`` are the service-side counterpart the local backend
+  now owns: decode the JPEG, RGB, ``smart_resize`` to multiples of 28 inside the pixel budget,
+  bicubic resample (PIL) - the geometry of TF:models/qwen2_vl/image_processing_pil_qwen2_vl.py:57-84.
+  Rescale / normalise / patchify happen on the GPU (csrc/misc.hip, vis_patchify_u8).
+"""
+from __future__ import annotations
+
+import base64
+import io
+import math
+from pathlib import Path
+from typing import Optional, Tuple, Union
+
+import numpy as np
+from PIL import Image
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56,
+                 max_pixels: int = 28 * 28 * 1280) -> Tuple[int, int]:
+    """Target (h, w): multiples of ``factor``, area within [min_pixels, max_pixels], aspect kept."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(
+            f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
+    h_bar = round(height / factor) * factor
+    w_bar = round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+def encode_image_optimized(image_path: Union[str, Path], max_size: int = 2048, convert_la: bool = True,
+                           enforce_limit: bool = True, logger=None) -> str:
+    """Request-side encode, byte-compatible with the reference's Inspector (``convert_la=True,
+    enforce_limit=True``) and Auditor (``max_size=1024, convert_la=False, enforce_limit=False``)."""
+    img = Image.open(image_path)
+    original_size = img.size
+    if max(img.size) > max_size:
+        img.thumbnail((max_size, max_size), Image.Resampling.LANCZOS)
+        if logger:
+            logger.debug(f"Resized image from {original_size} to {img.size}")
+    modes = ("RGBA", "P", "LA") if convert_la else ("RGBA", "P")
+    if img.mode in modes:
+        img = img.convert("RGB")
+    buffer = io.BytesIO()
+    img.save(buffer, format="JPEG", quality=85, optimize=True)
+    if buffer.tell() > 5_000_000:
+        buffer = io.BytesIO()
+        img.save(buffer, format="JPEG", quality=60, optimize=True)
+    payload_size = buffer.tell()
+    if enforce_limit and payload_size > 10_000_000:
+        raise ValueError(f"Image too large even after optimization: {payload_size} bytes")
+    return "data:image/jpeg;base64," + base64.b64encode(buffer.getvalue()).decode()
+
+
+def decode_data_uri(url: str) -> Image.Image:
+    """``data:image/...;base64,XXXX`` -> PIL RGB image.  Remote URLs are refused (no network)."""
+    if not url.startswith("data:"):
+        raise ValueError("local backend accepts only data: URIs for images (no remote fetch)")
+    try:
+        header, b64 = url.split(",", 1)
+    except ValueError:
+        raise ValueError("malformed data URI")
+    if ";base64" not in header:
+        raise ValueError("data URI must be base64 encoded")
+    img = Image.open(io.BytesIO(base64.b64decode(b64)))
+    img.load()
+    return img.convert("RGB")
+
+
+def resize_for_model(img: Image.Image, patch: int = 14, merge: int = 2, min_pixels: int = 56 * 56,
+                     max_pixels: int = 28 * 28 * 1280) -> np.ndarray:
+    """RGB PIL image -> uint8 [H, W, 3] with H, W multiples of patch*merge (bicubic, like the HF PIL backend)."""
+    img = img.convert("RGB")
+    w, h = img.size
+    th, tw = smart_resize(h, w, patch * merge, min_pixels, max_pixels)
+    if (th, tw) != (h, w):
+        img = img.resize((tw, th), resample=Image.Resampling.BICUBIC)
+    return np.ascontiguousarray(np.asarray(img, dtype=np.uint8))
+
+
+def grid_of(frame_u8: np.ndarray, patch: int = 14) -> Tuple[int, int, int]:
+    h, w, _ = frame_u8.shape
+    return (1, h // patch, w // patch)
