@@ -89,10 +89,12 @@ int vis_decode_attn(const void* q, const void* k_cache, const void* v_cache, con
                     void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int cache_tokens,
                     int slot_base, int nsplit, float scale, vis_stream_t stream);
 
-/* K12  greedy pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
- * torch.argmax), then *step += 1.  ws_val/ws_idx: 256 floats / 256 ints of workspace. */
+/* K12  next-token pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
+ * torch.argmax), then *step += 1.  inv_temp > 0 samples at temperature 1/inv_temp by Gumbel-max with a
+ * counter hash of (seed, *step, index); inv_temp == 0 is greedy (the reference request passes
+ * temperature=, src/agents/vlm_inspector.py:108).  ws_val/ws_idx: 256 floats / 256 ints of workspace. */
 int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* tokens, int max_tokens,
-                   void* cur_token, void* step_ptr, vis_stream_t stream);
+                   void* cur_token, void* step_ptr, float inv_temp, unsigned seed, vis_stream_t stream);
 
 /* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
  * out[row0 + p][ld_out] in the merge-group order of

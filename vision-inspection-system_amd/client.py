@@ -1,0 +1,200 @@
+"""Boundary B1: a ``chat.completions.create``-shaped client backed by the local MI355X engine.
+
+The reference talks to its models through exactly one call shape,
+    client.chat.completions.create(model=, messages=, temperature=, max_tokens=).choices[0].message.content
+(``huggingface_hub.InferenceClient`` at src/agents/vlm_inspector.py:32,:105-111 and
+src/agents/vlm_auditor.py:152-158; ``groq.Groq`` at :117-129; text-only health check
+vlm_inspector.py:533-544).  ``LocalVLMClient`` offers the same attribute chain and return shape, so
+the reference's agents can be pointed at it without touching their code.
+
+Errors: ordinary exceptions whose messages never contain "429", "rate", "413" or "payload" - the
+substrings the reference's retry logic keys on (vlm_inspector.py:113-140).
+"""
+from __future__ import annotations
+
+import os
+import threading
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional, Tuple
+
+from .config import LOCAL_PROVIDER, Qwen2VLConfig
+
+
+# ----------------------------------------------------------------------------- response objects
+@dataclass
+class _Message:
+    content: str
+    role: str = "assistant"
+
+
+@dataclass
+class _Choice:
+    message: _Message
+    index: int = 0
+    finish_reason: str = "stop"
+
+
+@dataclass
+class ChatCompletion:
+    choices: List[_Choice]
+    model: str = ""
+    usage: Dict[str, int] = field(default_factory=dict)
+
+
+class _Completions:
+    def __init__(self, owner):
+        self._owner = owner
+
+    def create(self, model: Optional[str] = None, messages: Optional[list] = None,
+               temperature: Optional[float] = None, max_tokens: Optional[int] = None, **kwargs) -> ChatCompletion:
+        return self._owner._complete(model, messages or [], temperature, max_tokens, **kwargs)
+
+
+class _Chat:
+    def __init__(self, owner):
+        self.completions = _Completions(owner)
+
+
+# ----------------------------------------------------------------------------- engine registry
+_ENGINES: Dict[Tuple[str, str], Any] = {}
+_ENGINES_LOCK = threading.Lock()
+
+
+@dataclass
+class LoadedModel:
+    engine: Any
+    tokenizer: Any
+    cfg: Qwen2VLConfig
+    model_id: str
+
+
+def resolve_model_dir(model_id: str) -> Optional[str]:
+    """A hub-style name is only ever mapped to a LOCAL directory: ``$VIS_MODEL_ROOT/<name>`` or
+    ``$VIS_MODEL_ROOT/<org>--<name>``.  Nothing is downloaded."""
+    if os.path.isdir(model_id):
+        return model_id
+    root = os.environ.get("VIS_MODEL_ROOT")
+    if root:
+        for cand in (os.path.join(root, model_id), os.path.join(root, model_id.replace("/", "--")),
+                     os.path.join(root, model_id.split("/")[-1])):
+            if os.path.isdir(cand):
+                return cand
+    return None
+
+
+def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
+    """Process-wide singleton per (model, device): the reference constructs a NEW agent object on every
+    node call (src/orchestration/nodes.py:128,:230), so the 16.6 GB model must not live in the agent."""
+    import torch
+    from .engine import Qwen2VLEngine
+    from .tokenizer import ByteTokenizer, HFTokenizer
+    from . import weights as W
+    if device is None:
+        device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
+    key = (model_id, str(device))
+    with _ENGINES_LOCK:
+        if key in _ENGINES:
+            return _ENGINES[key]
+        max_ctx = int(os.environ.get("VIS_MAX_CTX", "4096"))
+        if model_id.startswith("synthetic:"):
+            parts = model_id.split(":")
+            kind = parts[1]
+            seed = int(parts[2]) if len(parts) > 2 else 0
+            if kind == "tiny":
+                cfg = Qwen2VLConfig.tiny()
+                w = W.pack_device_weights(cfg, W.synth_state_dict(cfg, seed), device)
+                max_ctx = min(max_ctx, 1024)
+            elif kind in ("7b", "qwen2-vl-7b"):
+                cfg = Qwen2VLConfig.qwen2_vl_7b()
+                w = W.random_device_weights(cfg, device, seed)
+            else:
+                raise ValueError(f"unknown synthetic model {kind!r} (use synthetic:tiny or synthetic:7b)")
+            tok = ByteTokenizer(cfg.vocab, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
+        else:
+            path = resolve_model_dir(model_id)
+            if path is None:
+                raise FileNotFoundError(
+                    f"model {model_id!r} is not a local directory and VIS_MODEL_ROOT has no copy of it; the "
+                    f"'{LOCAL_PROVIDER}' provider only loads local files (config.json, *.safetensors, tokenizer.json)")
+            cfg = Qwen2VLConfig.from_hf_dir(path)
+            w = W.load_safetensors_dir(cfg, path, device)
+            tok = HFTokenizer(path, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
+        lm = LoadedModel(Qwen2VLEngine(cfg, w, device, max_ctx=max_ctx), tok, cfg, model_id)
+        _ENGINES[key] = lm
+        return lm
+
+
+def drop_models() -> None:
+    with _ENGINES_LOCK:
+        _ENGINES.clear()
+
+
+# ----------------------------------------------------------------------------- clients
+class LocalVLMClient:
+    """``InferenceClient``-shaped facade over the MI355X engine."""
+
+    def __init__(self, api_key: Optional[str] = None, device: Optional[str] = None, default_model: Optional[str] = None,
+                 seed: int = 0, **_ignored):
+        self.device = device
+        self.default_model = default_model
+        self.seed = seed
+        self.chat = _Chat(self)
+
+    def _complete(self, model, messages, temperature, max_tokens, **kwargs) -> ChatCompletion:
+        import torch
+        from .image_processing import decode_data_uri, resize_for_model
+        from .tokenizer import build_chat_ids
+        model_id = model or self.default_model
+        if not model_id:
+            raise ValueError("no model given")
+        lm = get_model(model_id, self.device)
+        cfg, eng, tok = lm.cfg, lm.engine, lm.tokenizer
+        frames = []
+        for m in messages:
+            content = m.get("content")
+            if isinstance(content, list):
+                for part in content:
+                    if part.get("type") == "image_url":
+                        url = part["image_url"]["url"] if isinstance(part.get("image_url"), dict) else part["image_url"]
+                        frames.append(resize_for_model(decode_data_uri(url), cfg.patch, cfg.merge, cfg.min_pixels,
+                                                       cfg.max_pixels))
+        counts = [(f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2 for f in frames]
+        ids = build_chat_ids(tok, messages, counts)
+        max_new = int(max_tokens) if max_tokens else 512
+        temp = float(temperature) if temperature else 0.0
+        with eng.lock:
+            dev_frames = [torch.from_numpy(f).to(eng.device) for f in frames]
+            out = eng.generate(ids, dev_frames, max_new_tokens=max_new, temperature=temp, seed=self.seed)
+        text = tok.decode(out)
+        return ChatCompletion([_Choice(_Message(text))], model=model_id,
+                              usage={"prompt_tokens": len(ids), "completion_tokens": len(out),
+                                     "total_tokens": len(ids) + len(out)})
+
+
+class CannedResponseClient:
+    """Mock backend (the reference declares ``use_mock_responses``, utils/config.py:191, but ships none):
+    returns a fixed reply.  Used for the no-GPU plumbing configuration (BASELINE config 1) and by tests;
+    it performs no model arithmetic and is never selected implicitly."""
+
+    def __init__(self, reply: str = "OK", **_ignored):
+        self.reply = reply
+        self.calls: List[dict] = []
+        self.chat = _Chat(self)
+
+    def _complete(self, model, messages, temperature, max_tokens, **kwargs) -> ChatCompletion:
+        self.calls.append({"model": model, "messages": messages, "temperature": temperature, "max_tokens": max_tokens})
+        reply = self.reply(messages) if callable(self.reply) else self.reply
+        return ChatCompletion([_Choice(_Message(reply))], model=model or "")
+
+
+def make_client(provider: str, api_key: Optional[str] = None, **kwargs):
+    """provider -> client object.  ``mi355x`` -> local engine; ``mock`` -> canned replies;
+    ``huggingface`` -> the reference's own remote client (only if huggingface_hub is importable)."""
+    if provider == LOCAL_PROVIDER:
+        return LocalVLMClient(api_key=api_key, **kwargs)
+    if provider == "mock":
+        return CannedResponseClient(**kwargs)
+    if provider == "huggingface":
+        from huggingface_hub import InferenceClient
+        return InferenceClient(api_key=api_key)
+    raise ValueError(f"unknown provider {provider!r}")

@@ -320,13 +320,29 @@ extern "C" int vis_decode_attn(const void* q, const void* k_cache, const void* v
 // ---------------------------------------------------------------------------
 // Greedy pick.  Stage 1: per-block (max, first index); stage 2: one block merges,
 // writes tokens[*step] = argmax, cur_token = argmax and then *step += 1.
+// temperature sampling = Gumbel-max: argmax(logit/T + g_i), g_i = -log(-log(u_i)), u_i from a counter hash of
+// (seed, step, i).  Exact categorical sampling, no softmax pass, no host round trip, graph-replayable.
+__device__ __forceinline__ float gumbel_noise(unsigned seed, unsigned step, unsigned i) {
+  unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^ i;
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
+  return -__logf(-__logf(u));
+}
+
 __global__ __launch_bounds__(256) void argmax_stage1_kernel(const float* __restrict__ logits, int V,
-                                                            float* __restrict__ bval, int* __restrict__ bidx) {
+                                                            float* __restrict__ bval, int* __restrict__ bidx,
+                                                            float inv_temp, unsigned seed,
+                                                            const int* __restrict__ step_ptr) {
   const int tid = threadIdx.x;
   float best = -INFINITY;
   int bi = 0x7fffffff;
+  const unsigned step = (unsigned)*step_ptr;
   for (int i = blockIdx.x * 256 + tid; i < V; i += gridDim.x * 256) {
-    const float v = logits[i];
+    float v = logits[i];
+    if (inv_temp > 0.f) v = v * inv_temp + gumbel_noise(seed, step, (unsigned)i);
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }
 #pragma unroll
@@ -374,11 +390,12 @@ __global__ __launch_bounds__(64) void argmax_stage2_kernel(const float* __restri
 }
 
 extern "C" int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* tokens, int max_tokens,
-                              void* cur_token, void* step_ptr, hipStream_t stream) {
+                              void* cur_token, void* step_ptr, float inv_temp, unsigned seed, hipStream_t stream) {
   if (!logits || V <= 0 || !ws_val || !ws_idx || !tokens || !cur_token || !step_ptr) return VIS_ERR_ARG;
+  if (!(inv_temp >= 0.f)) return VIS_ERR_ARG;
   const int nb = min(256, (V + 255) / 256);
   hipLaunchKernelGGL(argmax_stage1_kernel, dim3(nb), dim3(256), 0, stream, (const float*)logits, V, (float*)ws_val,
-                     (int*)ws_idx);
+                     (int*)ws_idx, inv_temp, seed, (const int*)step_ptr);
   hipLaunchKernelGGL(argmax_stage2_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx,
                      nb, (int*)tokens, max_tokens, (int*)cur_token, (int*)step_ptr);
   return vis_check_launch();

@@ -142,7 +142,8 @@ class Qwen2VLEngine:
         self.d_act = torch.empty(cfg.intermediate, dtype=bf, device=dev)
         self.part_o = torch.empty(Hq * self.nsplit * D, dtype=torch.float32, device=dev)
         self.part_ml = torch.empty(Hq * self.nsplit * 2, dtype=torch.float32, device=dev)
-        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.prompt_len = 0
         self.last_first_logits: Optional[torch.Tensor] = None
@@ -199,9 +200,12 @@ class Qwen2VLEngine:
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (),
-                ids_dev: Optional[torch.Tensor] = None, taps: Optional[dict] = None) -> None:
-        """Run the prompt through the LLM, fill the KV cache and pick the first token (greedy)."""
+                ids_dev: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
+                temperature: float = 0.0, seed: int = 0) -> None:
+        """Run the prompt through the LLM, fill the KV cache and pick the first token
+        (greedy when temperature == 0, Gumbel-max sampled otherwise)."""
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        self.temperature, self.seed = float(temperature), int(seed)
         S = len(input_ids)
         if S < 1 or S + 1 > self.max_ctx:
             raise ValueError(f"prompt of {S} tokens does not fit the context of {self.max_ctx}")
@@ -257,7 +261,8 @@ class Qwen2VLEngine:
         if taps is not None:
             taps["first_logits"] = self.logits.clone()
         self.step.fill_(S - 1)
-        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step)
+        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
+                   self.temperature, self.seed)
         self.prompt_len = S
 
     # ------------------------------------------------------------------ decode
@@ -277,11 +282,13 @@ class Qwen2VLEngine:
             hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])
         hip.gemv(x[0], w.lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
-        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step)
+        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
+                   self.temperature, self.seed)
 
-    def _ensure_graph(self) -> None:
-        if self._graph is not None:
-            return
+    def _ensure_graph(self) -> torch.cuda.CUDAGraph:
+        key = (self.temperature, self.seed)  # sampling parameters are kernel arguments baked into the graph
+        if key in self._graphs:
+            return self._graphs[key]
         # warm the kernels outside capture, then restore the counters the warm-up advanced
         saved = (self.step.clone(), self.cur_token.clone())
         side = torch.cuda.Stream(device=self.device)
@@ -295,16 +302,19 @@ class Qwen2VLEngine:
         with torch.cuda.graph(g):
             self._decode_step()
         # capture does not execute; state is unchanged
-        self._graph = g
+        if len(self._graphs) >= 8:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = g
+        return g
 
     def decode(self, n_steps: int, use_graph: bool = True) -> None:
         """Generate n_steps further tokens (each replays the captured step)."""
         if self.prompt_len + n_steps + 1 > self.max_ctx:
             raise ValueError("decode would overflow the KV cache")
         if use_graph:
-            self._ensure_graph()
+            g = self._ensure_graph()
             for _ in range(n_steps):
-                self._graph.replay()
+                g.replay()
         else:
             for _ in range(n_steps):
                 self._decode_step()
@@ -314,11 +324,13 @@ class Qwen2VLEngine:
         return self.tokens[s:s + n].cpu().tolist()
 
     def generate(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (), max_new_tokens: int = 128,
-                 ignore_eos: bool = False, use_graph: bool = True, check_every: int = 16) -> List[int]:
-        """Greedy generation.  EOS is checked on the host every ``check_every`` tokens so the decode
-        loop itself never synchronises; output is truncated at the first EOS (exclusive)."""
+                 ignore_eos: bool = False, use_graph: bool = True, check_every: int = 16,
+                 temperature: float = 0.0, seed: int = 0) -> List[int]:
+        """Generate up to max_new_tokens (greedy at temperature 0).  EOS is checked on the host every
+        ``check_every`` tokens so the decode loop itself never synchronises; output is truncated at the
+        first EOS (exclusive)."""
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
-        self.prefill(input_ids, frames)
+        self.prefill(input_ids, frames, temperature=temperature, seed=seed)
         done, eos = 1, set(self.cfg.eos_ids)
         while done < max_new_tokens:
             if not ignore_eos:

@@ -29,12 +29,12 @@ _SIGS = {
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_decode_rope_kv": "ppppppp" + "iiiii" + "p",
     "vis_decode_attn": "ppppppp" + "iiiiii" + "f" + "p",
-    "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "p",
+    "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint}
 
 
 class HipLibraryError(RuntimeError):
@@ -239,13 +239,15 @@ def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, s
 
 
 def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tokens: torch.Tensor,
-           cur_token: torch.Tensor, step: torch.Tensor) -> None:
+           cur_token: torch.Tensor, step: torch.Tensor, temperature: float = 0.0, seed: int = 0) -> None:
+    """Greedy (temperature 0) or Gumbel-max sampled next token; advances the device-side step."""
     if logits.dtype != torch.float32 or tokens.dtype != torch.int32 or cur_token.dtype != torch.int32:
         raise HipLibraryError("argmax: f32 logits / int32 tokens required")
     if ws_val.numel() < 256 or ws_idx.numel() < 256:
         raise HipLibraryError("argmax: workspace too small")
     rc = load().vis_argmax_f32(_ptr(logits), logits.numel(), _ptr(ws_val), _ptr(ws_idx), _ptr(tokens),
-                               tokens.numel(), _ptr(cur_token), _ptr(step), _stream())
+                               tokens.numel(), _ptr(cur_token), _ptr(step),
+                               (1.0 / temperature) if temperature > 0 else 0.0, seed & 0xFFFFFFFF, _stream())
     _check(rc, "vis_argmax_f32")
 
 
