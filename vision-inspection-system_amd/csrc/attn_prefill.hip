@@ -310,6 +310,7 @@ extern "C" int vis_attn_prefill(const void* Q, const void* K, const void* Vt, vo
   p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
   p.scale_log2 = scale * 1.4426950408889634f;
   const dim3 grid(n_work, Hq), block(256);
+  vis_clear_error();
   if (HD == 128) {
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, stream, p);

@@ -65,6 +65,9 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
   return base + (orig >> 3);
 }
 
+// hipGetLastError() is sticky per thread and the host application (PyTorch) leaves benign codes such as
+// hipErrorNotReady behind, so every launcher clears the slot before launching and reads it after.
+static inline void vis_clear_error() { (void)hipGetLastError(); }
 static inline int vis_check_launch() {
   return hipGetLastError() == hipSuccess ? VIS_OK : VIS_ERR_LAUNCH;
 }

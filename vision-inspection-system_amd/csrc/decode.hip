@@ -158,6 +158,7 @@ extern "C" int vis_gemv_bf16(const void* x, const void* W, const void* bias, con
   while (opb < 64 && (n_out + opb - 1) / opb > 2048) opb *= 2;
   p.outs_per_block = opb;
   const int blocks = (n_out + opb - 1) / opb;
+  vis_clear_error();
   hipLaunchKernelGGL(gemv_bf16_kernel, dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
   return vis_check_launch();
 }
@@ -311,6 +312,7 @@ extern "C" int vis_decode_attn(const void* q, const void* k_cache, const void* v
   p.step_ptr = (const int*)step_ptr; p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
   p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.slot_base = slot_base; p.nsplit = nsplit;
   p.scale_log2 = scale * 1.4426950408889634f;
+  vis_clear_error();
   hipLaunchKernelGGL(decode_attn_kernel, dim3(Hkv, nsplit), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(128), 0, stream, (const float*)part_o,
                      (const float*)part_ml, (bf16_t*)out, nsplit);
@@ -394,6 +396,7 @@ extern "C" int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_
   if (!logits || V <= 0 || !ws_val || !ws_idx || !tokens || !cur_token || !step_ptr) return VIS_ERR_ARG;
   if (!(inv_temp >= 0.f)) return VIS_ERR_ARG;
   const int nb = min(256, (V + 255) / 256);
+  vis_clear_error();
   hipLaunchKernelGGL(argmax_stage1_kernel, dim3(nb), dim3(256), 0, stream, (const float*)logits, V, (float*)ws_val,
                      (int*)ws_idx, inv_temp, seed, (const int*)step_ptr);
   hipLaunchKernelGGL(argmax_stage2_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx,

@@ -218,6 +218,7 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   const int nwg = p.tiles_m * p.tiles_n;
+  vis_clear_error();
   hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(nwg), dim3(256), 0, stream, p);
   return vis_check_launch();
 }

@@ -63,6 +63,7 @@ extern "C" int vis_patchify_u8(const void* img, void* out, int H, int W, int ld_
   }
   const long long total = (long long)(H / 14) * (W / 14) * (ld_out / 8);
   const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  vis_clear_error();
   hipLaunchKernelGGL(patchify_u8_kernel, dim3(blocks), dim3(256), 0, stream, p);
   return vis_check_launch();
 }
@@ -97,6 +98,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restr
 
 extern "C" int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D, int n_table,
                                hipStream_t stream) {
+  vis_clear_error();
   if (!table || !ids || !out || n <= 0 || D <= 0 || D % 8 != 0 || n_table <= 0) return VIS_ERR_ARG;
   if (((uintptr_t)table | (uintptr_t)out) & 15) return VIS_ERR_ARG;
   hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const bf16_t*)table,
@@ -106,6 +108,7 @@ extern "C" int vis_gather_rows(const void* table, const void* ids, void* out, in
 
 extern "C" int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
                                 hipStream_t stream) {
+  vis_clear_error();
   if (!src || !idx || !dst || n <= 0 || D <= 0 || D % 8 != 0 || n_dst <= 0) return VIS_ERR_ARG;
   if (((uintptr_t)src | (uintptr_t)dst) & 15) return VIS_ERR_ARG;
   hipLaunchKernelGGL(scatter_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (const bf16_t*)src,

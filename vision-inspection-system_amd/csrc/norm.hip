@@ -88,6 +88,7 @@ static int norm_launch(bool ln, const void* x, const void* w, const void* b, voi
   if (ln && !b) return VIS_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)b) & 15) return VIS_ERR_ARG;
   const dim3 grid((rows + 3) / 4), block(256);
+  vis_clear_error();
   if (ln)
     hipLaunchKernelGGL(norm_rows_kernel<true>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w,
                        (const bf16_t*)b, (bf16_t*)y, rows, N, ldx, ldy, eps);

@@ -123,6 +123,7 @@ extern "C" int vis_qkv_rope_split(const void* qkv, const void* cosv, const void*
   p.S = S; p.ld_qkv = ld_qkv; p.Hq = Hq; p.Hkv = Hkv;
   p.k_tokens = k_tokens; p.k_pos0 = k_pos0; p.vt_ld = vt_ld;
   const dim3 grid((S + 63) / 64, Hq + 2 * Hkv), block(256);
+  vis_clear_error();
   if (HD == 128)
     hipLaunchKernelGGL(qkv_rope_split_kernel<128>, grid, block, 0, stream, p);
   else
@@ -176,6 +177,7 @@ extern "C" int vis_decode_rope_kv(const void* qkv, const void* cos_t, const void
   if (!qkv || !cos_t || !sin_t || !step_ptr || !q_out || !k_cache || !v_cache) return VIS_ERR_ARG;
   if (HD != 128 || Hq <= 0 || Hkv <= 0 || slot_base < 0 || slot_base >= cache_tokens) return VIS_ERR_ARG;
   const int total = (Hq + Hkv) * 64 + Hkv * 128;
+  vis_clear_error();
   hipLaunchKernelGGL(decode_rope_kv_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
                      (const bf16_t*)qkv, (const float*)cos_t, (const float*)sin_t, (const int*)step_ptr,
                      (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, Hq, Hkv, cache_tokens, slot_base);
