@@ -77,17 +77,15 @@ int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, cons
 int vis_gemv_bf16(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,
                   void* y, int N, int K, int ldw, int act, int out_f32, float eps, vis_stream_t stream);
 
-/* K4 (decode)  rotate q,k of one packed qkv row with cos/sin row *step_ptr and append k,v to
- * the cache at slot slot_base + *step_ptr.  step_ptr is a device int (graph-replayable). */
-int vis_decode_rope_kv(const void* qkv, const void* cos_t, const void* sin_t, const void* step_ptr,
-                       void* q_out, void* k_cache, void* v_cache, int Hq, int Hkv, int HD,
-                       int cache_tokens, int slot_base, vis_stream_t stream);
-
-/* K11  GQA attention of the new token over slot_base + *step_ptr + 1 cached keys, split over
- * the context (part_o [Hq][nsplit][128] f32, part_ml [Hq][nsplit][2] f32 workspaces). */
-int vis_decode_attn(const void* q, const void* k_cache, const void* v_cache, const void* step_ptr,
-                    void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int cache_tokens,
-                    int slot_base, int nsplit, float scale, vis_stream_t stream);
+/* K4 + K11 (decode)  one launch per layer for the single new token: M-RoPE of q,k from the packed
+ * projection row (cos/sin row *step_ptr of the [cache_tokens][128] f32 tables), KV-cache append at slot
+ * *step_ptr, GQA attention over the *step_ptr + 1 cached keys split nsplit ways over the context
+ * (nsplit * 128 >= cache_tokens), then a combine launch.  step_ptr is a device int: graph-replayable.
+ * Workspaces: part_o [Hq][nsplit][128] f32, part_ml [Hq][nsplit][2] f32.  out: [Hq*128] bf16.
+ * Replaces TF modeling_qwen2_vl.py:180-222 + :508-556 for q_len == 1 with a KV cache. */
+int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                    const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
+                    int cache_tokens, int nsplit, float scale, vis_stream_t stream);
 
 /* K12  next-token pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
  * torch.argmax), then *step += 1.  inv_temp > 0 samples at temperature 1/inv_temp by Gumbel-max with a

@@ -276,46 +276,45 @@ def test_gemv_swiglu(hip, device):
     _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="gemv swiglu")
 
 
-# ----------------------------------------------------------------------------- K4/K11 decode attention
-@pytest.mark.parametrize("Hq,Hkv,ctx0,steps", [(2, 1, 37, 3), (28, 4, 2249, 2)])
-def test_decode_rope_and_attention(hip, device, Hq, Hkv, ctx0, steps):
+# ----------------------------------------------------------------------------- K4/K11 fused decode attention
+@pytest.mark.parametrize("Hq,Hkv,ctx0,steps,T", [(2, 1, 37, 3, 128), (28, 4, 2249, 2, 4096), (28, 4, 127, 3, 256)])
+def test_decode_attention_fused(hip, device, Hq, Hkv, ctx0, steps, T):
+    """rope(q,k) + KV append + attention over the cache, position read from device memory."""
     HD = 128
-    T = ctx0 + 16
     kc = torch.zeros((Hkv, T, HD), dtype=torch.bfloat16, device=device)
     vc = torch.zeros((Hkv, T, HD), dtype=torch.bfloat16, device=device)
     kc[:, :ctx0] = _randn((Hkv, ctx0, HD), device, 70)
     vc[:, :ctx0] = _randn((Hkv, ctx0, HD), device, 71)
     g = torch.Generator().manual_seed(72)
-    ang = torch.rand((8, HD // 2), generator=g) * 6.28
+    ang = torch.rand((T, HD // 2), generator=g) * 6.28
     emb = torch.cat((ang, ang), -1)
     cos_t, sin_t = emb.cos().to(device), emb.sin().to(device)
-    step = torch.zeros(1, dtype=torch.int32, device=device)
-    nsplit = 8
+    step = torch.full((1,), ctx0, dtype=torch.int32, device=device)
+    nsplit = T // 128
     part_o = torch.empty(Hq * nsplit * HD, dtype=torch.float32, device=device)
     part_ml = torch.empty(Hq * nsplit * 2, dtype=torch.float32, device=device)
-    q_out = torch.empty((Hq, HD), dtype=torch.bfloat16, device=device)
     out = torch.empty((Hq * HD,), dtype=torch.bfloat16, device=device)
     kref, vref = kc.float().cpu().clone(), vc.float().cpu().clone()
     for t in range(steps):
+        slot = ctx0 + t
         qkv = _randn(((Hq + 2 * Hkv) * HD,), device, 80 + t)
-        hip.decode_rope_kv(qkv, cos_t, sin_t, step, q_out, kc, vc, Hq, Hkv, HD, ctx0)
-        hip.decode_attn(q_out, kc, vc, step, part_o, part_ml, out, Hq, Hkv, HD, ctx0, nsplit, HD ** -0.5)
+        hip.decode_attn(qkv, cos_t, sin_t, kc, vc, step, part_o, part_ml, out, Hq, Hkv, HD, nsplit, HD ** -0.5)
         x = qkv.float().cpu().reshape(Hq + 2 * Hkv, HD)
-        c, s_ = emb[t].cos(), emb[t].sin()
+        c, s_ = emb[slot].cos(), emb[slot].sin()
         qr = (x[:Hq] * c + _rotate_half(x[:Hq]) * s_).to(torch.bfloat16).float()
         kr = (x[Hq:Hq + Hkv] * c + _rotate_half(x[Hq:Hq + Hkv]) * s_).to(torch.bfloat16).float()
-        kref[:, ctx0 + t] = kr
-        vref[:, ctx0 + t] = x[Hq + Hkv:]
-        n = ctx0 + t + 1
+        kref[:, slot] = kr
+        vref[:, slot] = x[Hq + Hkv:]
+        n = slot + 1
         ref = torch.zeros(Hq, HD)
         for h in range(Hq):
             kv = h // (Hq // Hkv)
             p = torch.softmax((kref[kv, :n] @ qr[h]) * HD ** -0.5, dim=0)
             ref[h] = p @ vref[kv, :n]
-        _assert_close(q_out, qr, atol=2e-2, rtol=1e-2, what="decode rope q")
         _assert_close(out.reshape(Hq, HD), ref, atol=2e-2, rtol=2e-2, what=f"decode attn step {t}")
         step += 1
     _assert_close(kc[:, :ctx0 + steps], kref[:, :ctx0 + steps], atol=2e-2, rtol=1e-2, what="kv cache k")
+    assert torch.equal(vc[:, :ctx0 + steps].float().cpu(), vref[:, :ctx0 + steps])
 
 
 # ----------------------------------------------------------------------------- K12 glue

@@ -110,15 +110,18 @@ def main():
         res[name] = {"ms": t * 1e3, "GBs": N * K * 2 / t / 1e9}
         del w
 
-    # decode attention at ctx 2300
+    # fused decode attention at ctx 2300 (rope + KV append + attention + combine)
     kc = rnd((4, 4096, 128), dev)
     vc = rnd((4, 4096, 128), dev)
-    qd = rnd((28, 128), dev)
+    qkvd = rnd((36 * 128,), dev)
+    cos_t = torch.rand((4096, 128), device=dev)
+    sin_t = torch.rand((4096, 128), device=dev)
     step = torch.full((1,), 2300, dtype=torch.int32, device=dev)
-    po = torch.empty(28 * 16 * 128, dtype=torch.float32, device=dev)
-    pml = torch.empty(28 * 16 * 2, dtype=torch.float32, device=dev)
+    ns = 32
+    po = torch.empty(28 * ns * 128, dtype=torch.float32, device=dev)
+    pml = torch.empty(28 * ns * 2, dtype=torch.float32, device=dev)
     od = torch.empty(28 * 128, dtype=torch.bfloat16, device=dev)
-    t = timeit(lambda: hip.decode_attn(qd, kc, vc, step, po, pml, od, 28, 4, 128, 0, 16, 128 ** -0.5))
+    t = timeit(lambda: hip.decode_attn(qkvd, cos_t, sin_t, kc, vc, step, po, pml, od, 28, 4, 128, ns, 128 ** -0.5))
     res["decode_attn_ctx2300"] = {"ms": t * 1e3, "GBs": 2 * 4 * 2301 * 128 * 2 / t / 1e9}
 
     # stream-copy calibration (achievable HBM rate on this box)

@@ -43,12 +43,93 @@ __device__ __forceinline__ float dot8(const u32x4& w, const u32x4& x, float acc)
   return acc;
 }
 
-// every wave produces outputs in pairs (two weight rows in flight per lane)
+// Work unit = "task": one row PAIR (two weight rows, or the gate/up rows of one SwiGLU output) x one
+// K-segment of GV_SEG 16-byte chunks per lane.  A wave owns a contiguous range of pairs and walks its tasks
+// with two register sets: the loads of task t+1 are issued before task t is consumed, so up to
+// 2 x 2 x GV_SEG 16-byte loads per lane are in flight and the pipeline never drains between rows.
+// Weight loads are non-temporal (each byte is read exactly once per token).
+#define GV_SEG 8
+
+struct GvBuf {
+  u32x4 w0[GV_SEG], w1[GV_SEG];
+};
+
+__device__ __forceinline__ void gv_rows(const GemvArgs& p, bool swiglu, int pair, int& r0, int& r1) {
+  if (swiglu) {
+    r0 = ((pair >> 4) << 5) + (pair & 15);  // gate row in the 16-interleaved weight
+    r1 = r0 + 16;                            // matching up row
+  } else {
+    r0 = 2 * pair;
+    r1 = min(r0 + 1, p.N - 1);
+  }
+}
+
+__device__ __forceinline__ void gv_load(GvBuf& b, const GemvArgs& p, bool swiglu, int pair, int seg, int lane,
+                                        int nch) {
+  int r0, r1;
+  gv_rows(p, swiglu, pair, r0, r1);
+  const bf16_t* w0 = p.W + (size_t)r0 * p.ldw;
+  const bf16_t* w1 = p.W + (size_t)r1 * p.ldw;
+#pragma unroll
+  for (int u = 0; u < GV_SEG; ++u) {
+    // unconditional loads (clamped address): a predicated load would make hipcc wait vmcnt(0) per branch
+    const int c = min(lane + 64 * (seg * GV_SEG + u), nch - 1);
+    b.w0[u] = __builtin_nontemporal_load((const u32x4*)(w0 + c * 8));
+    b.w1[u] = __builtin_nontemporal_load((const u32x4*)(w1 + c * 8));
+  }
+}
+
+__device__ __forceinline__ void gv_consume(const GvBuf& b, const bf16_t* xs, int seg, int lane, int nch, float& a0,
+                                           float& a1) {
+#pragma unroll
+  for (int u = 0; u < GV_SEG; ++u) {
+    const int c = lane + 64 * (seg * GV_SEG + u);
+    u32x4 xv = *(const u32x4*)(xs + min(c, nch - 1) * 8);
+    if (c >= nch) xv = (u32x4){0u, 0u, 0u, 0u};  // clamped duplicate chunk contributes nothing
+    a0 = dot8(b.w0[u], xv, a0);
+    a1 = dot8(b.w1[u], xv, a1);
+  }
+}
+
+__device__ __forceinline__ void gv_finish(const GemvArgs& p, bool swiglu, int pair, int lane, float a0, float a1) {
+  a0 = wave_sum(a0);
+  a1 = wave_sum(a1);
+  if (lane != 0) return;
+  if (swiglu) {
+    ((bf16_t*)p.y)[pair] = f2bf(a0 / (1.0f + __expf(-a0)) * a1);
+    return;
+  }
+  const int o = 2 * pair;
+  const bool two = (o + 1 < p.N);
+  float v0 = a0, v1 = a1;
+  if (p.bias) { v0 += bf2f(p.bias[o]); if (two) v1 += bf2f(p.bias[o + 1]); }
+  if (p.R) { v0 += bf2f(p.R[o]); if (two) v1 += bf2f(p.R[o + 1]); }
+  if (p.out_f32) {
+    ((float*)p.y)[o] = v0;
+    if (two) ((float*)p.y)[o + 1] = v1;
+  } else {
+    ((bf16_t*)p.y)[o] = f2bf(v0);
+    if (two) ((bf16_t*)p.y)[o + 1] = f2bf(v1);
+  }
+}
+
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nch = p.K >> 3;
+
+  const bool swiglu = (p.act == GV_ACT_SWIGLU);
+  const int n_pairs = swiglu ? (p.N >> 1) : ((p.N + 1) >> 1);
+  const int n_waves = gridDim.x * 4;
+  const int wid = blockIdx.x * 4 + wave;
+  const int p_begin = (int)((long long)n_pairs * wid / n_waves);
+  const int p_end = (int)((long long)n_pairs * (wid + 1) / n_waves);
+  const int nseg = ((nch + 63) / 64 + GV_SEG - 1) / GV_SEG;
+  const int n_tasks = (p_end - p_begin) * nseg;
+
+  GvBuf A, B;
+  if (n_tasks > 0) gv_load(A, p, swiglu, p_begin, 0, lane, nch);  // in flight while x is staged
 
   // ---- stage x (optionally RMS-normalised) into LDS
   if (p.norm_w) {
@@ -77,66 +158,24 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   }
   __syncthreads();
 
-  const bool swiglu = (p.act == GV_ACT_SWIGLU);
-  const int n_out = swiglu ? (p.N >> 1) : p.N;
-  const int o_begin = blockIdx.x * p.outs_per_block;
-  const int o_end = min(o_begin + p.outs_per_block, n_out);
-
-  // swiglu: one output per wave-iteration from rows (gate, up); else two outputs
-  const int step = swiglu ? 4 : 8;
-  for (int o = o_begin + (swiglu ? wave : 2 * wave); o < o_end; o += step) {
-    int r0, r1;
-    if (swiglu) {
-      r0 = ((o >> 4) << 5) + (o & 15);  // gate row in the 16-interleaved weight
-      r1 = r0 + 16;                      // matching up row
-    } else {
-      r0 = o;
-      r1 = min(o + 1, p.N - 1);
-    }
-    const bf16_t* w0 = p.W + (size_t)r0 * p.ldw;
-    const bf16_t* w1 = p.W + (size_t)r1 * p.ldw;
-    float a0 = 0.f, a1 = 0.f;
-    int c = lane;
-    for (; c + 192 < nch; c += 256) {
-      u32x4 wa[4], wb[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        wa[u] = *(const u32x4*)(w0 + (c + 64 * u) * 8);
-        wb[u] = *(const u32x4*)(w1 + (c + 64 * u) * 8);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const u32x4 xv = *(const u32x4*)(xs + (c + 64 * u) * 8);
-        a0 = dot8(wa[u], xv, a0);
-        a1 = dot8(wb[u], xv, a1);
-      }
-    }
-    for (; c < nch; c += 64) {
-      const u32x4 wa = *(const u32x4*)(w0 + c * 8);
-      const u32x4 wb = *(const u32x4*)(w1 + c * 8);
-      const u32x4 xv = *(const u32x4*)(xs + c * 8);
-      a0 = dot8(wa, xv, a0);
-      a1 = dot8(wb, xv, a1);
-    }
-    a0 = wave_sum(a0);
-    a1 = wave_sum(a1);
-    if (lane == 0) {
-      if (swiglu) {
-        const float v = a0 / (1.0f + __expf(-a0)) * a1;
-        ((bf16_t*)p.y)[o] = f2bf(v);
-      } else {
-        float v0 = a0, v1 = a1;
-        if (p.bias) { v0 += bf2f(p.bias[o]); v1 += bf2f(p.bias[r1]); }
-        if (p.R) { v0 += bf2f(p.R[o]); v1 += bf2f(p.R[r1]); }
-        if (p.out_f32) {
-          ((float*)p.y)[o] = v0;
-          if (o + 1 < o_end) ((float*)p.y)[o + 1] = v1;
-        } else {
-          ((bf16_t*)p.y)[o] = f2bf(v0);
-          if (o + 1 < o_end) ((bf16_t*)p.y)[o + 1] = f2bf(v1);
-        }
-      }
-    }
+  float a0 = 0.f, a1 = 0.f;
+  int pair = p_begin, seg = 0;  // task being consumed
+  for (int t = 0; t < n_tasks; t += 2) {
+    // next task (t+1) -> B
+    int pair1 = pair, seg1 = seg + 1;
+    if (seg1 == nseg) { seg1 = 0; ++pair1; }
+    if (t + 1 < n_tasks) gv_load(B, p, swiglu, pair1, seg1, lane, nch);
+    gv_consume(A, xs, seg, lane, nch, a0, a1);
+    if (seg == nseg - 1) { gv_finish(p, swiglu, pair, lane, a0, a1); a0 = 0.f; a1 = 0.f; }
+    if (t + 1 >= n_tasks) break;
+    // task t+2 -> A
+    int pair2 = pair1, seg2 = seg1 + 1;
+    if (seg2 == nseg) { seg2 = 0; ++pair2; }
+    if (t + 2 < n_tasks) gv_load(A, p, swiglu, pair2, seg2, lane, nch);
+    gv_consume(B, xs, seg1, lane, nch, a0, a1);
+    if (seg1 == nseg - 1) { gv_finish(p, swiglu, pair1, lane, a0, a1); a0 = 0.f; a1 = 0.f; }
+    pair = pair2;
+    seg = seg2;
   }
 }
 
@@ -152,37 +191,49 @@ extern "C" int vis_gemv_bf16(const void* x, const void* W, const void* bias, con
   p.x = (const bf16_t*)x; p.W = (const bf16_t*)W; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R;
   p.norm_w = (const bf16_t*)norm_w; p.y = y;
   p.N = N; p.K = K; p.ldw = ldw; p.act = act; p.out_f32 = out_f32; p.eps = eps;
-  const int n_out = (act == GV_ACT_SWIGLU) ? N / 2 : N;
-  // >= 8 outputs per workgroup (4 waves x 2 rows); aim for ~2048 workgroups on big matrices
-  int opb = 8;
-  while (opb < 64 && (n_out + opb - 1) / opb > 2048) opb *= 2;
-  p.outs_per_block = opb;
-  const int blocks = (n_out + opb - 1) / opb;
+  p.outs_per_block = 0;
+  const int n_pairs = (act == GV_ACT_SWIGLU) ? N / 2 : (N + 1) / 2;
+  // one row pair per wave until the grid reaches ~4096 waves, then several pairs per wave
+  int blocks = (n_pairs + 3) / 4;
+  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
+  if (blocks > 2048) blocks = 2048;
   vis_clear_error();
   hipLaunchKernelGGL(gemv_bf16_kernel, dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
   return vis_check_launch();
 }
 
 // ---------------------------------------------------------------------------
-// Decode attention: grid (Hkv, nsplit).  ctx = slot_base + *step + 1 keys.
-// Partial results (unnormalised o, running max m in log2 domain, sum l) go to
-// a workspace and are merged by decode_attn_combine_kernel.
+// Fused decode attention (K4 + K11): one launch per layer does, for the single new token,
+//   * M-RoPE of q and k from the packed projection row (cos/sin row = *step_ptr),
+//   * the KV-cache append at slot *step_ptr (done by the split that owns that slot),
+//   * GQA attention over the *step_ptr + 1 cached keys, split over the context.
+// grid (Hkv, nsplit), 256 threads.  Every K and V row a thread needs is requested up front
+// (<= DA_ITERS 16-byte loads each), so a block exposes one HBM latency, not one per key.
+// The position lives in DEVICE memory: the launch is hipGraph-replayable.
+// Partials (unnormalised o, running max in the log2 domain, sum) are merged by
+// decode_attn_combine_kernel.
 #define DA_MAXG 8
-#define DA_MAXKEYS 1024  // keys per split held in LDS
+#define DA_ITERS 8                  // 16 keys per block iteration
+#define DA_MAXKEYS (16 * DA_ITERS)  // keys per split
 
 struct DecAttnArgs {
-  const bf16_t* q;        // [Hq][128] rotated query of the new token
-  const bf16_t* k_cache;  // [Hkv][cache_tokens][128]
-  const bf16_t* v_cache;  // [Hkv][cache_tokens][128]
-  const int* step_ptr;
+  const bf16_t* qkv;      // [(Hq + 2 Hkv) * 128] packed projection row of the new token (bias added)
+  const float* cos_t;     // [cache_tokens][128]
+  const float* sin_t;
+  bf16_t* k_cache;        // [Hkv][cache_tokens][128]
+  bf16_t* v_cache;
+  const int* step_ptr;    // slot of the new token
   float* part_o;          // [Hq][nsplit][128]
   float* part_ml;         // [Hq][nsplit][2]
-  int Hq, Hkv, cache_tokens, slot_base, nsplit;
+  int Hq, Hkv, cache_tokens, nsplit;
   float scale_log2;
 };
 
-__global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
-  constexpr int HD = 128;
+__global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
+  constexpr int HD = 128, HALF = 64;
+  __shared__ __attribute__((aligned(16))) float q_s[DA_MAXG][HD];
+  __shared__ __attribute__((aligned(16))) float knew_s[HD];
+  __shared__ __attribute__((aligned(16))) float vnew_s[HD];
   __shared__ float sc[DA_MAXG][DA_MAXKEYS];
   __shared__ float red[4][DA_MAXG][HD];
   __shared__ float ml[DA_MAXG][2];
@@ -190,42 +241,92 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
   const int sub = lane & 15, kq = lane >> 4;
   const int hkv = blockIdx.x, split = blockIdx.y;
   const int G = p.Hq / p.Hkv;
-  const int ctx = min(p.slot_base + *p.step_ptr + 1, p.cache_tokens);
+  const int slot = min(*p.step_ptr, p.cache_tokens - 1);
+  const int ctx = slot + 1;
   int per = (ctx + p.nsplit - 1) / p.nsplit;
   per = min((per + 15) & ~15, DA_MAXKEYS);
   const int ks = split * per;
   const int ke = min(ks + per, ctx);
   const int nk = max(ke - ks, 0);
 
-  const bf16_t* Kh = p.k_cache + (size_t)hkv * p.cache_tokens * HD;
-  const bf16_t* Vh = p.v_cache + (size_t)hkv * p.cache_tokens * HD;
+  bf16_t* Kh = p.k_cache + (size_t)hkv * p.cache_tokens * HD;
+  bf16_t* Vh = p.v_cache + (size_t)hkv * p.cache_tokens * HD;
 
-  // phase 1: scores.  16 lanes per key (8 dims each), 16 keys per block iteration
+  // ---- request every K / V row this thread will touch (the new token's row is not in the cache yet)
+  u32x4 kreg[DA_ITERS], vreg[DA_ITERS];
+#pragma unroll
+  for (int i = 0; i < DA_ITERS; ++i) {
+    const int kk = wave * 4 + kq + 16 * i;
+    kreg[i] = (u32x4){0u, 0u, 0u, 0u};
+    vreg[i] = (u32x4){0u, 0u, 0u, 0u};
+    if (kk < nk && ks + kk != slot) {
+      kreg[i] = *(const u32x4*)(Kh + (size_t)(ks + kk) * HD + sub * 8);
+      vreg[i] = *(const u32x4*)(Vh + (size_t)(ks + kk) * HD + sub * 8);
+    }
+  }
+
+  // ---- rotate q (G heads) and the new k; stage them (bf16-rounded, like the cached rows) in LDS
+  const float* cr = p.cos_t + (size_t)slot * HD;
+  const float* sr = p.sin_t + (size_t)slot * HD;
+  for (int it = tid; it < (G + 1) * HALF; it += 256) {
+    const int g = it / HALF, d = it - g * HALF;
+    const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
+    const float a = bf2f(p.qkv[head * HD + d]), b = bf2f(p.qkv[head * HD + HALF + d]);
+    const float oa = bf2f(f2bf(a * cr[d] - b * sr[d]));
+    const float ob = bf2f(f2bf(b * cr[HALF + d] + a * sr[HALF + d]));
+    if (g < G) {
+      q_s[g][d] = oa;
+      q_s[g][HALF + d] = ob;
+    } else {
+      knew_s[d] = oa;
+      knew_s[HALF + d] = ob;
+    }
+  }
+  if (tid < HD) vnew_s[tid] = bf2f(p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid]);
+  __syncthreads();
+  const bool owner = (slot >= ks) && (slot < ke);
+  if (owner && tid < HD) {  // KV-cache append
+    Kh[(size_t)slot * HD + tid] = f2bf(knew_s[tid]);
+    Vh[(size_t)slot * HD + tid] = f2bf(vnew_s[tid]);
+  }
+
   float qreg[DA_MAXG][8];
 #pragma unroll
-  for (int g = 0; g < DA_MAXG; ++g) {
-    if (g < G) unpack8(*(const u32x4*)(p.q + (size_t)(hkv * G + g) * HD + sub * 8), qreg[g]);
-  }
-  for (int kk = wave * 4 + kq; kk < nk; kk += 16) {
-    float kf[8];
-    unpack8(*(const u32x4*)(Kh + (size_t)(ks + kk) * HD + sub * 8), kf);
+  for (int g = 0; g < DA_MAXG; ++g)
+    if (g < G) {
 #pragma unroll
-    for (int g = 0; g < DA_MAXG; ++g) {
-      if (g < G) {
-        float s = 0.f;
+      for (int e = 0; e < 8; ++e) qreg[g][e] = q_s[g][sub * 8 + e];
+    }
+
+  // ---- phase 1: scores (16 lanes per key, 8 dims each)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += kf[e] * qreg[g][e];
-        s += __shfl_xor(s, 8, 64);
-        s += __shfl_xor(s, 4, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 1, 64);
-        if (sub == g) sc[g][kk] = s * p.scale_log2;
+  for (int i = 0; i < DA_ITERS; ++i) {
+    const int kk = wave * 4 + kq + 16 * i;
+    if (16 * i < nk) {  // block-uniform
+      float kf[8];
+      unpack8(kreg[i], kf);
+      if (kk < nk && ks + kk == slot) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) kf[e] = knew_s[sub * 8 + e];
+      }
+#pragma unroll
+      for (int g = 0; g < DA_MAXG; ++g) {
+        if (g < G) {
+          float s = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s += kf[e] * qreg[g][e];
+          s += __shfl_xor(s, 8, 64);
+          s += __shfl_xor(s, 4, 64);
+          s += __shfl_xor(s, 2, 64);
+          s += __shfl_xor(s, 1, 64);
+          if (sub == g && kk < nk) sc[g][kk] = s * p.scale_log2;
+        }
       }
     }
   }
   __syncthreads();
 
-  // phase 2: per-head softmax statistics over this split (one wave per head)
+  // ---- phase 2: per-head softmax statistics over this split (one wave per head)
   for (int g = wave; g < G; g += 4) {
     float mx = -1.0e30f;
     for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, sc[g][i]);
@@ -241,21 +342,29 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(DecAttnArgs p) {
   }
   __syncthreads();
 
-  // phase 3: o[g][d] = sum_k p[g][k] V[k][d]; 16 lanes per V row, 4 keys per wave iteration
+  // ---- phase 3: o[g][d] = sum_k p[g][k] V[k][d]
   float acc[DA_MAXG][8];
 #pragma unroll
   for (int g = 0; g < DA_MAXG; ++g)
 #pragma unroll
     for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-  for (int kk = wave * 4 + kq; kk < nk; kk += 16) {
-    float vf[8];
-    unpack8(*(const u32x4*)(Vh + (size_t)(ks + kk) * HD + sub * 8), vf);
 #pragma unroll
-    for (int g = 0; g < DA_MAXG; ++g) {
-      if (g < G) {
-        const float pw = sc[g][kk];
+  for (int i = 0; i < DA_ITERS; ++i) {
+    const int kk = wave * 4 + kq + 16 * i;
+    if (kk < nk) {
+      float vf[8];
+      unpack8(vreg[i], vf);
+      if (ks + kk == slot) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[g][e] += pw * vf[e];
+        for (int e = 0; e < 8; ++e) vf[e] = vnew_s[sub * 8 + e];
+      }
+#pragma unroll
+      for (int g = 0; g < DA_MAXG; ++g) {
+        if (g < G) {
+          const float pw = sc[g][kk];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[g][e] += pw * vf[e];
+        }
       }
     }
   }
@@ -300,20 +409,23 @@ __global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* _
   out[(size_t)hq * HD + d] = f2bf(l > 0.f ? o / l : 0.f);
 }
 
-extern "C" int vis_decode_attn(const void* q, const void* k_cache, const void* v_cache, const void* step_ptr,
-                               void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int cache_tokens,
-                               int slot_base, int nsplit, float scale, hipStream_t stream) {
-  if (!q || !k_cache || !v_cache || !step_ptr || !part_o || !part_ml || !out) return VIS_ERR_ARG;
+extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                               const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
+                               int cache_tokens, int nsplit, float scale, hipStream_t stream) {
+  if (!qkv || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !part_o || !part_ml || !out)
+    return VIS_ERR_ARG;
   if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Hq / Hkv > DA_MAXG) return VIS_ERR_ARG;
-  if (nsplit <= 0 || nsplit > 64) return VIS_ERR_ARG;
+  if (nsplit <= 0 || nsplit > 256 || cache_tokens <= 0) return VIS_ERR_ARG;
   if ((long long)nsplit * DA_MAXKEYS < cache_tokens) return VIS_ERR_ARG;  // every key must be covered
+  if (((uintptr_t)k_cache | (uintptr_t)v_cache) & 15) return VIS_ERR_ARG;
   DecAttnArgs p;
-  p.q = (const bf16_t*)q; p.k_cache = (const bf16_t*)k_cache; p.v_cache = (const bf16_t*)v_cache;
-  p.step_ptr = (const int*)step_ptr; p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
-  p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.slot_base = slot_base; p.nsplit = nsplit;
+  p.qkv = (const bf16_t*)qkv; p.cos_t = (const float*)cos_t; p.sin_t = (const float*)sin_t;
+  p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache; p.step_ptr = (const int*)step_ptr;
+  p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
+  p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.nsplit = nsplit;
   p.scale_log2 = scale * 1.4426950408889634f;
   vis_clear_error();
-  hipLaunchKernelGGL(decode_attn_kernel, dim3(Hkv, nsplit), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(Hkv, nsplit), dim3(256), 0, stream, p);
   hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(128), 0, stream, (const float*)part_o,
                      (const float*)part_ml, (bf16_t*)out, nsplit);
   return vis_check_launch();

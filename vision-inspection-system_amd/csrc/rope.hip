@@ -131,55 +131,3 @@ extern "C" int vis_qkv_rope_split(const void* qkv, const void* cosv, const void*
   return vis_check_launch();
 }
 
-// ---------------------------------------------------------------------------
-// Decode step: one new token per sequence.  Rotates q and k of the packed
-// projection row, writes q (f32-accurate bf16) to q_out[Hq][HD] and appends the
-// rotated k and the v row to the KV cache at slot  slot_base + *step.
-// The position comes from DEVICE memory so the launch can sit in a hipGraph
-// that is replayed for every generated token.
-// cos/sin tables: [max_new_tokens][HD] f32, row *step.
-__global__ __launch_bounds__(256) void decode_rope_kv_kernel(const bf16_t* __restrict__ qkv,
-                                                             const float* __restrict__ cos_t,
-                                                             const float* __restrict__ sin_t,
-                                                             const int* __restrict__ step_ptr,
-                                                             bf16_t* __restrict__ q_out,
-                                                             bf16_t* __restrict__ k_cache,
-                                                             bf16_t* __restrict__ v_cache, int Hq, int Hkv,
-                                                             int cache_tokens, int slot_base) {
-  constexpr int HD = 128, HALF = 64;
-  const int step = *step_ptr;
-  const int slot = slot_base + step;
-  if (slot >= cache_tokens) return;
-  const float* cr = cos_t + (size_t)step * HD;
-  const float* sr = sin_t + (size_t)step * HD;
-  const int nrot = (Hq + Hkv) * HALF;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nrot + Hkv * HD; i += gridDim.x * blockDim.x) {
-    if (i < nrot) {
-      const int head = i / HALF, d = i - head * HALF;
-      const float a = bf2f(qkv[head * HD + d]), b = bf2f(qkv[head * HD + HALF + d]);
-      const float oa = a * cr[d] - b * sr[d];
-      const float ob = b * cr[HALF + d] + a * sr[HALF + d];
-      bf16_t* dst = head < Hq ? q_out + head * HD
-                              : k_cache + ((size_t)(head - Hq) * cache_tokens + slot) * HD;
-      dst[d] = f2bf(oa);
-      dst[HALF + d] = f2bf(ob);
-    } else {
-      const int j = i - nrot;
-      const int hh = j / HD, d = j - hh * HD;
-      v_cache[((size_t)hh * cache_tokens + slot) * HD + d] = qkv[(Hq + Hkv + hh) * HD + d];
-    }
-  }
-}
-
-extern "C" int vis_decode_rope_kv(const void* qkv, const void* cos_t, const void* sin_t, const void* step_ptr,
-                                  void* q_out, void* k_cache, void* v_cache, int Hq, int Hkv, int HD,
-                                  int cache_tokens, int slot_base, hipStream_t stream) {
-  if (!qkv || !cos_t || !sin_t || !step_ptr || !q_out || !k_cache || !v_cache) return VIS_ERR_ARG;
-  if (HD != 128 || Hq <= 0 || Hkv <= 0 || slot_base < 0 || slot_base >= cache_tokens) return VIS_ERR_ARG;
-  const int total = (Hq + Hkv) * 64 + Hkv * 128;
-  vis_clear_error();
-  hipLaunchKernelGGL(decode_rope_kv_kernel, dim3((total + 255) / 256), dim3(256), 0, stream,
-                     (const bf16_t*)qkv, (const float*)cos_t, (const float*)sin_t, (const int*)step_ptr,
-                     (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache, Hq, Hkv, cache_tokens, slot_base);
-  return vis_check_launch();
-}

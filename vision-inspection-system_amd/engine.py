@@ -111,14 +111,14 @@ class Qwen2VLEngine:
     """One model replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
 
     def __init__(self, cfg: Qwen2VLConfig, weights: DeviceWeights, device, max_ctx: int = 4096,
-                 decode_splits: int = 16):
+                 decode_splits: int = 0):
         cfg.validate_for_kernels()
         hip.load()  # fail loudly when the gfx950 library is missing: there is no other path
         if not torch.cuda.is_available():
             raise hip.HipLibraryError("Qwen2VLEngine needs a ROCm GPU (no CPU fallback exists)")
         self.cfg, self.w, self.device = cfg, weights, torch.device(device)
         self.max_ctx = _round_up(max_ctx, 64)
-        self.nsplit = decode_splits
+        self.nsplit = decode_splits or max(1, self.max_ctx // 128)  # <= 128 keys per split
         self.lock = threading.Lock()
         dev, bf = self.device, torch.bfloat16
         L, Hkv, Hq, D, H = cfg.layers, cfg.kv_heads, cfg.heads, cfg.head_dim, cfg.hidden
@@ -137,7 +137,6 @@ class Qwen2VLEngine:
         self.d_x = torch.empty((1, H), dtype=bf, device=dev)
         self.d_x2 = torch.empty((1, H), dtype=bf, device=dev)
         self.d_qkv = torch.empty(nq, dtype=bf, device=dev)
-        self.d_q = torch.empty((Hq, D), dtype=bf, device=dev)
         self.d_attn = torch.empty(Hq * D, dtype=bf, device=dev)
         self.d_act = torch.empty(cfg.intermediate, dtype=bf, device=dev)
         self.part_o = torch.empty(Hq * self.nsplit * D, dtype=torch.float32, device=dev)
@@ -274,10 +273,8 @@ class Qwen2VLEngine:
         x, x2 = self.d_x, self.d_x2
         for li, lw in enumerate(w.llm):
             hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
-            hip.decode_rope_kv(self.d_qkv, self.cos_t, self.sin_t, self.step, self.d_q, self.kcache[li],
-                               self.vcache[li], Hq, Hkv, D, 0)
-            hip.decode_attn(self.d_q, self.kcache[li], self.vcache[li], self.step, self.part_o, self.part_ml,
-                            self.d_attn, Hq, Hkv, D, 0, self.nsplit, scale)
+            hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
+                            self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
             hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
             hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])

@@ -27,8 +27,7 @@ _SIGS = {
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
-    "vis_decode_rope_kv": "ppppppp" + "iiiii" + "p",
-    "vis_decode_attn": "ppppppp" + "iiiiii" + "f" + "p",
+    "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
@@ -214,25 +213,25 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     return out
 
 
-def decode_rope_kv(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, step: torch.Tensor,
-                   q_out: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_q: int, n_kv: int,
-                   head_dim: int, slot_base: int) -> None:
-    if step.dtype != torch.int32 or cos_t.dtype != torch.float32:
-        raise HipLibraryError("decode_rope_kv: step int32 / cos f32 required")
-    if k_cache.shape[0] != n_kv or k_cache.shape[2] != head_dim or not k_cache.is_contiguous():
-        raise HipLibraryError("decode_rope_kv: bad cache shape")
-    rc = load().vis_decode_rope_kv(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(step), _ptr(q_out), _ptr(k_cache),
-                                   _ptr(v_cache), n_q, n_kv, head_dim, k_cache.shape[1], slot_base, _stream())
-    _check(rc, "vis_decode_rope_kv")
-
-
-def decode_attn(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, step: torch.Tensor,
-                part_o: torch.Tensor, part_ml: torch.Tensor, out: torch.Tensor, n_q: int, n_kv: int,
-                head_dim: int, slot_base: int, nsplit: int, scale: float) -> torch.Tensor:
+def decode_attn(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
+                v_cache: torch.Tensor, step: torch.Tensor, part_o: torch.Tensor, part_ml: torch.Tensor,
+                out: torch.Tensor, n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float) -> torch.Tensor:
+    """Fused decode step attention: rope(q,k) + KV append at slot *step + attention over *step+1 keys."""
+    _bf16(qkv, "qkv"); _bf16(k_cache, "k_cache")
+    if step.dtype != torch.int32 or cos_t.dtype != torch.float32 or sin_t.dtype != torch.float32:
+        raise HipLibraryError("decode_attn: step int32 / cos,sin f32 required")
+    if k_cache.shape[0] != n_kv or k_cache.shape[2] != head_dim or not k_cache.is_contiguous() \
+            or v_cache.shape != k_cache.shape or not v_cache.is_contiguous():
+        raise HipLibraryError("decode_attn: bad cache shape")
+    T = k_cache.shape[1]
+    if cos_t.shape != (T, head_dim) or sin_t.shape != (T, head_dim) or not cos_t.is_contiguous():
+        raise HipLibraryError("decode_attn: cos/sin tables must be [cache_tokens, head_dim]")
+    if qkv.numel() != (n_q + 2 * n_kv) * head_dim:
+        raise HipLibraryError("decode_attn: bad qkv row")
     if part_o.dtype != torch.float32 or part_o.numel() < n_q * nsplit * head_dim or part_ml.numel() < n_q * nsplit * 2:
         raise HipLibraryError("decode_attn: workspace too small")
-    rc = load().vis_decode_attn(_ptr(q), _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(part_o), _ptr(part_ml),
-                                _ptr(out), n_q, n_kv, head_dim, k_cache.shape[1], slot_base, nsplit, scale,
+    rc = load().vis_decode_attn(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(k_cache), _ptr(v_cache), _ptr(step),
+                                _ptr(part_o), _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, T, nsplit, scale,
                                 _stream())
     _check(rc, "vis_decode_attn")
     return out
