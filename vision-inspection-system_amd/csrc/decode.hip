@@ -393,20 +393,45 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   }
 }
 
-__global__ __launch_bounds__(128) void decode_attn_combine_kernel(const float* __restrict__ part_o,
+// merge the per-split partials of one query head: 256 threads = 128 dims x 2 split-halves, all loads
+// of a thread are independent (4 in flight), statistics staged through LDS first
+__global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
                                                                   bf16_t* __restrict__ out, int nsplit) {
   constexpr int HD = 128;
-  const int hq = blockIdx.x, d = threadIdx.x;
-  float M = -1.0e30f;
-  for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[((size_t)hq * nsplit + s) * 2]);
-  float o = 0.f, l = 0.f;
-  for (int s = 0; s < nsplit; ++s) {
-    const float w = exp2f(part_ml[((size_t)hq * nsplit + s) * 2] - M);
-    l += w * part_ml[((size_t)hq * nsplit + s) * 2 + 1];
-    o += w * part_o[((size_t)hq * nsplit + s) * HD + d];
+  __shared__ float wgt[256];
+  __shared__ float osum[2][HD];
+  __shared__ float stat[2];
+  const int hq = blockIdx.x, tid = threadIdx.x, d = tid & 127, half = tid >> 7;
+  const float* ml = part_ml + (size_t)hq * nsplit * 2;
+  float m = -1.0e30f, l = 0.f;
+  if (tid < nsplit) { m = ml[tid * 2]; l = ml[tid * 2 + 1]; }
+  float M = wave_max(m);
+  __shared__ float wm[4];
+  if ((tid & 63) == 0) wm[tid >> 6] = M;
+  __syncthreads();
+  M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+  const float w = (tid < nsplit) ? exp2f(m - M) : 0.f;
+  wgt[tid] = w;
+  float lw = wave_sum(w * l);
+  __syncthreads();
+  if ((tid & 63) == 0) wm[tid >> 6] = lw;
+  const float* po = part_o + (size_t)hq * nsplit * HD + d;
+  float o = 0.f;
+  int s = half;
+  for (; s + 6 < nsplit; s += 8) {
+    const float v0 = po[(size_t)s * HD], v1 = po[(size_t)(s + 2) * HD], v2 = po[(size_t)(s + 4) * HD],
+                v3 = po[(size_t)(s + 6) * HD];
+    o += wgt[s] * v0 + wgt[s + 2] * v1 + wgt[s + 4] * v2 + wgt[s + 6] * v3;
   }
-  out[(size_t)hq * HD + d] = f2bf(l > 0.f ? o / l : 0.f);
+  for (; s < nsplit; s += 2) o += wgt[s] * po[(size_t)s * HD];
+  osum[half][d] = o;
+  __syncthreads();
+  if (tid < HD) {
+    const float lt = wm[0] + wm[1] + wm[2] + wm[3];
+    const float ot = osum[0][tid] + osum[1][tid];
+    out[(size_t)hq * HD + tid] = f2bf(lt > 0.f ? ot / lt : 0.f);
+  }
 }
 
 extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
@@ -426,7 +451,7 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
   p.scale_log2 = scale * 1.4426950408889634f;
   vis_clear_error();
   hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(Hkv, nsplit), dim3(256), 0, stream, p);
-  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(128), 0, stream, (const float*)part_o,
+  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(256), 0, stream, (const float*)part_o,
                      (const float*)part_ml, (bf16_t*)out, nsplit);
   return vis_check_launch();
 }

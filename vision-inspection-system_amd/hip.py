@@ -11,7 +11,7 @@ import ctypes
 import os
 from typing import Optional
 
-import torch
+import torch  # imported BEFORE the library is dlopen-ed: libvis_hip.so must bind to the HIP runtime torch loaded
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libvis_hip.so")
