@@ -70,8 +70,8 @@ class Qwen2VLConfig:
             problems.append(f"LLM head_dim must be 128, got {self.head_dim}")
         if self.v_head_dim != 80:
             problems.append(f"ViT head_dim must be 80, got {self.v_head_dim}")
-        if self.heads % self.kv_heads or self.heads // self.kv_heads > 8:
-            problems.append("heads/kv_heads must be an integer <= 8")
+        if self.heads % self.kv_heads or self.heads // self.kv_heads not in (1, 2, 4, 7, 8):
+            problems.append("heads/kv_heads must be one of 1, 2, 4, 7, 8 (instantiated GQA group sizes)")
         for nm, v in (("hidden", self.hidden), ("intermediate", self.intermediate), ("v_embed", self.v_embed),
                       ("v_mlp", self.v_mlp), ("merger", self.v_embed * self.merge ** 2)):
             if v % 64:

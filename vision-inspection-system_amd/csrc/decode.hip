@@ -212,7 +212,6 @@ extern "C" int vis_gemv_bf16(const void* x, const void* W, const void* bias, con
 // The position lives in DEVICE memory: the launch is hipGraph-replayable.
 // Partials (unnormalised o, running max in the log2 domain, sum) are merged by
 // decode_attn_combine_kernel.
-#define DA_MAXG 8
 #define DA_ITERS 8                  // 16 keys per block iteration
 #define DA_MAXKEYS (16 * DA_ITERS)  // keys per split
 
@@ -229,18 +228,27 @@ struct DecAttnArgs {
   float scale_log2;
 };
 
+// Structure (no cross-lane reductions inside a wave):
+//   scores : S^T[key][head] = K * Q^T on the MFMA (v_mfma_f32_16x16x32_bf16): a K row group of 16 keys x 128
+//            dims is loaded straight from the cache into the A-operand layout (lane = key, 16 B of d), Q^T
+//            (heads padded to 16) is the B operand; the accumulator already has (key, head) per lane.
+//   softmax: statistics per head over the <= 128 keys of the split (LDS).
+//   P * V  : each lane owns two output dims for all G heads and walks its wave's keys; V rows are read as
+//            256-byte coalesced rows, p[head][key] is an LDS broadcast; waves are merged through LDS.
+template <int G>
 __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   constexpr int HD = 128, HALF = 64;
-  __shared__ __attribute__((aligned(16))) float q_s[DA_MAXG][HD];
-  __shared__ __attribute__((aligned(16))) float knew_s[HD];
-  __shared__ __attribute__((aligned(16))) float vnew_s[HD];
-  __shared__ float sc[DA_MAXG][DA_MAXKEYS];
-  __shared__ float red[4][DA_MAXG][HD];
-  __shared__ float ml[DA_MAXG][2];
+  constexpr int KGRP = DA_MAXKEYS / 16 / 4;  // 16-key groups per wave (2)
+  constexpr int VROWS = DA_MAXKEYS / 4;      // V rows per wave (32)
+  __shared__ __attribute__((aligned(16))) bf16_t q_s[16][HD];   // heads >= G are zero
+  __shared__ __attribute__((aligned(16))) bf16_t knew_s[HD];
+  __shared__ __attribute__((aligned(16))) bf16_t vnew_s[HD];
+  __shared__ float sc[G][DA_MAXKEYS];
+  __shared__ float red[4][G][HD];
+  __shared__ float ml[G][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int sub = lane & 15, kq = lane >> 4;
+  const int l15 = lane & 15, h = lane >> 4;
   const int hkv = blockIdx.x, split = blockIdx.y;
-  const int G = p.Hq / p.Hkv;
   const int slot = min(*p.step_ptr, p.cache_tokens - 1);
   const int ctx = slot + 1;
   int per = (ctx + p.nsplit - 1) / p.nsplit;
@@ -252,81 +260,70 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   bf16_t* Kh = p.k_cache + (size_t)hkv * p.cache_tokens * HD;
   bf16_t* Vh = p.v_cache + (size_t)hkv * p.cache_tokens * HD;
 
-  // ---- request every K / V row this thread will touch (the new token's row is not in the cache yet)
-  u32x4 kreg[DA_ITERS], vreg[DA_ITERS];
+  // ---- issue every cache read up front (unconditional, clamped rows: one exposed HBM latency per block)
+  u32x4 kreg[KGRP][4];
 #pragma unroll
-  for (int i = 0; i < DA_ITERS; ++i) {
-    const int kk = wave * 4 + kq + 16 * i;
-    kreg[i] = (u32x4){0u, 0u, 0u, 0u};
-    vreg[i] = (u32x4){0u, 0u, 0u, 0u};
-    if (kk < nk && ks + kk != slot) {
-      kreg[i] = *(const u32x4*)(Kh + (size_t)(ks + kk) * HD + sub * 8);
-      vreg[i] = *(const u32x4*)(Vh + (size_t)(ks + kk) * HD + sub * 8);
-    }
+  for (int gi = 0; gi < KGRP; ++gi) {
+    const int row = min(ks + (wave + 4 * gi) * 16 + l15, p.cache_tokens - 1);
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) kreg[gi][ds] = *(const u32x4*)(Kh + (size_t)row * HD + ds * 32 + 8 * h);
+  }
+  uint32_t vreg[VROWS];
+#pragma unroll
+  for (int i = 0; i < VROWS; ++i) {
+    const int row = min(ks + wave + 4 * i, p.cache_tokens - 1);
+    vreg[i] = *(const uint32_t*)(Vh + (size_t)row * HD + 2 * lane);
   }
 
-  // ---- rotate q (G heads) and the new k; stage them (bf16-rounded, like the cached rows) in LDS
+  // ---- rotate q (G heads) and the new k; stage them as bf16 (exactly what later steps read back)
   const float* cr = p.cos_t + (size_t)slot * HD;
   const float* sr = p.sin_t + (size_t)slot * HD;
   for (int it = tid; it < (G + 1) * HALF; it += 256) {
     const int g = it / HALF, d = it - g * HALF;
     const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
     const float a = bf2f(p.qkv[head * HD + d]), b = bf2f(p.qkv[head * HD + HALF + d]);
-    const float oa = bf2f(f2bf(a * cr[d] - b * sr[d]));
-    const float ob = bf2f(f2bf(b * cr[HALF + d] + a * sr[HALF + d]));
-    if (g < G) {
-      q_s[g][d] = oa;
-      q_s[g][HALF + d] = ob;
-    } else {
-      knew_s[d] = oa;
-      knew_s[HALF + d] = ob;
-    }
+    const bf16_t oa = f2bf(a * cr[d] - b * sr[d]);
+    const bf16_t ob = f2bf(b * cr[HALF + d] + a * sr[HALF + d]);
+    bf16_t* dst = (g < G) ? q_s[g] : knew_s;
+    dst[d] = oa;
+    dst[HALF + d] = ob;
   }
-  if (tid < HD) vnew_s[tid] = bf2f(p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid]);
+  for (int it = tid; it < (16 - G) * HD; it += 256) q_s[G + it / HD][it % HD] = 0;
+  if (tid < HD) vnew_s[tid] = p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid];
   __syncthreads();
   const bool owner = (slot >= ks) && (slot < ke);
-  if (owner && tid < HD) {  // KV-cache append
-    Kh[(size_t)slot * HD + tid] = f2bf(knew_s[tid]);
-    Vh[(size_t)slot * HD + tid] = f2bf(vnew_s[tid]);
+  if (owner && tid < HD) {  // KV-cache append (no other block reads this row in this launch)
+    Kh[(size_t)slot * HD + tid] = knew_s[tid];
+    Vh[(size_t)slot * HD + tid] = vnew_s[tid];
   }
 
-  float qreg[DA_MAXG][8];
+  // ---- scores on the MFMA
+  bf16x8 qf[4];
 #pragma unroll
-  for (int g = 0; g < DA_MAXG; ++g)
-    if (g < G) {
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(&q_s[l15][ds * 32 + 8 * h]);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) qreg[g][e] = q_s[g][sub * 8 + e];
-    }
-
-  // ---- phase 1: scores (16 lanes per key, 8 dims each)
+  for (int gi = 0; gi < KGRP; ++gi) {
+    const int kbase = (wave + 4 * gi) * 16;
+    if (kbase < nk) {  // wave-uniform
+      const bool is_new = (ks + kbase + l15 == slot);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < DA_ITERS; ++i) {
-    const int kk = wave * 4 + kq + 16 * i;
-    if (16 * i < nk) {  // block-uniform
-      float kf[8];
-      unpack8(kreg[i], kf);
-      if (kk < nk && ks + kk == slot) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) kf[e] = knew_s[sub * 8 + e];
+      for (int ds = 0; ds < 4; ++ds) {
+        u32x4 kv = kreg[gi][ds];
+        const u32x4 nv = *(const u32x4*)(&knew_s[ds * 32 + 8 * h]);
+        if (is_new) kv = nv;
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kv), qf[ds], acc, 0, 0, 0);
       }
+      // acc[r] = S^T[key = kbase + 4h + r][head = l15]
+      if (l15 < G) {
 #pragma unroll
-      for (int g = 0; g < DA_MAXG; ++g) {
-        if (g < G) {
-          float s = 0.f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) s += kf[e] * qreg[g][e];
-          s += __shfl_xor(s, 8, 64);
-          s += __shfl_xor(s, 4, 64);
-          s += __shfl_xor(s, 2, 64);
-          s += __shfl_xor(s, 1, 64);
-          if (sub == g && kk < nk) sc[g][kk] = s * p.scale_log2;
-        }
+        for (int r = 0; r < 4; ++r) sc[l15][kbase + 4 * h + r] = acc[r] * p.scale_log2;
       }
     }
   }
   __syncthreads();
 
-  // ---- phase 2: per-head softmax statistics over this split (one wave per head)
+  // ---- per-head softmax statistics over this split (one wave per head)
   for (int g = wave; g < G; g += 4) {
     float mx = -1.0e30f;
     for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, sc[g][i]);
@@ -342,43 +339,29 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   }
   __syncthreads();
 
-  // ---- phase 3: o[g][d] = sum_k p[g][k] V[k][d]
-  float acc[DA_MAXG][8];
+  // ---- O[g][d] += p[g][key] * V[key][d]; lane owns d = 2*lane, 2*lane+1
+  float acc0[G], acc1[G];
 #pragma unroll
-  for (int g = 0; g < DA_MAXG; ++g)
+  for (int g = 0; g < G; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
+  const uint32_t vnew = *(const uint32_t*)(&vnew_s[2 * lane]);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
+  for (int i = 0; i < VROWS; ++i) {
+    const int kk = wave + 4 * i;
+    if (kk < nk) {  // wave-uniform
+      const uint32_t raw = (ks + kk == slot) ? vnew : vreg[i];
+      const float v0 = __uint_as_float(raw << 16), v1 = __uint_as_float(raw & 0xffff0000u);
 #pragma unroll
-  for (int i = 0; i < DA_ITERS; ++i) {
-    const int kk = wave * 4 + kq + 16 * i;
-    if (kk < nk) {
-      float vf[8];
-      unpack8(vreg[i], vf);
-      if (ks + kk == slot) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vf[e] = vnew_s[sub * 8 + e];
-      }
-#pragma unroll
-      for (int g = 0; g < DA_MAXG; ++g) {
-        if (g < G) {
-          const float pw = sc[g][kk];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) acc[g][e] += pw * vf[e];
-        }
+      for (int g = 0; g < G; ++g) {
+        const float pw = sc[g][kk];
+        acc0[g] += pw * v0;
+        acc1[g] += pw * v1;
       }
     }
   }
 #pragma unroll
-  for (int g = 0; g < DA_MAXG; ++g) {
-    if (g < G) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float v = acc[g][e];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        if (kq == 0) red[wave][g][sub * 8 + e] = v;
-      }
-    }
+  for (int g = 0; g < G; ++g) {
+    red[wave][g][2 * lane] = acc0[g];
+    red[wave][g][2 * lane + 1] = acc1[g];
   }
   __syncthreads();
   for (int i = tid; i < G * HD; i += 256) {
@@ -439,7 +422,9 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
                                int cache_tokens, int nsplit, float scale, hipStream_t stream) {
   if (!qkv || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !part_o || !part_ml || !out)
     return VIS_ERR_ARG;
-  if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || Hq / Hkv > DA_MAXG) return VIS_ERR_ARG;
+  if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  const int G = Hq / Hkv;
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;  // instantiated GQA group sizes
   if (nsplit <= 0 || nsplit > 256 || cache_tokens <= 0) return VIS_ERR_ARG;
   if ((long long)nsplit * DA_MAXKEYS < cache_tokens) return VIS_ERR_ARG;  // every key must be covered
   if (((uintptr_t)k_cache | (uintptr_t)v_cache) & 15) return VIS_ERR_ARG;
@@ -450,7 +435,14 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
   p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.nsplit = nsplit;
   p.scale_log2 = scale * 1.4426950408889634f;
   vis_clear_error();
-  hipLaunchKernelGGL(decode_attn_fused_kernel, dim3(Hkv, nsplit), dim3(256), 0, stream, p);
+  const dim3 grid(Hkv, nsplit), block(256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL(decode_attn_fused_kernel<1>, grid, block, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL(decode_attn_fused_kernel<2>, grid, block, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL(decode_attn_fused_kernel<4>, grid, block, 0, stream, p); break;
+    case 7: hipLaunchKernelGGL(decode_attn_fused_kernel<7>, grid, block, 0, stream, p); break;
+    default: hipLaunchKernelGGL(decode_attn_fused_kernel<8>, grid, block, 0, stream, p); break;
+  }
   hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(256), 0, stream, (const float*)part_o,
                      (const float*)part_ml, (bf16_t*)out, nsplit);
   return vis_check_launch();
