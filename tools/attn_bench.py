@@ -1,0 +1,31 @@
+"""Attention-only microbench (ViT varlen d=80 and LLM causal d=128) for profiling runs."""
+import sys, os, argparse
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vision_inspection_system_amd import hip
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--which", default="vit")
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+hip.load()
+S, Hq, Hkv, HD, causal = (4900, 16, 16, 80, False) if a.which == "vit" else (2249, 28, 4, 128, True)
+q = torch.randn((Hq, S, HD), device=dev).to(torch.bfloat16)
+k = torch.randn((Hkv, S, HD), device=dev).to(torch.bfloat16)
+ld = (S + 63) // 64 * 64
+vt = torch.randn((Hkv, HD, ld), device=dev).to(torch.bfloat16)
+o = torch.empty((S, Hq * HD), dtype=torch.bfloat16, device=dev)
+work = hip.make_attn_work([(0, S)], causal, dev)
+for _ in range(2):
+    hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(a.reps):
+    hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
+e.record()
+torch.cuda.synchronize()
+t = s.elapsed_time(e) / a.reps * 1e-3
+fl = 4.0 * S * S * HD * Hq * (0.5 if causal else 1.0)
+print(f"{a.which}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s")

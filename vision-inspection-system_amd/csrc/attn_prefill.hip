@@ -26,7 +26,8 @@
 //    contiguous) with two ds_read_b64 per fragment.  No cross-lane movement of
 //    P and no transposed LDS read are needed.
 //  * K tile: 256-B rows, 16-B chunk index XOR (row & 15)   -> conflict-free b128
-//    (head_dim 80: 208-B padded rows, zero-filled d 80..95);
+//    (head_dim 80: 224-B padded rows - 16-B slot (14 r + c) mod 16 is distinct over every ds_read_b128
+//    lane group - with zero-filled d 80..95);
 //    V^T tile: 128-B rows, 8-B slot index XOR (d & 14)     -> conflict-free b64.
 // Online softmax in the log2 domain with a finite -1e30 sentinel (no inf-inf).
 // Output O[s][head*HD + d] is staged through LDS and written as whole 16-B
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   constexpr int DKS = (HD + 31) / 32;           // QK^T k-steps over d: 4 / 3
   constexpr int ND = HD / 16;                   // P*V output blocks over d: 8 / 5
   constexpr int KCH = HD / 8;                   // valid 16-B chunks per K row: 16 / 10
-  constexpr int KROW = (HD == 128) ? 256 : 208; // LDS bytes per K row
+  constexpr int KROW = (HD == 128) ? 256 : 224; // LDS bytes per K row (224: conflict-free b128 reads)
   constexpr int K_BYTES = 64 * KROW;            // 16384 / 13312
   constexpr int V_BYTES = HD * 128;             // 16384 / 10240
   constexpr int BUF = K_BYTES + V_BYTES;
@@ -96,46 +97,40 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     }
   }
 
+  // per-thread staging slots, computed once (no div/mod inside the KV loop)
+  int k_goff[K_ITERS], k_loff[K_ITERS], k_row[K_ITERS], v_goff[V_ITERS], v_loff[V_ITERS];
+#pragma unroll
+  for (int i = 0; i < K_ITERS; ++i) {
+    const int it = min(tid + i * 256, 64 * KCH - 1);
+    const int row = it / KCH, c = it - row * KCH;
+    k_row[i] = row;
+    k_goff[i] = c * 8;
+    k_loff[i] = row * KROW + (((HD == 128) ? (c ^ (row & 15)) : c) << 4);
+  }
+#pragma unroll
+  for (int i = 0; i < V_ITERS; ++i) {
+    const int it = min(tid + i * 256, HD * 8 - 1);
+    const int d = it >> 3, c = it & 7;
+    v_goff[i] = d * p.vt_ld + c * 8;
+    v_loff[i] = K_BYTES + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+  }
   u32x4 kreg[K_ITERS], vreg[V_ITERS];
+  // loads are unconditional (a thread past the end re-loads the last chunk; the duplicate store is benign)
   auto load_tile = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < K_ITERS; ++i) {
-      const int it = tid + i * 256;
-      if (it < 64 * KCH) {
-        const int row = it / KCH, c = it - row * KCH;
-        const int key = min(kt + row, p.k_tokens - 1);
-        kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + c * 8);
-      }
+      const int key = min(kt + k_row[i], p.k_tokens - 1);
+      kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + k_goff[i]);
     }
 #pragma unroll
-    for (int i = 0; i < V_ITERS; ++i) {
-      const int it = tid + i * 256;
-      if (it < HD * 8) {
-        const int d = it >> 3, c = it & 7;
-        vreg[i] = *(const u32x4*)(Vh + (size_t)d * p.vt_ld + kt + c * 8);
-      }
-    }
+    for (int i = 0; i < V_ITERS; ++i) vreg[i] = *(const u32x4*)(Vh + v_goff[i] + kt);
   };
   auto store_tile = [&](int buf) {
-    char* kb = lds + buf * BUF;
-    char* vb = kb + K_BYTES;
+    char* base = lds + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < K_ITERS; ++i) {
-      const int it = tid + i * 256;
-      if (it < 64 * KCH) {
-        const int row = it / KCH, c = it - row * KCH;
-        const int pc = (HD == 128) ? (c ^ (row & 15)) : c;
-        *(u32x4*)(kb + row * KROW + pc * 16) = kreg[i];
-      }
-    }
+    for (int i = 0; i < K_ITERS; ++i) *(u32x4*)(base + k_loff[i]) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < V_ITERS; ++i) {
-      const int it = tid + i * 256;
-      if (it < HD * 8) {
-        const int d = it >> 3, c = it & 7;
-        *(u32x4*)(vb + d * 128 + ((c ^ ((d >> 1) & 7)) << 4)) = vreg[i];
-      }
-    }
+    for (int i = 0; i < V_ITERS; ++i) *(u32x4*)(base + v_loff[i]) = vreg[i];
   };
 
   f32x4 oacc[2][ND];
@@ -185,31 +180,33 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
             sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], sacc[kbk][qb], 0, 0, 0);
       }
 
-      // ---- online softmax (query on the lane, keys in registers)
+      // ---- online softmax (query on the lane, keys in registers), log2 domain:
+      //      p = exp2(s * scale_log2 - m), one FMA + one raw v_exp_f32 per score
       const bool need_mask = (kt < k0) || (kt + 64 > k1) || (CAUSAL && (kt + 63 > wq0));
       float alpha[2];
       bf16x8 pf[2][2];
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
         const int q = wq0 + qb * 16 + l15;
-        float mx = ATT_NEG;
+        if (need_mask) {
 #pragma unroll
-        for (int kbk = 0; kbk < 4; ++kbk)
+          for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float s = sacc[kbk][qb][r] * p.scale_log2;
-            if (need_mask) {
+            for (int r = 0; r < 4; ++r) {
               const int key = kt + kbk * 16 + 4 * h + r;
               const bool ok = (key >= k0) && (key < k1) && (!CAUSAL || key <= q);
-              s = ok ? s : ATT_NEG;
+              sacc[kbk][qb][r] = ok ? sacc[kbk][qb][r] : ATT_NEG;
             }
-            sacc[kbk][qb][r] = s;
-            mx = fmaxf(mx, s);
-          }
+        }
+        float mx = fmaxf(fmaxf(sacc[0][qb][0], sacc[0][qb][1]), fmaxf(sacc[0][qb][2], sacc[0][qb][3]));
+#pragma unroll
+        for (int kbk = 1; kbk < 4; ++kbk)
+          mx = fmaxf(fmaxf(mx, fmaxf(sacc[kbk][qb][0], sacc[kbk][qb][1])), fmaxf(sacc[kbk][qb][2], sacc[kbk][qb][3]));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrow[qb], mx);
-        alpha[qb] = exp2f(mrow[qb] - mnew);
+        // raw scores are masked with -1e30; scaled they stay a huge negative number
+        const float mnew = fmaxf(mrow[qb], mx * p.scale_log2);
+        alpha[qb] = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
         mrow[qb] = mnew;
         float ls = 0.f;
         float pv[4][4];
@@ -217,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = exp2f(sacc[kbk][qb][r] - mnew);
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
             pv[kbk][r] = e;
             ls += e;
           }
