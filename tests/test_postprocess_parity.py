@@ -99,3 +99,53 @@ def test_reference_test_suite_cases():
     assert DefectInfo(**{**d1, "type": "  CRACK "}).type == "crack"
     r = VLMAnalysisResult(**{**dam, "defects": [d1, d2, {**d1, "type": "Crack"}]})
     assert r.critical_defect_count == 2 and sorted(r.defect_types) == ["crack", "rust"]
+
+
+@pytest.mark.parametrize("case", VEC["gates"], ids=[f"{c['name']}-{c['context']['criticality']}-{c['context'].get('domain','')}" for c in VEC["gates"]])
+def test_gates_match_reference(case):
+    """Structured outcome of the safety gates vs the reference's code (not its stale tests)."""
+    from vision_inspection_system_amd import config as C
+    from vision_inspection_system_amd.consensus import analyze_consensus
+    from vision_inspection_system_amd.gates import DEFAULT_DOMAINS, SafetyGateEngine
+    from vision_inspection_system_amd.schemas import InspectionContext, VLMAnalysisResult
+    by_name = {c["name"]: c for c in VEC["consensus"]}[case["name"]]
+    cons = analyze_consensus(VLMAnalysisResult(**copy.deepcopy(by_name["inspector"])),
+                             VLMAnalysisResult(**copy.deepcopy(by_name["auditor"])))
+    got = SafetyGateEngine(domains=DEFAULT_DOMAINS, settings=C.Config()).evaluate(cons, InspectionContext(**case["context"]))
+    exp = case["verdict"]
+    assert got.verdict == exp["verdict"]
+    assert got.requires_human == exp["requires_human"]
+    assert got.confidence_level == exp["confidence_level"]
+    assert got.triggered_gates == exp["triggered_gates"]
+    assert got.errors == exp["errors"]
+    g_got = [(g["gate_id"], g["passed"], g["details"]) for g in got.defect_summary["all_gate_results"]]
+    g_exp = [(g["gate_id"], g["passed"], g["details"]) for g in exp["defect_summary"]["all_gate_results"]]
+    assert g_got == g_exp
+    for k, v in exp["defect_summary"].items():
+        if k != "all_gate_results":
+            assert got.defect_summary[k] == v, k
+
+
+def test_reference_gate_suite_cases():
+    """The live cases of the reference's tests/test_safety_gates.py:115-292 with the CODE's answers
+    (its test_gate_3_model_disagreement expectation is stale: the code returns SAFE/UNSAFE, never review)."""
+    from vision_inspection_system_amd import config as C
+    from vision_inspection_system_amd.consensus import analyze_consensus
+    from vision_inspection_system_amd.gates import DEFAULT_DOMAINS, SafetyGateEngine
+    from vision_inspection_system_amd.schemas import InspectionContext, VLMAnalysisResult
+    eng = SafetyGateEngine(domains=DEFAULT_DOMAINS, settings=C.Config())
+    d = dict(type="crack", location="a", safety_impact="CRITICAL", reasoning="r", confidence="high", recommended_action="x")
+    clean = dict(object_identified="bolt", overall_condition="good", defects=[], overall_confidence="high")
+    dam = dict(object_identified="bolt", overall_condition="damaged", defects=[d], overall_confidence="high")
+    ctx = InspectionContext(image_id="t", criticality="medium")
+    v = eng.evaluate(analyze_consensus(VLMAnalysisResult(**dam), VLMAnalysisResult(**dam)), ctx)
+    assert v.verdict == "UNSAFE" and "GATE_1_CRITICAL_DEFECT" in v.triggered_gates
+    v = eng.evaluate(analyze_consensus(VLMAnalysisResult(**clean), VLMAnalysisResult(**clean)), ctx)
+    assert v.verdict == "SAFE" and "GATE_7_NO_DEFECTS" in v.triggered_gates
+    assert len(v.defect_summary["all_gate_results"]) >= 7
+    cos = {**d, "safety_impact": "COSMETIC", "type": "scratch"}
+    c2 = dict(object_identified="bolt", overall_condition="damaged", defects=[cos], overall_confidence="high")
+    v = eng.evaluate(analyze_consensus(VLMAnalysisResult(**c2), VLMAnalysisResult(**c2)), ctx)
+    assert v.verdict == "SAFE"
+    v = eng.evaluate(analyze_consensus(VLMAnalysisResult(**clean), VLMAnalysisResult(**{**clean, "overall_condition": "damaged"})), ctx)
+    assert v.verdict == "SAFE" and v.requires_human is False and v.triggered_gates == ["GATE_3_MODEL_DISAGREEMENT"]
