@@ -249,14 +249,9 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
   const int hkv = blockIdx.x, split = blockIdx.y;
-  const int slot = min(*p.step_ptr, p.cache_tokens - 1);
-  const int ctx = slot + 1;
-  int per = (ctx + p.nsplit - 1) / p.nsplit;
-  per = min((per + 15) & ~15, DA_MAXKEYS);
-  const int ks = split * per;
-  const int ke = min(ks + per, ctx);
-  const int nk = max(ke - ks, 0);
-
+  // Split s always owns keys [128 s, 128 s + 128): the row addresses do not depend on the position, so the
+  // cache reads below are issued BEFORE *step_ptr has even arrived; splits past the context just exit.
+  const int ks = split * DA_MAXKEYS;
   bf16_t* Kh = p.k_cache + (size_t)hkv * p.cache_tokens * HD;
   bf16_t* Vh = p.v_cache + (size_t)hkv * p.cache_tokens * HD;
 
@@ -274,6 +269,12 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
     const int row = min(ks + wave + 4 * i, p.cache_tokens - 1);
     vreg[i] = *(const uint32_t*)(Vh + (size_t)row * HD + 2 * lane);
   }
+
+  const int slot = min(*p.step_ptr, p.cache_tokens - 1);
+  const int ctx = slot + 1;
+  if (ks >= ctx) return;  // whole block: nothing to attend to (its partials are never read by the combine)
+  const int ke = min(ks + DA_MAXKEYS, ctx);
+  const int nk = ke - ks;
 
   // ---- rotate q (G heads) and the new k; stage them as bf16 (exactly what later steps read back)
   const float* cr = p.cos_t + (size_t)slot * HD;
@@ -376,38 +377,51 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   }
 }
 
-// merge the per-split partials of one query head: 256 threads = 128 dims x 2 split-halves, all loads
-// of a thread are independent (4 in flight), statistics staged through LDS first
+// merge the per-split partials of one query head (only the splits that ran): 256 threads = 128 dims x 2
+// split-halves; the first partial loads are issued before the position is known
 __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
-                                                                  bf16_t* __restrict__ out, int nsplit) {
+                                                                  bf16_t* __restrict__ out, int nsplit,
+                                                                  const int* __restrict__ step_ptr,
+                                                                  int cache_tokens) {
   constexpr int HD = 128;
   __shared__ float wgt[256];
   __shared__ float osum[2][HD];
-  __shared__ float stat[2];
+  __shared__ float wm[4];
   const int hq = blockIdx.x, tid = threadIdx.x, d = tid & 127, half = tid >> 7;
+  const float* po = part_o + (size_t)hq * nsplit * HD + d;
+  // partial loads first (independent of the position), then the statistics
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = po[(size_t)min(half + 2 * j, nsplit - 1) * HD];
+  const int ctx = min(*step_ptr, cache_tokens - 1) + 1;
+  const int active = min((ctx + DA_MAXKEYS - 1) / DA_MAXKEYS, nsplit);  // splits that ran
   const float* ml = part_ml + (size_t)hq * nsplit * 2;
   float m = -1.0e30f, l = 0.f;
-  if (tid < nsplit) { m = ml[tid * 2]; l = ml[tid * 2 + 1]; }
+  if (tid < active) { m = ml[tid * 2]; l = ml[tid * 2 + 1]; }
   float M = wave_max(m);
-  __shared__ float wm[4];
   if ((tid & 63) == 0) wm[tid >> 6] = M;
   __syncthreads();
   M = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
-  const float w = (tid < nsplit) ? exp2f(m - M) : 0.f;
+  const float w = (tid < active) ? exp2f(m - M) : 0.f;
   wgt[tid] = w;
-  float lw = wave_sum(w * l);
+  const float lw = wave_sum(w * l);
   __syncthreads();
   if ((tid & 63) == 0) wm[tid >> 6] = lw;
-  const float* po = part_o + (size_t)hq * nsplit * HD + d;
   float o = 0.f;
-  int s = half;
-  for (; s + 6 < nsplit; s += 8) {
-    const float v0 = po[(size_t)s * HD], v1 = po[(size_t)(s + 2) * HD], v2 = po[(size_t)(s + 4) * HD],
-                v3 = po[(size_t)(s + 6) * HD];
-    o += wgt[s] * v0 + wgt[s + 2] * v1 + wgt[s + 4] * v2 + wgt[s + 6] * v3;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int s = half + 2 * j;
+    if (s < active) o += wgt[s] * v[j];
   }
-  for (; s < nsplit; s += 2) o += wgt[s] * po[(size_t)s * HD];
+  for (int s = half + 8; s < active; s += 8) {
+    const float a0 = po[(size_t)s * HD];
+    const float a1 = (s + 2 < active) ? po[(size_t)(s + 2) * HD] : 0.f;
+    const float a2 = (s + 4 < active) ? po[(size_t)(s + 4) * HD] : 0.f;
+    const float a3 = (s + 6 < active) ? po[(size_t)(s + 6) * HD] : 0.f;
+    o += wgt[s] * a0 + ((s + 2 < active) ? wgt[s + 2] * a1 : 0.f) + ((s + 4 < active) ? wgt[s + 4] * a2 : 0.f) +
+         ((s + 6 < active) ? wgt[s + 6] * a3 : 0.f);
+  }
   osum[half][d] = o;
   __syncthreads();
   if (tid < HD) {
@@ -444,7 +458,7 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
     default: hipLaunchKernelGGL(decode_attn_fused_kernel<8>, grid, block, 0, stream, p); break;
   }
   hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(256), 0, stream, (const float*)part_o,
-                     (const float*)part_ml, (bf16_t*)out, nsplit);
+                     (const float*)part_ml, (bf16_t*)out, nsplit, (const int*)step_ptr, cache_tokens);
   return vis_check_launch();
 }
 
