@@ -26,6 +26,7 @@
 //  * 1-D grid with a bijective XCD remap; all M-tiles that share one W panel
 //    are adjacent inside one XCD so the panel is read from HBM once.
 #include "common.hip.h"
+#include <stdlib.h>
 
 #define GEMM_BM 128
 #define GEMM_BN 128
@@ -49,6 +50,67 @@ __device__ __forceinline__ float act_apply(float x, int act) {
   if (act == ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
   if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
   return x;
+}
+
+// Epilogue shared by both tile shapes.  The MFMAs were issued with W as the A operand, so a lane holds
+// D[n = nbase + 16 j + 4 h + r][m = mbase + 16 i + l15], r = 0..3: four consecutive output columns.
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], int mbase, int nbase, int l15,
+                                              int h) {
+  const bool swiglu = (p.act == ACT_SWIGLU);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mbase + i * 16 + l15;
+    if (m >= p.M) continue;
+    if (swiglu) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int n = nbase + j * 16 + 4 * h;  // gate row index in the interleaved weight
+        if (n >= p.N) continue;
+        const int oc = (nbase >> 1) + (j >> 1) * 16 + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[i][j][r], u = acc[i][j + 1][r];
+          v[r] = g / (1.0f + __expf(-g)) * u;
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + oc) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + 4 * h;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if (p.bias) {
+          const u32x2 b = *(const u32x2*)(p.bias + n);
+          v[0] += __uint_as_float(b[0] << 16);
+          v[1] += __uint_as_float(b[0] & 0xffff0000u);
+          v[2] += __uint_as_float(b[1] << 16);
+          v[3] += __uint_as_float(b[1] & 0xffff0000u);
+        }
+        if (p.act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
+        }
+        if (p.R) {
+          const u32x2 rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
+          v[0] += __uint_as_float(rr[0] << 16);
+          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rr[1] << 16);
+          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
@@ -137,62 +199,116 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
     cur ^= 1;
   }
 
-  // ---- epilogue: lane holds D[n = 4h + r][m = l15] for r = 0..3
-  const bool swiglu = (p.act == ACT_SWIGLU);
+  gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
+}
+
+// ---------------------------------------------------------------------------
+// 256x128x64 tile, 512 threads = 8 waves (4 x 2, each 64x64), ONE workgroup per CU, 3-stage LDS ring
+// (3 x 48 KiB).  The global_load_lds of K-step t+2 are issued while step t is computed; the only waits in the
+// loop are a COUNTED s_waitcnt vmcnt(6) (this thread's 6 loads of step t+1 may stay in flight) and one raw
+// s_barrier per K-step - never a __syncthreads(), whose fence would drain the in-flight LDS-DMA.
+//   iteration t:  wait(stage t landed) ; barrier ; issue stage t+2 into the buffer everyone just finished
+//                 reading (stage t-1) ; ds_read + 32 MFMA on stage t
+// The barrier both publishes stage t (every wave waited for its own part) and retires the reads of stage t-1.
+#define GEMM2_BM 256
+#define GEMM2_STAGE_BYTES ((GEMM2_BM + GEMM_BN) * GEMM_BK * 2)  // 49152
+#define GEMM2_LDS_BYTES (3 * GEMM2_STAGE_BYTES)                  // 147456
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256x128_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds2[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * GEMM2_BM, n0 = tn * GEMM_BN;
+
+  const bf16_t* a_src[4];
+  const bf16_t* w_src[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + l15;
-    if (m >= p.M) continue;
-    if (swiglu) {
-#pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * h;  // gate row index in the interleaved weight
-        if (n >= p.N) continue;
-        const int oc = ((n0 + wn * 64) >> 1) + (j >> 1) * 16 + 4 * h;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g = acc[i][j][r], u = acc[i][j + 1][r];
-          v[r] = g / (1.0f + __expf(-g)) * u;
-        }
-        u32x2 o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        *(u32x2*)(p.C + (size_t)m * p.ldc + oc) = o;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * h;
-        if (n >= p.N) continue;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-        if (p.bias) {
-          const u32x2 b = *(const u32x2*)(p.bias + n);
-          v[0] += __uint_as_float(b[0] << 16);
-          v[1] += __uint_as_float(b[0] & 0xffff0000u);
-          v[2] += __uint_as_float(b[1] << 16);
-          v[3] += __uint_as_float(b[1] & 0xffff0000u);
-        }
-        if (p.act != ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], p.act);
-        }
-        if (p.R) {
-          const u32x2 rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
-          v[0] += __uint_as_float(rr[0] << 16);
-          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-          v[2] += __uint_as_float(rr[1] << 16);
-          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-        }
-        u32x2 o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
-      }
-    }
+    const int c = i * 512 + tid;
+    const int row = c >> 3;
+    const int ch = (c & 7) ^ (row & 7);
+    a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid;
+    const int row = c >> 3;
+    const int ch = (c & 7) ^ (row & 7);
+    w_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + ch * 8;
+  }
+  const int wave_base = (tid & ~63) * 16;
+  constexpr int A_BYTES = GEMM2_BM * GEMM_BK * 2;  // 32 KiB
+
+  auto stage = [&](int buf) {
+    char* base = lds2 + buf * GEMM2_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)a_src[i],
+          (__attribute__((address_space(3))) void*)(base + i * 8192 + wave_base), 16, 0, 0);
+      a_src[i] += GEMM_BK;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)w_src[i],
+          (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8192 + wave_base), 16, 0, 0);
+      w_src[i] += GEMM_BK;
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = lane & 7;
+  const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
+  const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
+  const int a_rd = wm * 64 * 128;
+  const int w_rd = A_BYTES + wn * 64 * 128;
+
+  const int nk = p.K / GEMM_BK;
+  stage(0);
+  if (nk > 1) stage(1);
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      int nb = buf + 2;
+      if (nb >= 3) nb -= 3;
+      stage(nb);
+    }
+    const char* base = lds2 + buf * GEMM2_STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int rd = ks ? rd1 : rd0;
+      bf16x8 af[4], wf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    buf = (buf == 2) ? 0 : buf + 1;
+  }
+  gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
 }
 
 // C-ABI launcher (declared in include/vis_hip.h)
@@ -215,10 +331,22 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act;
-  p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+  // tile choice: the 3-stage 256x128 kernel wins on large problems; VIS_GEMM_TILE=1|2 forces a shape (A/B runs)
+  static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const bool big = forced ? (forced == 2) : (M >= 1024 && K >= 256);
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  const int nwg = p.tiles_m * p.tiles_n;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(nwg), dim3(256), 0, stream, p);
+  if (big) {
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute((const void*)gemm_bf16_256x128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM2_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr_ok) return VIS_ERR_LAUNCH;
+    p.tiles_m = (M + GEMM2_BM - 1) / GEMM2_BM;
+    hipLaunchKernelGGL(gemm_bf16_256x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM2_LDS_BYTES, stream, p);
+  } else {
+    p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+    hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+  }
   return vis_check_launch();
 }
