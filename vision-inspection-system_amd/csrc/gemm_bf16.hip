@@ -276,37 +276,74 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x128_kernel(GemmArgs p) {
   const int a_rd = wm * 64 * 128;
   const int w_rd = A_BYTES + wn * 64 * 128;
 
+  // Software pipeline (fragments double-buffered in registers, one barrier per K-step placed BETWEEN the two
+  // MFMA clusters so every LDS fragment read overlaps a cluster instead of stalling behind the barrier):
+  //   F0 = frags(t, k-half 0) already in registers
+  //   A:  ds_read F1 = frags(t, 1)          || 16 MFMA on F0
+  //       s_waitcnt vmcnt(0) [stage t+1, issued a whole K-step ago] ; s_barrier ; issue stage t+2 -> buf (t+2)%3
+  //   B:  ds_read F0 = frags(t+1, 0)        || 16 MFMA on F1
+  // Buffer (t+2)%3 == (t-1)%3 was last read in iteration t-1 (its MFMAs have retired before this barrier).
   const int nk = p.K / GEMM_BK;
   stage(0);
   if (nk > 1) stage(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6) : "memory");
+  if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 af0[4], wf0[4], af1[4], wf1[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af0[i] = *(const bf16x8*)(lds2 + a_rd + i * 2048 + rd0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wf0[j] = *(const bf16x8*)(lds2 + w_rd + j * 2048 + rd0);
+  auto mfma16 = [&](bf16x8 (&wf)[4], bf16x8 (&af)[4]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
   int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // main loop: every K-step except the last; the body is branch-free apart from the (uniform) stage issue, so
+  // the compiler's s_waitcnt lgkmcnt counts stay exact (fragment reads always overlap an MFMA cluster)
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const char* base = lds2 + buf * GEMM2_STAGE_BYTES;
+    const int nbuf = (buf == 2) ? 0 : buf + 1;
+    // phase A.  F0 crossed the loop back-edge, so hipcc waits lgkmcnt(0) before its first use: issue the F1
+    // reads only AFTER the first MFMA (order pinned), then they overlap the other 15 MFMAs of the cluster.
+    __builtin_amdgcn_s_setprio(1);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[0], af0[0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af1[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf1[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (i | j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[j], af0[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // stage kt+1 (issued a whole K-step ago) has landed
     __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) {
-      int nb = buf + 2;
-      if (nb >= 3) nb -= 3;
-      stage(nb);
-    }
+    if (kt + 2 < nk) stage((nbuf == 2) ? 0 : nbuf + 1);
+    const char* nbase = lds2 + nbuf * GEMM2_STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af0[i] = *(const bf16x8*)(nbase + a_rd + i * 2048 + rd0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf0[j] = *(const bf16x8*)(nbase + w_rd + j * 2048 + rd0);
+    mfma16(wf1, af1);                                   // phase B (overlaps the F0 reads just issued)
+    buf = nbuf;
+  }
+  {  // last K-step
     const char* base = lds2 + buf * GEMM2_STAGE_BYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int rd = ks ? rd1 : rd0;
-      bf16x8 af[4], wf[4];
+    for (int i = 0; i < 4; ++i) af1[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-    buf = (buf == 2) ? 0 : buf + 1;
+    for (int j = 0; j < 4; ++j) wf1[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd1);
+    mfma16(wf0, af0);
+    mfma16(wf1, af1);
   }
   gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
 }
