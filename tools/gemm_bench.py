@@ -1,0 +1,23 @@
+"""GEMM-only microbench for profiling runs: python tools/gemm_bench.py M N K [reps]."""
+import math, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vision_inspection_system_amd import hip
+M, N, K = (int(x) for x in sys.argv[1:4])
+reps = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+dev = torch.device("cuda:0")
+hip.load()
+a = (torch.randn((M, K), device=dev)).to(torch.bfloat16)
+w = (torch.randn((N, K), device=dev) / math.sqrt(K)).to(torch.bfloat16)
+out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+for _ in range(2):
+    hip.gemm(a, w, out=out)
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+s.record()
+for _ in range(reps):
+    hip.gemm(a, w, out=out)
+e.record()
+torch.cuda.synchronize()
+t = s.elapsed_time(e) / reps * 1e-3
+print(f"gemm {M}x{N}x{K} tile={os.environ.get('VIS_GEMM_TILE','auto')}: {t*1e3:.3f} ms {2.0*M*N*K/t/1e12:.1f} TFLOP/s")

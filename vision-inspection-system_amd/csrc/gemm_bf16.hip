@@ -126,39 +126,37 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
   const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
   const int m0 = tm * GEMM_BM, n0 = tn * GEMM_BN;
 
-  // ---- staging addresses: 4 A chunks + 4 W chunks of 16 B per thread per K-step
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[4];
+  // ---- staging addresses: 4 A chunks + 4 W chunks of 16 B per thread per K-step.
+  // Keep the K-loop free of vector address arithmetic: a wave-uniform (SGPR) base pointer that advances by
+  // one K-step with scalar adds, plus a per-lane 32-bit byte offset that never changes.
+  uint32_t a_off[4], w_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = i * 256 + tid;
     const int row = c >> 3;
     const int ch = (c & 7) ^ (row & 7);  // logical chunk stored at this physical slot
-    const int am = min(m0 + row, p.M - 1);
-    const int wr = min(n0 + row, p.N - 1);
-    a_src[i] = p.A + (size_t)am * p.lda + ch * 8;
-    w_src[i] = p.W + (size_t)wr * p.ldw + ch * 8;
+    a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
+    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
   }
-  const int wave_base = (tid & ~63) * 16;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;  // provably wave-uniform LDS slot
   constexpr int A_BYTES = GEMM_BM * GEMM_BK * 2;  // 16 KiB
   constexpr int BUF_BYTES = (GEMM_BM + GEMM_BN) * GEMM_BK * 2;
 
   auto stage = [&](int buf) {
-    char* base = lds + buf * BUF_BYTES;
+    char* base = lds + buf * BUF_BYTES + wave_base;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)a_src[i],
-          (__attribute__((address_space(3))) void*)(base + i * 4096 + wave_base), 16, 0, 0);
-      a_src[i] += GEMM_BK;
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)w_src[i],
-          (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096 + wave_base), 16, 0, 0);
-      w_src[i] += GEMM_BK;
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096), 16, 0,
+                                       0);
+    a_base += GEMM_BK * 2;
+    w_base += GEMM_BK * 2;
   };
 
   f32x4 acc[4][4];
@@ -227,41 +225,39 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x128_kernel(GemmArgs p) {
   const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
   const int m0 = tm * GEMM2_BM, n0 = tn * GEMM_BN;
 
-  const bf16_t* a_src[4];
-  const bf16_t* w_src[2];
+  uint32_t a_off[4], w_off[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = i * 512 + tid;
     const int row = c >> 3;
     const int ch = (c & 7) ^ (row & 7);
-    a_src[i] = p.A + (size_t)min(m0 + row, p.M - 1) * p.lda + ch * 8;
+    a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int c = i * 512 + tid;
     const int row = c >> 3;
     const int ch = (c & 7) ^ (row & 7);
-    w_src[i] = p.W + (size_t)min(n0 + row, p.N - 1) * p.ldw + ch * 8;
+    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
   }
-  const int wave_base = (tid & ~63) * 16;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
   constexpr int A_BYTES = GEMM2_BM * GEMM_BK * 2;  // 32 KiB
 
   auto stage = [&](int buf) {
-    char* base = lds2 + buf * GEMM2_STAGE_BYTES;
+    char* base = lds2 + buf * GEMM2_STAGE_BYTES + wave_base;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)a_src[i],
-          (__attribute__((address_space(3))) void*)(base + i * 8192 + wave_base), 16, 0, 0);
-      a_src[i] += GEMM_BK;
-    }
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)w_src[i],
-          (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8192 + wave_base), 16, 0, 0);
-      w_src[i] += GEMM_BK;
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8192), 16, 0,
+                                       0);
+    a_base += GEMM_BK * 2;
+    w_base += GEMM_BK * 2;
   };
 
   f32x4 acc[4][4];
