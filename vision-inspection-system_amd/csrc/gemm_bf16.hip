@@ -366,7 +366,10 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   p.act = act;
   // tile choice: the 3-stage 256x128 kernel wins on large problems; VIS_GEMM_TILE=1|2 forces a shape (A/B runs)
   static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  const bool big = forced ? (forced == 2) : (M >= 1024 && K >= 256);
+  // measured on MI355X (tools/kbench.py): the 256x128 kernel wins when its grid is one full round of the 256 CUs
+  // and K is long (LLM o/down projections: 9 x 28 = 252 tiles); the 128x128 kernel (2 WG/CU) wins elsewhere
+  const int t2 = ((M + GEMM2_BM - 1) / GEMM2_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
+  const bool big = forced ? (forced == 2) : (K >= 2048 && t2 >= 200 && t2 <= 256);
   p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   vis_clear_error();
   if (big) {
