@@ -108,11 +108,6 @@ int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D,
 int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
                      vis_stream_t stream);
 
-/* Cache hint: read `bytes` at src with allocating loads so they become L2 / Infinity-Cache resident (used on
- * a side stream to overlap the next GEMVs' weight fetch with the HBM-idle decode attention).  Writes nothing
- * (sink may be NULL); no result depends on it. */
-int vis_prefetch(const void* src, long long bytes, int blocks, void* sink, vis_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

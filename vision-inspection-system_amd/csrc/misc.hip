@@ -116,30 +116,4 @@ extern "C" int vis_scatter_rows(const void* src, const void* idx, void* dst, int
   return vis_check_launch();
 }
 
-// ---------------------------------------------------------------------------
-// vis_prefetch: pull a byte range into the L2 / 256 MB Infinity Cache with plain (allocating) loads.
-// Launched on a SIDE stream while the HBM-idle decode attention runs, so the next weight-streaming GEMVs
-// find their first tens of MB on die.  Pure hint: it writes nothing and no result depends on it.
-__global__ __launch_bounds__(256) void prefetch_kernel(const u32x4* __restrict__ src, long long n_chunks,
-                                                       uint32_t* __restrict__ sink) {
-  uint32_t acc = 0;
-  long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long stride = (long long)gridDim.x * 256;
-  for (; i + 3 * stride < n_chunks; i += 4 * stride) {
-    const u32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-    acc ^= a[0] ^ b[1] ^ c[2] ^ d[3];
-  }
-  for (; i < n_chunks; i += stride) acc ^= src[i][0];
-  if (acc == 0x9e3779b9u && sink) *sink = acc;  // practically never true; keeps the loads alive
-}
-
-extern "C" int vis_prefetch(const void* src, long long bytes, int blocks, void* sink, hipStream_t stream) {
-  if (!src || bytes <= 0 || blocks <= 0 || blocks > 4096) return VIS_ERR_ARG;
-  if ((uintptr_t)src & 15) return VIS_ERR_ARG;
-  vis_clear_error();
-  hipLaunchKernelGGL(prefetch_kernel, dim3(blocks), dim3(256), 0, stream, (const u32x4*)src, bytes / 16,
-                     (uint32_t*)sink);
-  return vis_check_launch();
-}
-
 extern "C" int vis_abi_version(void) { return 1; }

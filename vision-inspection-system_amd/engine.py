@@ -142,9 +142,6 @@ class Qwen2VLEngine:
         self.part_o = torch.empty(Hq * self.nsplit * D, dtype=torch.float32, device=dev)
         self.part_ml = torch.empty(Hq * self.nsplit * 2, dtype=torch.float32, device=dev)
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
-        # decode-time weight prefetch (side stream, overlaps the HBM-idle attention): bytes of the next GEMVs
-        self.prefetch_bytes = int(__import__("os").environ.get("VIS_DECODE_PREFETCH_MB", "80")) << 20
-        self._side = torch.cuda.Stream(device=dev)
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.prompt_len = 0
@@ -276,20 +273,8 @@ class Qwen2VLEngine:
         x, x2 = self.d_x, self.d_x2
         for li, lw in enumerate(w.llm):
             hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
-            if self.prefetch_bytes > 0:
-                # fork: while attention + combine run (HBM nearly idle), a side stream pulls the o-projection and
-                # the head of the gate/up matrix into the Infinity Cache; joined again before the o GEMV
-                main = torch.cuda.current_stream()
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    o_bytes = lw.o_w.numel() * 2
-                    hip.prefetch(lw.o_w, min(o_bytes, self.prefetch_bytes))
-                    if self.prefetch_bytes > o_bytes:
-                        hip.prefetch(lw.gateup_w, self.prefetch_bytes - o_bytes)
             hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
                             self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
-            if self.prefetch_bytes > 0:
-                torch.cuda.current_stream().wait_stream(self._side)
             hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
             hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])

@@ -32,9 +32,8 @@ _SIGS = {
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
-    "vis_prefetch": "p" + "l" + "i" + "p" + "p",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint, "l": ctypes.c_longlong}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint}
 
 
 class HipLibraryError(RuntimeError):
@@ -287,11 +286,3 @@ def scatter_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor) -> tor
                                  _stream())
     _check(rc, "vis_scatter_rows")
     return dst
-
-
-def prefetch(t: torch.Tensor, nbytes: Optional[int] = None, blocks: int = 128) -> None:
-    """Cache hint on the CURRENT stream: make the first nbytes of t L2 / Infinity-Cache resident."""
-    total = t.numel() * t.element_size()
-    nbytes = total if nbytes is None else min(nbytes, total)
-    rc = load().vis_prefetch(_ptr(t), nbytes, blocks, None, _stream())
-    _check(rc, "vis_prefetch")
