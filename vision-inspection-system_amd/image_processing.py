@@ -89,7 +89,7 @@ def resize_for_model(img: Image.Image, patch: int = 14, merge: int = 2, min_pixe
     th, tw = smart_resize(h, w, patch * merge, min_pixels, max_pixels)
     if (th, tw) != (h, w):
         img = img.resize((tw, th), resample=Image.Resampling.BICUBIC)
-    return np.ascontiguousarray(np.asarray(img, dtype=np.uint8))
+    return np.array(img, dtype=np.uint8)  # writable copy
 
 
 def grid_of(frame_u8: np.ndarray, patch: int = 14) -> Tuple[int, int, int]:
