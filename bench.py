@@ -247,7 +247,7 @@ def main():
         m = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
         s.record()
-        engine.prefill(ids, [frame], ids_dev=ids_dev)
+        engine.prefill(ids, [frame], ids_dev=ids_dev, max_new_tokens=new)
         m.record()
         engine.decode(new - 1, use_graph=not args.no_graph)
         e.record()

@@ -85,14 +85,36 @@ int vis_gemv_bf16(const void* x, const void* W, const void* bias, const void* R,
  * Replaces TF modeling_qwen2_vl.py:180-222 + :508-556 for q_len == 1 with a KV cache. */
 int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
                     const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
-                    int cache_tokens, int nsplit, float scale, vis_stream_t stream);
+                    int cache_tokens, int nsplit, float scale, int batch, long long qkv_bs, long long cache_bs,
+                    long long tab_bs, vis_stream_t stream);
+/* batch > 1: sequence b uses qkv + b*qkv_bs, caches + b*cache_bs, tables + b*tab_bs (element strides),
+ * step_ptr[b], part_o/part_ml/out blocks of Hq*nsplit*128 / Hq*nsplit*2 / Hq*128 elements. */
 
 /* K12  next-token pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
  * torch.argmax), then *step += 1.  inv_temp > 0 samples at temperature 1/inv_temp by Gumbel-max with a
  * counter hash of (seed, *step, index); inv_temp == 0 is greedy (the reference request passes
  * temperature=, src/agents/vlm_inspector.py:108).  ws_val/ws_idx: 256 floats / 256 ints of workspace. */
 int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* tokens, int max_tokens,
-                   void* cur_token, void* step_ptr, float inv_temp, unsigned seed, vis_stream_t stream);
+                   void* cur_token, void* step_ptr, float inv_temp, unsigned seed, int batch, int ld_logits,
+                   vis_stream_t stream);
+/* batch > 1: sequence b reads logits + b*ld_logits, writes tokens[b*max_tokens + step[b]], cur_token[b],
+ * step_ptr[b]; ws_val / ws_idx need 256 entries per sequence. */
+
+/* K10 (batched decode)  Y[b,n] = act(sum_k W[n,k] xn[b,k] + bias[n]) + R[b,n] for up to 16 in-flight sequences:
+ * the weight matrix is streamed from HBM once for all of them (MFMA with the weight rows as the A operand).
+ * xn = bf16(x * rstd[b]) * norm_w when norm_w != NULL.  With `part` != NULL and act == NONE, bf16 output, K is
+ * split over vis_skinny_ksplit(N, K) grid slices that write f32 partials part[ksplit][16][N]; the caller then
+ * runs vis_skinny_finalize.  SwiGLU / f32-logit launches are never split. */
+int vis_skinny_ksplit(int N, int K);
+int vis_gemm_skinny_bf16(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,
+                         const void* rstd, void* part, void* y, int B, int N, int K, int ldx, int ldw, int ldr,
+                         int ldy, int act, int out_f32, vis_stream_t stream);
+
+/* y[b][n] = sum_ks part[ks][b][n] + bias[n] + R[b][n] (fixed order, bitwise reproducible); rstd_out[b] =
+ * rsqrt(mean(y[b]^2) + eps) for the next fused RMSNorm (TF modeling_qwen2_vl.py:96-110).  ksplit == 0: only the
+ * statistics of the finished rows y. */
+int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const void* R, void* y, void* rstd_out,
+                        int B, int N, int ldr, int ldy, float eps, vis_stream_t stream);
 
 /* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
  * out[row0 + p][ld_out] in the merge-group order of

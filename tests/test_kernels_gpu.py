@@ -367,3 +367,84 @@ def test_patchify_matches_reference_layout(hip, device):
     got = out.float().cpu().numpy()
     assert np.abs(got[:, :1176] - p).max() < 2e-2
     assert np.abs(got[:, 1176:]).max() == 0.0
+
+
+# ----------------------------------------------------------------------------- K10 batched (skinny GEMM)
+@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 704), (16, 4608, 3584), (8, 3584, 18944), (3, 152064, 3584)])
+def test_skinny_gemm_split_and_finalize(hip, device, B, N, K):
+    x = _randn((B, K), device, 100, 2.0)
+    w = _randn((N, K), device, 101, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 102)
+    r = _randn((B, N), device, 103)
+    out = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+    part = torch.empty(16 * 16 * N, dtype=torch.float32, device=device)
+    rstd = torch.empty(16, dtype=torch.float32, device=device)
+    hip.skinny_gemm(x, w, out, part=part, bias=b, residual=r, rstd_out=rstd)
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    _assert_close(out, ref, atol=4e-2, rtol=1e-2, what=f"skinny {B}x{N}x{K}")
+    ref_rstd = torch.rsqrt(out.float().pow(2).mean(-1) + 1e-6)
+    _assert_close(rstd[:B], ref_rstd, atol=1e-4, rtol=1e-4, what="finalize rstd")
+    # bitwise reproducible (fixed summation order)
+    out2 = torch.empty_like(out)
+    hip.skinny_gemm(x, w, out2, part=part, bias=b, residual=r)
+    assert torch.equal(out, out2)
+
+
+def test_skinny_gemm_fused_norm_swiglu_and_logits(hip, device):
+    from vision_inspection_system_amd.weights import interleave_gate_up
+    B, K, I = 7, 256, 704
+    x = _randn((B, K), device, 104, 2.0)
+    nw = _randn((K,), device, 105)
+    wg = _randn((I, K), device, 106, 1.0 / math.sqrt(K))
+    wu = _randn((I, K), device, 107, 1.0 / math.sqrt(K))
+    rstd = torch.empty(16, dtype=torch.float32, device=device)
+    hip.rows_rstd(x, rstd, 1e-6)
+    xf = x.float()
+    xn = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float() * nw.float())
+    xn = xn.to(torch.bfloat16).float()
+    out = torch.empty((B, I), dtype=torch.bfloat16, device=device)
+    hip.skinny_gemm(x, interleave_gate_up(wg, wu), out, norm_w=nw, rstd=rstd, act=hip.ACT_SWIGLU)
+    ref = torch.nn.functional.silu(xn @ wg.float().t()) * (xn @ wu.float().t())
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="skinny swiglu")
+    wl = _randn((1000, K), device, 108, 1.0 / math.sqrt(K))
+    logits = torch.empty((B, 1000), dtype=torch.float32, device=device)
+    hip.skinny_gemm(x, wl, logits, norm_w=nw, rstd=rstd)
+    _assert_close(logits, xn @ wl.float().t(), atol=2e-2, rtol=1e-2, what="skinny f32 logits")
+
+
+def test_batched_decode_attention_and_argmax(hip, device):
+    """B sequences with different context lengths in one launch == B single-sequence launches."""
+    Hq, Hkv, HD, T, B = 28, 4, 128, 512, 3
+    ctx = [37, 300, 511]
+    kc = _randn((B, Hkv, T, HD), device, 110)
+    vc = _randn((B, Hkv, T, HD), device, 111)
+    g = torch.Generator().manual_seed(112)
+    ang = torch.rand((B, T, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos_t, sin_t = emb.cos().to(device), emb.sin().to(device)
+    qkv = _randn((B, (Hq + 2 * Hkv) * HD), device, 113)
+    step = torch.tensor(ctx, dtype=torch.int32, device=device)
+    ns = T // 128
+    po = torch.empty(B * Hq * ns * HD, dtype=torch.float32, device=device)
+    pml = torch.empty(B * Hq * ns * 2, dtype=torch.float32, device=device)
+    out = torch.empty((B, Hq * HD), dtype=torch.bfloat16, device=device)
+    kc1, vc1 = kc.clone(), vc.clone()
+    hip.decode_attn(qkv, cos_t, sin_t, kc, vc, step, po, pml, out, Hq, Hkv, HD, ns, HD ** -0.5)
+    for b in range(B):
+        o1 = torch.empty((Hq * HD,), dtype=torch.bfloat16, device=device)
+        hip.decode_attn(qkv[b].contiguous(), cos_t[b].contiguous(), sin_t[b].contiguous(), kc1[b].contiguous(),
+                        vc1[b].contiguous(), step[b:b + 1].clone(), po, pml, o1, Hq, Hkv, HD, ns, HD ** -0.5)
+        assert torch.equal(out[b], o1), f"sequence {b}"
+    # batched argmax: per-sequence logits, tokens, counters
+    V = 5000
+    lg = torch.randn((B, V), generator=torch.Generator().manual_seed(114)).to(device)
+    for b in range(B):
+        lg[b, 100 * (b + 1)] = 99.0
+    tokens = torch.full((B, 8), -1, dtype=torch.int32, device=device)
+    cur = torch.zeros(B, dtype=torch.int32, device=device)
+    st = torch.tensor([0, 3, 7], dtype=torch.int32, device=device)
+    hip.argmax(lg, torch.empty(256 * B, device=device), torch.empty(256 * B, dtype=torch.int32, device=device),
+               tokens, cur, st)
+    assert cur.cpu().tolist() == [100, 200, 300] and st.cpu().tolist() == [1, 4, 8]
+    t = tokens.cpu()
+    assert t[0, 0] == 100 and t[1, 3] == 200 and t[2, 7] == 300 and int((t >= 0).sum()) == 3

@@ -226,6 +226,8 @@ struct DecAttnArgs {
   float* part_ml;         // [Hq][nsplit][2]
   int Hq, Hkv, cache_tokens, nsplit;
   float scale_log2;
+  // batch (blockIdx.z = sequence): element strides between sequences
+  long long qkv_bs, cache_bs, tab_bs;
 };
 
 // Structure (no cross-lane reductions inside a wave):
@@ -248,7 +250,15 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   __shared__ float ml[G][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
-  const int hkv = blockIdx.x, split = blockIdx.y;
+  const int hkv = blockIdx.x, split = blockIdx.y, seq = blockIdx.z;
+  p.qkv += seq * p.qkv_bs;
+  p.k_cache += seq * p.cache_bs;
+  p.v_cache += seq * p.cache_bs;
+  p.cos_t += seq * p.tab_bs;
+  p.sin_t += seq * p.tab_bs;
+  p.step_ptr += seq;
+  p.part_o += (size_t)seq * p.Hq * p.nsplit * 128;
+  p.part_ml += (size_t)seq * p.Hq * p.nsplit * 2;
   // Split s always owns keys [128 s, 128 s + 128): the row addresses do not depend on the position, so the
   // cache reads below are issued BEFORE *step_ptr has even arrived; splits past the context just exit.
   const int ks = split * DA_MAXKEYS;
@@ -388,7 +398,11 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
   __shared__ float wgt[256];
   __shared__ float osum[2][HD];
   __shared__ float wm[4];
-  const int hq = blockIdx.x, tid = threadIdx.x, d = tid & 127, half = tid >> 7;
+  const int hq = blockIdx.x, seq = blockIdx.y, tid = threadIdx.x, d = tid & 127, half = tid >> 7;
+  part_o += (size_t)seq * gridDim.x * nsplit * HD;
+  part_ml += (size_t)seq * gridDim.x * nsplit * 2;
+  out += (size_t)seq * gridDim.x * HD;
+  step_ptr += seq;
   const float* po = part_o + (size_t)hq * nsplit * HD + d;
   // partial loads first (independent of the position), then the statistics
   float v[4];
@@ -433,9 +447,12 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
 
 extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
                                const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
-                               int cache_tokens, int nsplit, float scale, hipStream_t stream) {
+                               int cache_tokens, int nsplit, float scale, int batch, long long qkv_bs,
+                               long long cache_bs, long long tab_bs, hipStream_t stream) {
   if (!qkv || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !part_o || !part_ml || !out)
     return VIS_ERR_ARG;
+  if (batch <= 0 || batch > 64 || (batch > 1 && (qkv_bs <= 0 || cache_bs <= 0 || tab_bs < 0))) return VIS_ERR_ARG;
+  if ((qkv_bs % 8) || (cache_bs % 8)) return VIS_ERR_ARG;
   if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
   const int G = Hq / Hkv;
   if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;  // instantiated GQA group sizes
@@ -448,8 +465,9 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
   p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
   p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.nsplit = nsplit;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.qkv_bs = qkv_bs; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
   vis_clear_error();
-  const dim3 grid(Hkv, nsplit), block(256);
+  const dim3 grid(Hkv, nsplit, batch), block(256);
   switch (G) {
     case 1: hipLaunchKernelGGL(decode_attn_fused_kernel<1>, grid, block, 0, stream, p); break;
     case 2: hipLaunchKernelGGL(decode_attn_fused_kernel<2>, grid, block, 0, stream, p); break;
@@ -457,7 +475,7 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
     case 7: hipLaunchKernelGGL(decode_attn_fused_kernel<7>, grid, block, 0, stream, p); break;
     default: hipLaunchKernelGGL(decode_attn_fused_kernel<8>, grid, block, 0, stream, p); break;
   }
-  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq), dim3(256), 0, stream, (const float*)part_o,
+  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, batch), dim3(256), 0, stream, (const float*)part_o,
                      (const float*)part_ml, (bf16_t*)out, nsplit, (const int*)step_ptr, cache_tokens);
   return vis_check_launch();
 }
@@ -480,11 +498,15 @@ __device__ __forceinline__ float gumbel_noise(unsigned seed, unsigned step, unsi
 __global__ __launch_bounds__(256) void argmax_stage1_kernel(const float* __restrict__ logits, int V,
                                                             float* __restrict__ bval, int* __restrict__ bidx,
                                                             float inv_temp, unsigned seed,
-                                                            const int* __restrict__ step_ptr) {
-  const int tid = threadIdx.x;
+                                                            const int* __restrict__ step_ptr, int ld_logits) {
+  const int tid = threadIdx.x, seq = blockIdx.y;
+  logits += (size_t)seq * ld_logits;
+  bval += seq * 256;
+  bidx += seq * 256;
+  seed += 0x9E3779B9u * (unsigned)seq;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  const unsigned step = (unsigned)*step_ptr;
+  const unsigned step = (unsigned)step_ptr[seq];
   for (int i = blockIdx.x * 256 + tid; i < V; i += gridDim.x * 256) {
     float v = logits[i];
     if (inv_temp > 0.f) v = v * inv_temp + gumbel_noise(seed, step, (unsigned)i);
@@ -512,7 +534,12 @@ __global__ __launch_bounds__(64) void argmax_stage2_kernel(const float* __restri
                                                            const int* __restrict__ bidx, int nb,
                                                            int* __restrict__ tokens, int max_tokens,
                                                            int* __restrict__ cur_token, int* __restrict__ step_ptr) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, seq = blockIdx.x;
+  bval += seq * 256;
+  bidx += seq * 256;
+  tokens += (size_t)seq * max_tokens;
+  cur_token += seq;
+  step_ptr += seq;
   float best = -INFINITY;
   int bi = 0x7fffffff;
   for (int i = lane; i < nb; i += 64) {
@@ -535,14 +562,15 @@ __global__ __launch_bounds__(64) void argmax_stage2_kernel(const float* __restri
 }
 
 extern "C" int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* tokens, int max_tokens,
-                              void* cur_token, void* step_ptr, float inv_temp, unsigned seed, hipStream_t stream) {
+                              void* cur_token, void* step_ptr, float inv_temp, unsigned seed, int batch,
+                              int ld_logits, hipStream_t stream) {
   if (!logits || V <= 0 || !ws_val || !ws_idx || !tokens || !cur_token || !step_ptr) return VIS_ERR_ARG;
-  if (!(inv_temp >= 0.f)) return VIS_ERR_ARG;
+  if (!(inv_temp >= 0.f) || batch <= 0 || batch > 64 || (batch > 1 && ld_logits < V)) return VIS_ERR_ARG;
   const int nb = min(256, (V + 255) / 256);
   vis_clear_error();
-  hipLaunchKernelGGL(argmax_stage1_kernel, dim3(nb), dim3(256), 0, stream, (const float*)logits, V, (float*)ws_val,
-                     (int*)ws_idx, inv_temp, seed, (const int*)step_ptr);
-  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx,
+  hipLaunchKernelGGL(argmax_stage1_kernel, dim3(nb, batch), dim3(256), 0, stream, (const float*)logits, V,
+                     (float*)ws_val, (int*)ws_idx, inv_temp, seed, (const int*)step_ptr, ld_logits);
+  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(batch), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx,
                      nb, (int*)tokens, max_tokens, (int*)cur_token, (int*)step_ptr);
   return vis_check_launch();
 }

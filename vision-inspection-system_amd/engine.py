@@ -145,6 +145,8 @@ class Qwen2VLEngine:
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.prompt_len = 0
+        self._decoded = 0
+        self.decode_limit = 0
         self.last_first_logits: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ vision tower
@@ -200,7 +202,7 @@ class Qwen2VLEngine:
     # ------------------------------------------------------------------ prefill
     def prefill(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (),
                 ids_dev: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
-                temperature: float = 0.0, seed: int = 0) -> None:
+                temperature: float = 0.0, seed: int = 0, max_new_tokens: Optional[int] = None) -> None:
         """Run the prompt through the LLM, fill the KV cache and pick the first token
         (greedy when temperature == 0, Gumbel-max sampled otherwise)."""
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
@@ -215,11 +217,12 @@ class Qwen2VLEngine:
         pos3, next_pos = rope_index(cfg, ids_np, grids)
         cos_np, sin_np = mrope_cos_sin(cfg, pos3)
         # decode rows: slot S + t carries rope position next_pos + t on all three axes
-        n_dec = self.max_ctx - S
+        n_dec = self.max_ctx - S if max_new_tokens is None else min(self.max_ctx - S, max_new_tokens + 1)
         dpos = np.broadcast_to((next_pos + np.arange(n_dec))[None, :], (3, n_dec))
         dcos, dsin = mrope_cos_sin(cfg, dpos)
-        self.cos_t.copy_(torch.from_numpy(np.concatenate([cos_np, dcos])), non_blocking=True)
-        self.sin_t.copy_(torch.from_numpy(np.concatenate([sin_np, dsin])), non_blocking=True)
+        self.cos_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([cos_np, dcos])), non_blocking=True)
+        self.sin_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([sin_np, dsin])), non_blocking=True)
+        self.decode_limit = S + n_dec
         if ids_dev is None:
             ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
         H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
@@ -263,6 +266,7 @@ class Qwen2VLEngine:
         hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
                    self.temperature, self.seed)
         self.prompt_len = S
+        self._decoded = 0
 
     # ------------------------------------------------------------------ decode
     def _decode_step(self) -> None:
@@ -308,6 +312,9 @@ class Qwen2VLEngine:
         """Generate n_steps further tokens (each replays the captured step)."""
         if self.prompt_len + n_steps + 1 > self.max_ctx:
             raise ValueError("decode would overflow the KV cache")
+        if self.prompt_len + self._decoded + n_steps > self.decode_limit:
+            raise ValueError("decode beyond the rope rows prepared by prefill (pass max_new_tokens)")
+        self._decoded += n_steps
         if use_graph:
             g = self._ensure_graph()
             for _ in range(n_steps):
@@ -327,7 +334,7 @@ class Qwen2VLEngine:
         ``check_every`` tokens so the decode loop itself never synchronises; output is truncated at the
         first EOS (exclusive)."""
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
-        self.prefill(input_ids, frames, temperature=temperature, seed=seed)
+        self.prefill(input_ids, frames, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
         done, eos = 1, set(self.cfg.eos_ids)
         while done < max_new_tokens:
             if not ignore_eos:

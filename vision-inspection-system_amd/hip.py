@@ -27,13 +27,16 @@ _SIGS = {
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
-    "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "p",
-    "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "p",
+    "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
+    "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
+    "vis_skinny_ksplit": "ii",
+    "vis_gemm_skinny_bf16": "pppppppp" + "iiiiiiiii" + "p",
+    "vis_skinny_finalize": "ppppp" + "p" + "iiii" + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
 }
-_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint}
+_CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint, "l": ctypes.c_longlong}
 
 
 class HipLibraryError(RuntimeError):
@@ -216,38 +219,101 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[tor
 def decode_attn(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
                 v_cache: torch.Tensor, step: torch.Tensor, part_o: torch.Tensor, part_ml: torch.Tensor,
                 out: torch.Tensor, n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float) -> torch.Tensor:
-    """Fused decode step attention: rope(q,k) + KV append at slot *step + attention over *step+1 keys."""
+    """Fused decode step attention: rope(q,k) + KV append at slot step[b] + attention over step[b]+1 keys.
+
+    Single sequence: qkv [nq*D], caches [Hkv,T,D], tables [T,D], step [1].
+    Batch of B: qkv [B, nq*D], caches [B,Hkv,T,D], tables [B,T,D], step [B], out [B, Hq*D]."""
     _bf16(qkv, "qkv"); _bf16(k_cache, "k_cache")
     if step.dtype != torch.int32 or cos_t.dtype != torch.float32 or sin_t.dtype != torch.float32:
         raise HipLibraryError("decode_attn: step int32 / cos,sin f32 required")
-    if k_cache.shape[0] != n_kv or k_cache.shape[2] != head_dim or not k_cache.is_contiguous() \
-            or v_cache.shape != k_cache.shape or not v_cache.is_contiguous():
+    batched = k_cache.dim() == 4
+    B = k_cache.shape[0] if batched else 1
+    kc = k_cache[0] if batched else k_cache
+    if kc.shape[0] != n_kv or kc.shape[2] != head_dim or v_cache.shape != k_cache.shape \
+            or kc.stride(2) != 1 or kc.stride(1) != head_dim or kc.stride(0) != kc.shape[1] * head_dim:
         raise HipLibraryError("decode_attn: bad cache shape")
-    T = k_cache.shape[1]
-    if cos_t.shape != (T, head_dim) or sin_t.shape != (T, head_dim) or not cos_t.is_contiguous():
+    T = kc.shape[1]
+    tab = cos_t[0] if batched else cos_t
+    if tab.shape != (T, head_dim) or sin_t.shape != cos_t.shape or not tab.is_contiguous():
         raise HipLibraryError("decode_attn: cos/sin tables must be [cache_tokens, head_dim]")
-    if qkv.numel() != (n_q + 2 * n_kv) * head_dim:
-        raise HipLibraryError("decode_attn: bad qkv row")
-    if part_o.dtype != torch.float32 or part_o.numel() < n_q * nsplit * head_dim or part_ml.numel() < n_q * nsplit * 2:
-        raise HipLibraryError("decode_attn: workspace too small")
+    nq = (n_q + 2 * n_kv) * head_dim
+    if qkv.numel() != B * nq or step.numel() != B:
+        raise HipLibraryError("decode_attn: bad qkv / step shape")
+    if part_o.dtype != torch.float32 or part_o.numel() < B * n_q * nsplit * head_dim \
+            or part_ml.numel() < B * n_q * nsplit * 2 or out.numel() != B * n_q * head_dim:
+        raise HipLibraryError("decode_attn: workspace/output too small")
+    qkv_bs = qkv.stride(0) if (batched and qkv.dim() == 2) else nq
+    cache_bs = k_cache.stride(0) if batched else 0
+    if batched and (v_cache.stride(0) != cache_bs or cos_t.stride(0) != sin_t.stride(0)):
+        raise HipLibraryError("decode_attn: k/v caches (cos/sin tables) must share their batch stride")
+    tab_bs = cos_t.stride(0) if batched else 0
     rc = load().vis_decode_attn(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(k_cache), _ptr(v_cache), _ptr(step),
                                 _ptr(part_o), _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, T, nsplit, scale,
-                                _stream())
+                                B, qkv_bs, cache_bs, tab_bs, _stream())
     _check(rc, "vis_decode_attn")
     return out
 
 
 def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tokens: torch.Tensor,
            cur_token: torch.Tensor, step: torch.Tensor, temperature: float = 0.0, seed: int = 0) -> None:
-    """Greedy (temperature 0) or Gumbel-max sampled next token; advances the device-side step."""
+    """Greedy (temperature 0) or Gumbel-max sampled next token; advances the device-side step.
+    logits [V] (tokens [T], cur/step [1]) or logits [B,V] (tokens [B,T], cur/step [B])."""
     if logits.dtype != torch.float32 or tokens.dtype != torch.int32 or cur_token.dtype != torch.int32:
         raise HipLibraryError("argmax: f32 logits / int32 tokens required")
-    if ws_val.numel() < 256 or ws_idx.numel() < 256:
-        raise HipLibraryError("argmax: workspace too small")
-    rc = load().vis_argmax_f32(_ptr(logits), logits.numel(), _ptr(ws_val), _ptr(ws_idx), _ptr(tokens),
-                               tokens.numel(), _ptr(cur_token), _ptr(step),
-                               (1.0 / temperature) if temperature > 0 else 0.0, seed & 0xFFFFFFFF, _stream())
+    B = logits.shape[0] if logits.dim() == 2 else 1
+    V = logits.shape[-1]
+    if ws_val.numel() < 256 * B or ws_idx.numel() < 256 * B or cur_token.numel() != B or step.numel() != B:
+        raise HipLibraryError("argmax: workspace too small / bad state shapes")
+    if logits.stride(-1) != 1 or not tokens.is_contiguous() or tokens.numel() % B:
+        raise HipLibraryError("argmax: bad strides")
+    rc = load().vis_argmax_f32(_ptr(logits), V, _ptr(ws_val), _ptr(ws_idx), _ptr(tokens), tokens.numel() // B,
+                               _ptr(cur_token), _ptr(step), (1.0 / temperature) if temperature > 0 else 0.0,
+                               seed & 0xFFFFFFFF, B, logits.stride(0) if logits.dim() == 2 else V, _stream())
     _check(rc, "vis_argmax_f32")
+
+
+def skinny_gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, part: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                norm_w: Optional[torch.Tensor] = None, rstd: Optional[torch.Tensor] = None,
+                rstd_out: Optional[torch.Tensor] = None, act: int = ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
+    """Batched-decode projection: out[B, N(/2)] = act(xn @ w.T + bias) + residual for B <= 16 rows.
+
+    Non-SwiGLU bf16 outputs run split-K (f32 partials in ``part``) followed by the finalize kernel, which also
+    emits ``rstd_out`` (statistics of the produced rows for the next fused RMSNorm)."""
+    _bf16(x, "skinny x"); _bf16(w, "skinny w")
+    B, K = x.shape
+    N = w.shape[0]
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if w.shape[1] != K or out.shape != (B, n_out) or x.stride(1) != 1 or w.stride(1) != 1 or out.stride(1) != 1:
+        raise HipLibraryError("skinny_gemm: bad shapes")
+    lib = load()
+    f32 = out.dtype == torch.float32
+    split = (act == ACT_NONE) and not f32 and part is not None
+    ks = lib.vis_skinny_ksplit(N, K) if split else 1
+    if split and part.numel() < ks * 16 * N:
+        raise HipLibraryError("skinny_gemm: partial workspace too small")
+    direct = not split or ks == 1
+    rc = lib.vis_gemm_skinny_bf16(_ptr(x), _ptr(w), _ptr(bias) if direct else None,
+                                  _ptr(residual) if direct else None, _ptr(norm_w), _ptr(rstd),
+                                  _ptr(part) if (split and ks > 1) else None, _ptr(out), B, N, K, x.stride(0),
+                                  w.stride(0), residual.stride(0) if residual is not None else 0, out.stride(0),
+                                  act, 1 if f32 else 0, _stream())
+    _check(rc, "vis_gemm_skinny_bf16")
+    if not direct:
+        rc = lib.vis_skinny_finalize(_ptr(part), ks, _ptr(bias), _ptr(residual), _ptr(out), _ptr(rstd_out), B, N,
+                                     residual.stride(0) if residual is not None else 0, out.stride(0), eps, _stream())
+        _check(rc, "vis_skinny_finalize")
+    elif rstd_out is not None:
+        rows_rstd(out, rstd_out, eps)
+    return out
+
+
+def rows_rstd(y: torch.Tensor, rstd_out: torch.Tensor, eps: float) -> None:
+    """rstd_out[b] = rsqrt(mean(y[b]^2) + eps) of finished bf16 rows (statistics pass of vis_skinny_finalize)."""
+    _bf16(y, "rows_rstd y")
+    B, N = y.shape
+    rc = load().vis_skinny_finalize(None, 0, None, None, _ptr(y), _ptr(rstd_out), B, N, 0, y.stride(0), eps, _stream())
+    _check(rc, "vis_skinny_finalize")
 
 
 _MEAN = (ctypes.c_float * 3)()
