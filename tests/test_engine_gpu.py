@@ -95,3 +95,34 @@ def test_prompt_validation(setup):
         eng.prefill([cfg.vocab + 5], [])
     with pytest.raises(ValueError):
         eng.prefill([256, cfg.image_token_id, 10], [])  # image token without an image
+
+
+def test_batched_generation_matches_single(device):
+    """Batched decode (skinny MFMA GEMM, one weight pass for all sequences) vs the single-sequence GEMV path:
+    same prompts -> same greedy tokens up to genuine near-ties (different summation order), and the
+    first token (prefill path, identical code) must agree exactly."""
+    from oracle import qwen2vl_ref as R
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=4)
+    g = load_golden()
+    fa = [torch.from_numpy(g["frame_a"]).to(device)]
+    fb = [torch.from_numpy(g["frame_b1"]).to(device), torch.from_numpy(g["frame_b2"]).to(device)]
+    reqs = [(g["ids_a"].tolist(), fa), (g["ids_b"].tolist(), fb), ([256, 72, 105, 33], []), (g["ids_a"].tolist(), fa)]
+    singles = [eng.generate(ids, fr, max_new_tokens=12, ignore_eos=True) for ids, fr in reqs]
+    for use_graph in (False, True):
+        batch = eng.generate_batch(reqs, max_new_tokens=12, ignore_eos=True, use_graph=use_graph)
+        assert [len(t) for t in batch] == [12] * 4
+        assert batch[0] == batch[3]                      # identical requests in different slots
+        for b, (ids, fr) in enumerate(reqs):
+            assert batch[b][0] == singles[b][0]
+            frames_np = [f.cpu().numpy() for f in fr]
+            pv, grids = oracle_inputs(frames_np) if frames_np else (None, [])
+            ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, pv, grids, 12)
+            assert _check_tokens(batch[b], ref_toks, ref_logits) >= 3, (b, batch[b], ref_toks)
+    # a second batch after the first reuses the captured graph and the slots
+    again = eng.generate_batch(reqs[:2], max_new_tokens=6, ignore_eos=True)
+    assert again[0] == batch[0][:6] and again[1] == batch[1][:6]

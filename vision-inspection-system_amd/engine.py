@@ -111,7 +111,7 @@ class Qwen2VLEngine:
     """One model replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
 
     def __init__(self, cfg: Qwen2VLConfig, weights: DeviceWeights, device, max_ctx: int = 4096,
-                 decode_splits: int = 0):
+                 decode_splits: int = 0, max_batch: int = 1):
         cfg.validate_for_kernels()
         hip.load()  # fail loudly when the gfx950 library is missing: there is no other path
         if not torch.cuda.is_available():
@@ -122,25 +122,43 @@ class Qwen2VLEngine:
         self.lock = threading.Lock()
         dev, bf = self.device, torch.bfloat16
         L, Hkv, Hq, D, H = cfg.layers, cfg.kv_heads, cfg.heads, cfg.head_dim, cfg.hidden
-        self.kcache = torch.zeros((L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
-        self.vcache = torch.zeros((L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
-        self.cos_t = torch.zeros((self.max_ctx, D), dtype=torch.float32, device=dev)
-        self.sin_t = torch.zeros((self.max_ctx, D), dtype=torch.float32, device=dev)
+        if not 1 <= max_batch <= 16:
+            raise ValueError("max_batch must be in 1..16 (one MFMA column block of in-flight sequences)")
+        Bm = self.max_batch = max_batch
+        # per-sequence ("slot") state; slot 0 doubles as the single-sequence engine
+        self.kcache_b = torch.zeros((Bm, L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
+        self.vcache_b = torch.zeros((Bm, L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
+        self.cos_b = torch.zeros((Bm, self.max_ctx, D), dtype=torch.float32, device=dev)
+        self.sin_b = torch.zeros((Bm, self.max_ctx, D), dtype=torch.float32, device=dev)
         # decode-step state (device resident so the step is one replayable graph)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.cur_token = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.tokens = torch.zeros(self.max_ctx, dtype=torch.int32, device=dev)
-        self.ws_val = torch.empty(256, dtype=torch.float32, device=dev)
-        self.ws_idx = torch.empty(256, dtype=torch.int32, device=dev)
-        self.logits = torch.empty(cfg.vocab, dtype=torch.float32, device=dev)
+        self.step_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
+        self.cur_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
+        self.tokens_b = torch.zeros((Bm, self.max_ctx), dtype=torch.int32, device=dev)
+        self.ws_val = torch.empty(256 * Bm, dtype=torch.float32, device=dev)
+        self.ws_idx = torch.empty(256 * Bm, dtype=torch.int32, device=dev)
+        self.logits_b = torch.empty((Bm, cfg.vocab), dtype=torch.float32, device=dev)
+        self.kcache, self.vcache = self.kcache_b[0], self.vcache_b[0]
+        self.cos_t, self.sin_t = self.cos_b[0], self.sin_b[0]
+        self.step, self.cur_token = self.step_b[0:1], self.cur_b[0:1]
+        self.tokens, self.logits = self.tokens_b[0], self.logits_b[0]
         nq = (Hq + 2 * Hkv) * D
         self.d_x = torch.empty((1, H), dtype=bf, device=dev)
         self.d_x2 = torch.empty((1, H), dtype=bf, device=dev)
         self.d_qkv = torch.empty(nq, dtype=bf, device=dev)
         self.d_attn = torch.empty(Hq * D, dtype=bf, device=dev)
         self.d_act = torch.empty(cfg.intermediate, dtype=bf, device=dev)
-        self.part_o = torch.empty(Hq * self.nsplit * D, dtype=torch.float32, device=dev)
-        self.part_ml = torch.empty(Hq * self.nsplit * 2, dtype=torch.float32, device=dev)
+        self.part_o = torch.empty(Bm * Hq * self.nsplit * D, dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty(Bm * Hq * self.nsplit * 2, dtype=torch.float32, device=dev)
+        if Bm > 1:  # batched-decode activations and the split-K partial workspace
+            self.b_x = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_x2 = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_qkv = torch.empty((Bm, nq), dtype=bf, device=dev)
+            self.b_attn = torch.empty((Bm, Hq * D), dtype=bf, device=dev)
+            self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
+            self.b_part = torch.empty(16 * 16 * max(nq, H), dtype=torch.float32, device=dev)
+            self.b_rstd1 = torch.empty(16, dtype=torch.float32, device=dev)
+            self.b_rstd2 = torch.empty(16, dtype=torch.float32, device=dev)
+        self.slot_prompt_len = [0] * Bm
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -202,11 +220,18 @@ class Qwen2VLEngine:
     # ------------------------------------------------------------------ prefill
     def prefill(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (),
                 ids_dev: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
-                temperature: float = 0.0, seed: int = 0, max_new_tokens: Optional[int] = None) -> None:
-        """Run the prompt through the LLM, fill the KV cache and pick the first token
+                temperature: float = 0.0, seed: int = 0, max_new_tokens: Optional[int] = None,
+                slot: int = 0) -> None:
+        """Run the prompt through the LLM, fill the KV cache of ``slot`` and pick the first token
         (greedy when temperature == 0, Gumbel-max sampled otherwise)."""
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        if not 0 <= slot < self.max_batch:
+            raise ValueError("slot out of range")
         self.temperature, self.seed = float(temperature), int(seed)
+        kcache, vcache = self.kcache_b[slot], self.vcache_b[slot]
+        cos_t, sin_t = self.cos_b[slot], self.sin_b[slot]
+        step, cur_token = self.step_b[slot:slot + 1], self.cur_b[slot:slot + 1]
+        tokens, logits = self.tokens_b[slot], self.logits_b[slot]
         S = len(input_ids)
         if S < 1 or S + 1 > self.max_ctx:
             raise ValueError(f"prompt of {S} tokens does not fit the context of {self.max_ctx}")
@@ -220,9 +245,10 @@ class Qwen2VLEngine:
         n_dec = self.max_ctx - S if max_new_tokens is None else min(self.max_ctx - S, max_new_tokens + 1)
         dpos = np.broadcast_to((next_pos + np.arange(n_dec))[None, :], (3, n_dec))
         dcos, dsin = mrope_cos_sin(cfg, dpos)
-        self.cos_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([cos_np, dcos])), non_blocking=True)
-        self.sin_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([sin_np, dsin])), non_blocking=True)
-        self.decode_limit = S + n_dec
+        cos_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([cos_np, dcos])), non_blocking=True)
+        sin_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([sin_np, dsin])), non_blocking=True)
+        if slot == 0:
+            self.decode_limit = S + n_dec
         if ids_dev is None:
             ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
         H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
@@ -236,7 +262,7 @@ class Qwen2VLEngine:
             hip.scatter_rows(img, torch.from_numpy(idx).to(dev), x)
             if taps is not None:
                 taps["image_embeds"] = img
-        cos, sin = self.cos_t[:S], self.sin_t[:S]
+        cos, sin = cos_t[:S], sin_t[:S]
         work = hip.make_attn_work([(0, S)], True, dev)
         ld = _round_up(S, 64)
         nq = (Hq + 2 * Hkv) * D
@@ -250,8 +276,8 @@ class Qwen2VLEngine:
         for li, lw in enumerate(w.llm):
             hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
             hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
-            hip.qkv_rope_split(qkv, cos, sin, q, self.kcache[li], self.vcache[li], vt, Hq, Hkv, D, k_pos0=0)
-            hip.attn_prefill(q, self.kcache[li], vt, att, work, True, scale)
+            hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=0)
+            hip.attn_prefill(q, kcache[li], vt, att, work, True, scale)
             hip.gemm(att, lw.o_w, residual=x, out=x)
             hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
             hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
@@ -259,14 +285,16 @@ class Qwen2VLEngine:
             if taps is not None and li == 0:
                 taps["layer0"] = x.clone()
         # first token: final norm fused into the lm_head GEMV of the last position only
-        hip.gemv(x[S - 1], w.lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+        hip.gemv(x[S - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
         if taps is not None:
-            taps["first_logits"] = self.logits.clone()
-        self.step.fill_(S - 1)
-        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
-                   self.temperature, self.seed)
-        self.prompt_len = S
-        self._decoded = 0
+            taps["first_logits"] = logits.clone()
+        step.fill_(S - 1)
+        hip.argmax(logits, self.ws_val, self.ws_idx, tokens, cur_token, step, self.temperature,
+                   self.seed + 0x9E3779B9 * slot)
+        self.slot_prompt_len[slot] = S
+        if slot == 0:
+            self.prompt_len = S
+            self._decoded = 0
 
     # ------------------------------------------------------------------ decode
     def _decode_step(self) -> None:
@@ -286,22 +314,44 @@ class Qwen2VLEngine:
         hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
                    self.temperature, self.seed)
 
-    def _ensure_graph(self) -> torch.cuda.CUDAGraph:
-        key = (self.temperature, self.seed)  # sampling parameters are kernel arguments baked into the graph
+    # ---- batched decode: B in-flight sequences (slots 0..B-1) share every weight read of a step
+    def _decode_step_batched(self, B: int) -> None:
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        scale, eps = D ** -0.5, cfg.rms_eps
+        x, x2, qkv, att, act = self.b_x[:B], self.b_x2[:B], self.b_qkv[:B], self.b_attn[:B], self.b_act[:B]
+        r1, r2, part = self.b_rstd1, self.b_rstd2, self.b_part
+        hip.gather_rows(w.embed, self.cur_b[:B], x)
+        hip.rows_rstd(x, r1, eps)
+        for li, lw in enumerate(w.llm):
+            hip.skinny_gemm(x, lw.qkv_w, qkv, part=part, bias=lw.qkv_b, norm_w=lw.ln1_w, rstd=r1, eps=eps)
+            hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+            hip.skinny_gemm(att, lw.o_w, x2, part=part, residual=x, rstd_out=r2, eps=eps)
+            hip.skinny_gemm(x2, lw.gateup_w, act, norm_w=lw.ln2_w, rstd=r2, act=hip.ACT_SWIGLU, eps=eps)
+            hip.skinny_gemm(act, lw.down_w, x, part=part, residual=x2, rstd_out=r1, eps=eps)
+        hip.skinny_gemm(x, w.lm_head, self.logits_b[:B], norm_w=w.final_norm_w, rstd=r1, eps=eps)
+        hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
+                   self.temperature, self.seed)
+
+    def _ensure_graph(self, batch: int = 0) -> torch.cuda.CUDAGraph:
+        # sampling parameters (and the batch size) are kernel arguments baked into the graph
+        key = (self.temperature, self.seed, batch)
         if key in self._graphs:
             return self._graphs[key]
+        step_fn = (lambda: self._decode_step_batched(batch)) if batch else self._decode_step
         # warm the kernels outside capture, then restore the counters the warm-up advanced
-        saved = (self.step.clone(), self.cur_token.clone())
+        saved = (self.step_b.clone(), self.cur_b.clone())
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._decode_step()
+            step_fn()
         torch.cuda.current_stream().wait_stream(side)
-        self.step.copy_(saved[0])
-        self.cur_token.copy_(saved[1])
+        self.step_b.copy_(saved[0])
+        self.cur_b.copy_(saved[1])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            self._decode_step()
+            step_fn()
         # capture does not execute; state is unchanged
         if len(self._graphs) >= 8:
             self._graphs.pop(next(iter(self._graphs)))
@@ -350,3 +400,43 @@ class Qwen2VLEngine:
                 if t in eos:
                     return toks[:i]
         return toks
+
+    # ------------------------------------------------------------------ batched generation
+    def generate_batch(self, requests: Sequence[Tuple[Sequence[int], Sequence[torch.Tensor]]],
+                       max_new_tokens: int = 128, ignore_eos: bool = False, use_graph: bool = True,
+                       check_every: int = 16, temperature: float = 0.0, seed: int = 0) -> List[List[int]]:
+        """requests: [(input_ids, frames)] for up to max_batch images.  Prefill runs per image (M = S rows is
+        already MFMA-efficient); the decode steps are shared: one weight pass per step for all sequences."""
+        B = len(requests)
+        if not 1 <= B <= self.max_batch:
+            raise ValueError(f"batch of {B} does not fit max_batch={self.max_batch}")
+        if B == 1:
+            ids, frames = requests[0]
+            return [self.generate(ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)]
+        longest = max(len(r[0]) for r in requests)
+        max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - longest - 1))
+        for b, (ids, frames) in enumerate(requests):
+            self.prefill(ids, frames, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens, slot=b)
+        eos = set(self.cfg.eos_ids)
+        starts = [self.slot_prompt_len[b] - 1 for b in range(B)]
+
+        def collect(n):
+            t = self.tokens_b[:B].cpu()
+            return [t[b, starts[b]:starts[b] + n].tolist() for b in range(B)]
+
+        done = 1
+        g = self._ensure_graph(B) if use_graph else None
+        while done < max_new_tokens:
+            if not ignore_eos and all(any(t in eos for t in seq) for seq in collect(done)):
+                break
+            n = min(check_every if not ignore_eos else max_new_tokens, max_new_tokens - done)
+            for _ in range(n):
+                if g is not None:
+                    g.replay()
+                else:
+                    self._decode_step_batched(B)
+            done += n
+        outs = collect(done)
+        if not ignore_eos:
+            outs = [seq[:next((i for i, t in enumerate(seq) if t in eos), len(seq))] for seq in outs]
+        return outs
