@@ -209,6 +209,9 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="images per step per GPU; > 1 uses the batched decode path (BASELINE configs[3]/[4] style "
+                         "batch inspection) - NOT the headline single-image configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -229,7 +232,7 @@ def main():
 
     cfg = Qwen2VLConfig.qwen2_vl_7b() if args.model == "7b" else Qwen2VLConfig.tiny()
     weights = random_device_weights(cfg, dev, seed=0)
-    engine = Qwen2VLEngine(cfg, weights, dev, max_ctx=4096 if args.model == "7b" else 1024)
+    engine = Qwen2VLEngine(cfg, weights, dev, max_ctx=4096 if args.model == "7b" else 1024, max_batch=args.batch)
 
     frame_np = synthetic_frame(rank, args.image_size)
     n_patches = (frame_np.shape[0] // cfg.patch) * (frame_np.shape[1] // cfg.patch)
@@ -242,7 +245,31 @@ def main():
 
     pre_ev, step_records = [], []
 
+    def one_step_batched(timed: bool):
+        s = torch.cuda.Event(enable_timing=True)
+        m = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        B = args.batch
+        s.record()
+        for b in range(B):
+            engine.prefill(ids, [frame], ids_dev=ids_dev, max_new_tokens=new, slot=b)
+        m.record()
+        g = engine._ensure_graph(B) if not args.no_graph else None
+        for _ in range(new - 1):
+            if g is not None:
+                g.replay()
+            else:
+                engine._decode_step_batched(B)
+        e.record()
+        toks = engine.tokens_b[:B, S - 1:S - 1 + new].cpu().tolist()
+        rec = gather_records([{"image": f"synthetic_{rank}_{b}", "tokens": toks[b]} for b in range(B)], world)
+        if timed:
+            pre_ev.append((s, m, e))
+            step_records.append(len(rec))
+
     def one_step(timed: bool):
+        if args.batch > 1:
+            return one_step_batched(timed)
         s = torch.cuda.Event(enable_timing=True)
         m = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
@@ -283,11 +310,15 @@ def main():
         flops = prefill_flops(cfg, n_patches, S)
         out = {
             "metric": "inspected images/sec (1024x1024, Qwen2-VL-7B)" if args.model == "7b" else "images/sec (tiny)",
-            "value": world * args.steps / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "value": world * args.steps * args.batch / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: Qwen2-VL-7B Inspector bf16, single {args.image_size}x"
-                                   f"{args.image_size} image per step per GPU, greedy decode {new} tok",
+            "config": {"workload": (f"configs[1]: Qwen2-VL-7B Inspector bf16, single {args.image_size}x"
+                                    f"{args.image_size} image per step per GPU, greedy decode {new} tok")
+                       if args.batch == 1 else
+                       (f"batch inspection: {args.batch} x {args.image_size}x{args.image_size} images per step per GPU, "
+                        f"per-image prefill + batched decode {new} tok (NOT the headline configuration)"),
+                       "batch": args.batch,
                        "image_px": args.image_size, "resized_px": list(frame_np.shape[:2]),
                        "image_tokens": n_img_tok, "prompt_tokens": S, "new_tokens": new,
                        "weights": "seeded random bf16 at exact 7B shapes", "parallelism": f"dp{world} (whole images)"},
@@ -298,7 +329,8 @@ def main():
             "prefill_mfma": {"flops": flops, "ms": t_pre * 1e3, "achieved": flops / t_pre / 1e12,
                              "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t_pre / 1e12 / MFMA_BF16_PEAK_TF},
             "decode": {"ms": t_dec * 1e3, "ms_per_token": t_dec / (new - 1) * 1e3,
-                       "weight_GBps": gemv_bytes_per_step(cfg) * (new - 1) / t_dec / 1e9},
+                       "weight_GBps": gemv_bytes_per_step(cfg) * (new - 1) / t_dec / 1e9,
+                       "sequences_per_step": args.batch},
         }
         if not args.no_cpu_baseline and args.model == "7b":
             out["cpu_baseline"] = cpu_baseline(cfg, n_patches, S, new)
