@@ -20,6 +20,7 @@
 // accumulators across all K-chunks; the loads of the next K-chunk are issued before the current one is
 // consumed (two register sets).
 #include "common.hip.h"
+#include <stdlib.h>
 
 #define SK_KC 256          // K-chunk staged in LDS (8 k-steps of 32): two 64-VGPR weight buffers fit
 #define SK_STEPS (SK_KC / 32)
@@ -43,6 +44,7 @@ struct SkBuf {
   u32x4 w[2][SK_STEPS];
 };
 
+template <bool NT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
   // x chunk, row stride padded by 16 B so the 16 rows of a B-operand read land on distinct bank groups
   constexpr int XROW = SK_KC * 2 + 16;
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
       for (int s = 0; s < SK_STEPS; ++s) {
         const int k = min(k0 + s * 32, p.K - 32);  // unconditional load; out-of-range steps are zeroed via x
-        b.w[g][s] = __builtin_nontemporal_load((const u32x4*)(wrow[g] + k));
+        b.w[g][s] = NT ? __builtin_nontemporal_load((const u32x4*)(wrow[g] + k)) : *(const u32x4*)(wrow[g] + k);
       }
   };
 
@@ -240,7 +242,9 @@ extern "C" int vis_gemm_skinny_bf16(const void* x, const void* W, const void* bi
   p.ksplit = (act == 3 || out_f32 || !part) ? 1 : skinny_ksplit(N, K);
   const int blocks = (N + SK_ROWS_PER_BLOCK - 1) / SK_ROWS_PER_BLOCK;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_skinny_kernel, dim3(blocks, p.ksplit), dim3(256), 0, stream, p);
+  static const int nt = [] { const char* e = getenv("VIS_SKINNY_NT"); return e ? atoi(e) : 1; }();
+  if (nt) hipLaunchKernelGGL(gemm_skinny_kernel<true>, dim3(blocks, p.ksplit), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(gemm_skinny_kernel<false>, dim3(blocks, p.ksplit), dim3(256), 0, stream, p);
   return vis_check_launch();
 }
 
