@@ -100,35 +100,21 @@ int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* 
 /* batch > 1: sequence b reads logits + b*ld_logits, writes tokens[b*max_tokens + step[b]], cur_token[b],
  * step_ptr[b]; ws_val / ws_idx need 256 entries per sequence. */
 
-/* K10 (batched decode)  Y[b,n] = act(sum_k W[n,k] xn[b,k] + bias[n]) + R[b,n] for up to 16 in-flight sequences:
- * the weight matrix is streamed from HBM once for all of them (MFMA with the weight rows as the A operand).
- * xn = bf16(x * rstd[b]) * norm_w when norm_w != NULL.  With `part` != NULL and act == NONE, bf16 output, K is
- * split over vis_skinny_ksplit(N, K) grid slices that write f32 partials part[ksplit][16][N]; the caller then
- * runs vis_skinny_finalize.  SwiGLU / f32-logit launches are never split. */
-int vis_skinny_ksplit(int N, int K);
-int vis_gemm_skinny_bf16(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,
-                         const void* rstd, void* part, void* y, int B, int N, int K, int ldx, int ldw, int ldr,
-                         int ldy, int act, int out_f32, vis_stream_t stream);
+/* K10 (batched decode), first half.  For up to 16 in-flight sequences the weight matrix is streamed from HBM
+ * ONCE per step: partial[ks][16][N] (f32) = x[B,K] * W[N,K]^T over K-slice ks of `ksplit` (32x128x64 MFMA tile,
+ * LDS-DMA staging in full cache lines, split-K over grid.y for occupancy).  part == NULL: ksplit = 1 and C is
+ * written directly (bf16, or f32 logits when out_f32).  vis_gemm_decode_ksplit suggests a split factor. */
+int vis_gemm_decode_ksplit(int N, int K);
+int vis_gemm_decode_bf16(const void* x, const void* W, void* part, void* C, int B, int N, int K, int ldx, int ldw,
+                         int ldc, int ksplit, int out_f32, vis_stream_t stream);
 
-/* y[b][n] = sum_ks part[ks][b][n] + bias[n] + R[b][n] (fixed order, bitwise reproducible); rstd_out[b] =
- * rsqrt(mean(y[b]^2) + eps) for the next fused RMSNorm (TF modeling_qwen2_vl.py:96-110).  ksplit == 0: only the
- * statistics of the finished rows y. */
-int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const void* R, void* y, void* rstd_out,
-                        int B, int N, int ldr, int ldy, float eps, vis_stream_t stream);
-
-/* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
- * out[row0 + p][ld_out] in the merge-group order of
- * TF image_processing_pil_qwen2_vl.py:156-190; mean/stdv are HOST pointers to 3 floats. */
-int vis_patchify_u8(const void* img, void* out, int H, int W, int ld_out, int row0, const float* mean,
-                    const float* stdv, vis_stream_t stream);
-
-/* K12  out[i][:] = table[ids[i]][:] (embedding lookup, ids int32 on device). */
-int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D, int n_table,
-                    vis_stream_t stream);
-
-/* K12  dst[idx[i]][:] = src[i][:] (image-token scatter, TF modeling_qwen2_vl.py:1144-1200). */
-int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
-                     vis_stream_t stream);
+/* K10 (batched decode), second half: one workgroup per sequence sums the K-slices in a fixed order (bitwise
+ * reproducible), applies bias / residual or SwiGLU (16-column interleaved gate/up, N/2 outputs) -> y, and when
+ * norm_w != NULL also writes yn = bf16(bf16(y * rsqrt(mean(y^2) + eps)) * norm_w) - the RMSNorm'd input of the
+ * NEXT projection (TF modeling_qwen2_vl.py:96-110,:459-466,:598-624). */
+int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const void* R, const void* norm_w, void* y,
+                        void* yn, int B, int N, int ldr, int ldy, int ldyn, int swiglu, float eps,
+                        vis_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -369,47 +369,50 @@ def test_patchify_matches_reference_layout(hip, device):
     assert np.abs(got[:, 1176:]).max() == 0.0
 
 
-# ----------------------------------------------------------------------------- K10 batched (skinny GEMM)
-@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 704), (16, 4608, 3584), (8, 3584, 18944), (3, 152064, 3584)])
-def test_skinny_gemm_split_and_finalize(hip, device, B, N, K):
+# ----------------------------------------------------------------------------- K10 batched decode projection
+@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 704), (16, 4608, 3584), (8, 3584, 18944)])
+def test_decode_gemm_split_and_finalize(hip, device, B, N, K):
     x = _randn((B, K), device, 100, 2.0)
     w = _randn((N, K), device, 101, 1.0 / math.sqrt(K))
     b = _randn((N,), device, 102)
     r = _randn((B, N), device, 103)
-    out = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+    nw = _randn((N,), device, 104)
     part = torch.empty(16 * 16 * N, dtype=torch.float32, device=device)
-    rstd = torch.empty(16, dtype=torch.float32, device=device)
-    hip.skinny_gemm(x, w, out, part=part, bias=b, residual=r, rstd_out=rstd)
+    y = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+    yn = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+    ks = hip.decode_gemm(x, w, part=part)
+    assert 1 <= ks <= 16
+    hip.skinny_finalize(part, ks, y, N, bias=b, residual=r, norm_w=nw, yn=yn)
     ref = x.float() @ w.float().t() + b.float() + r.float()
-    _assert_close(out, ref, atol=4e-2, rtol=1e-2, what=f"skinny {B}x{N}x{K}")
-    ref_rstd = torch.rsqrt(out.float().pow(2).mean(-1) + 1e-6)
-    _assert_close(rstd[:B], ref_rstd, atol=1e-4, rtol=1e-4, what="finalize rstd")
-    # bitwise reproducible (fixed summation order)
-    out2 = torch.empty_like(out)
-    hip.skinny_gemm(x, w, out2, part=part, bias=b, residual=r)
-    assert torch.equal(out, out2)
+    _assert_close(y, ref, atol=4e-2, rtol=1e-2, what=f"decode gemm {B}x{N}x{K} ks={ks}")
+    yf = y.float()
+    ref_n = (yf * torch.rsqrt(yf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float() * nw.float()
+    _assert_close(yn, ref_n, atol=3e-2, rtol=1e-2, what="finalize next-norm")
+    y2 = torch.empty_like(y)
+    hip.decode_gemm(x, w, part=part, ksplit=ks)
+    hip.skinny_finalize(part, ks, y2, N, bias=b, residual=r)
+    assert torch.equal(y, y2)            # fixed summation order: bitwise reproducible
 
 
-def test_skinny_gemm_fused_norm_swiglu_and_logits(hip, device):
+def test_decode_gemm_swiglu_and_direct_logits(hip, device):
     from vision_inspection_system_amd.weights import interleave_gate_up
     B, K, I = 7, 256, 704
-    x = _randn((B, K), device, 104, 2.0)
-    nw = _randn((K,), device, 105)
+    x = _randn((B, K), device, 105)
     wg = _randn((I, K), device, 106, 1.0 / math.sqrt(K))
     wu = _randn((I, K), device, 107, 1.0 / math.sqrt(K))
-    rstd = torch.empty(16, dtype=torch.float32, device=device)
-    hip.rows_rstd(x, rstd, 1e-6)
-    xf = x.float()
-    xn = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float() * nw.float())
-    xn = xn.to(torch.bfloat16).float()
+    part = torch.empty(16 * 16 * 2 * I, dtype=torch.float32, device=device)
     out = torch.empty((B, I), dtype=torch.bfloat16, device=device)
-    hip.skinny_gemm(x, interleave_gate_up(wg, wu), out, norm_w=nw, rstd=rstd, act=hip.ACT_SWIGLU)
-    ref = torch.nn.functional.silu(xn @ wg.float().t()) * (xn @ wu.float().t())
-    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="skinny swiglu")
-    wl = _randn((1000, K), device, 108, 1.0 / math.sqrt(K))
-    logits = torch.empty((B, 1000), dtype=torch.float32, device=device)
-    hip.skinny_gemm(x, wl, logits, norm_w=nw, rstd=rstd)
-    _assert_close(logits, xn @ wl.float().t(), atol=2e-2, rtol=1e-2, what="skinny f32 logits")
+    ks = hip.decode_gemm(x, interleave_gate_up(wg, wu), part=part)
+    hip.skinny_finalize(part, ks, out, 2 * I, swiglu=True)
+    ref = torch.nn.functional.silu(x.float() @ wg.float().t()) * (x.float() @ wu.float().t())
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="decode gemm swiglu")
+    wl = _randn((152064, K), device, 108, 1.0 / math.sqrt(K))
+    logits = torch.empty((B, 152064), dtype=torch.float32, device=device)
+    hip.decode_gemm(x, wl, out=logits)
+    _assert_close(logits, x.float() @ wl.float().t(), atol=2e-2, rtol=1e-2, what="decode gemm f32 logits")
+    yb = torch.empty((B, 1000), dtype=torch.bfloat16, device=device)
+    hip.decode_gemm(x, wl[:1000], out=yb)
+    _assert_close(yb, x.float() @ wl[:1000].float().t(), atol=3e-2, rtol=1e-2, what="decode gemm direct bf16")
 
 
 def test_batched_decode_attention_and_argmax(hip, device):

@@ -44,6 +44,9 @@ struct GemmArgs {
   int lda, ldw, ldc, ldr;
   int act;
   int tiles_m, tiles_n;
+  // 32-row (batched decode) tile only: K split over grid.y, f32 partials part[ks][16][N]; out_f32: direct f32 C
+  float* part;
+  int ksplit, out_f32;
 };
 
 __device__ __forceinline__ float act_apply(float x, int act) {
@@ -344,6 +347,144 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x128_kernel(GemmArgs p) {
   gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
 }
 
+// ---------------------------------------------------------------------------
+// 32x128x64 tile for the batched decode step (M = in-flight sequences <= 16, padded to one 32-row tile):
+// the weight panel is streamed in FULL cache lines by LDS-DMA exactly like the big tiles (a lane-per-row
+// "fragment shaped" global load is texture-addresser bound at ~2.5 TB/s), four waves split the 128 columns,
+// K is split over grid.y so that even N = 3584 launches hundreds of workgroups; partial sums go to
+// part[ks][16][N] (f32) and vis_skinny_finalize applies the epilogue.  ksplit == 1 writes C directly
+// (bf16 via gemm_epilogue, or f32 logits).
+#define GEMM3_BM 32
+#define GEMM3_STAGE_BYTES ((GEMM3_BM + GEMM_BN) * GEMM_BK * 2)  // 20480
+
+__global__ __launch_bounds__(256, 2) void gemm_bf16_32x128_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds3[2 * GEMM3_STAGE_BYTES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wn = tid >> 6;  // wave = 32-column slice
+  const int l15 = lane & 15, h = lane >> 4;
+  const int n0 = blockIdx.x * GEMM_BN;
+  const int nk_all = p.K / GEMM_BK;
+  const int kt0 = (int)((long long)nk_all * blockIdx.y / p.ksplit);
+  const int kt1 = (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit);
+  const int nk = kt1 - kt0;
+
+  // staging: A tile 32 rows x 8 chunks = 256 chunks (1 per thread), W tile 128 x 8 = 1024 chunks (4 per thread)
+  uint32_t a_off, w_off[4];
+  {
+    const int row = tid >> 3, ch = (tid & 7) ^ (row & 7);
+    a_off = (uint32_t)min(row, p.M - 1) * (uint32_t)(p.lda * 2) + ch * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 3, ch = (c & 7) ^ (row & 7);
+    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+  }
+  const char* a_base = (const char*)p.A + (size_t)kt0 * GEMM_BK * 2;
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt0 * GEMM_BK * 2;
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
+  constexpr int A_BYTES = GEMM3_BM * GEMM_BK * 2;  // 4 KiB
+
+  auto stage = [&](int buf) {
+    char* base = lds3 + buf * GEMM3_STAGE_BYTES + wave_base;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off),
+                                     (__attribute__((address_space(3))) void*)(base), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096), 16, 0, 0);
+    a_base += GEMM_BK * 2;
+    w_base += GEMM_BK * 2;
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int sw = lane & 7;
+  const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
+  const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
+  const int w_rd = A_BYTES + wn * 32 * 128;
+
+  if (nk > 0) stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* base = lds3 + cur * GEMM3_STAGE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int rd = ks ? rd1 : rd0;
+      bf16x8 af[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(base + i * 2048 + rd);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // lane holds D[n = n0 + 32 wn + 16 j + 4 h + r][m = 16 i + l15]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = i * 16 + l15;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + 4 * h;
+      if (n >= p.N) continue;
+      if (p.part) {
+        *(f32x4*)(p.part + ((size_t)blockIdx.y * 16 + m) * p.N + n) = acc[i][j];
+      } else if (p.out_f32) {
+        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = acc[i][j];
+      } else {
+        u32x2 o;
+        o[0] = pack2bf(acc[i][j][0], acc[i][j][1]);
+        o[1] = pack2bf(acc[i][j][2], acc[i][j][3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// Batched-decode projection, first half: partial[ks][16][N] = x[B,K] * W[N,K]^T over K-slice ks (f32), or with
+// part == NULL a direct C (bf16, or f32 when out_f32).  B <= 16.  ksplit <= 0 picks one automatically.
+extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, void* C, int B, int N, int K, int lda,
+                                    int ldw, int ldc, int ksplit, int out_f32, hipStream_t stream) {
+  if (!A || !W || (!part && !C) || B <= 0 || B > 16 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % GEMM_BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || (C && ldc % 4 != 0)) return VIS_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)part | (uintptr_t)C) & 15) return VIS_ERR_ARG;
+  const int nkt = K / GEMM_BK;
+  if (!part) ksplit = 1;
+  if (ksplit <= 0 || ksplit > 16 || ksplit > nkt) return VIS_ERR_ARG;
+  GemmArgs p;
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = nullptr; p.R = nullptr; p.C = (bf16_t*)C;
+  p.M = B; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.act = ACT_NONE;
+  p.tiles_m = 1; p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
+  p.part = (float*)part; p.ksplit = ksplit; p.out_f32 = out_f32;
+  vis_clear_error();
+  hipLaunchKernelGGL(gemm_bf16_32x128_kernel, dim3(p.tiles_n, ksplit), dim3(256), 0, stream, p);
+  return vis_check_launch();
+}
+
+// split factor giving >= ~768 workgroups (3 per CU) without K-slices shorter than 4 K-steps
+extern "C" int vis_gemm_decode_ksplit(int N, int K) {
+  if (N <= 0 || K < GEMM_BK) return 0;
+  const int tiles = (N + GEMM_BN - 1) / GEMM_BN, nkt = K / GEMM_BK;
+  int ks = (768 + tiles - 1) / tiles;
+  if (ks > nkt / 4) ks = nkt / 4;
+  if (ks > 16) ks = 16;
+  return ks < 1 ? 1 : ks;
+}
+
 // C-ABI launcher (declared in include/vis_hip.h)
 extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, const void* R, void* C,
                              int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
@@ -364,6 +505,7 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   p.M = M; p.N = N; p.K = K;
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act;
+  p.part = nullptr; p.ksplit = 1; p.out_f32 = 0;
   // tile choice: the 3-stage 256x128 kernel wins on large problems; VIS_GEMM_TILE=1|2 forces a shape (A/B runs)
   static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
   // measured on MI355X (tools/kbench.py): the 256x128 kernel wins when its grid is one full round of the 256 CUs

@@ -155,9 +155,9 @@ class Qwen2VLEngine:
             self.b_qkv = torch.empty((Bm, nq), dtype=bf, device=dev)
             self.b_attn = torch.empty((Bm, Hq * D), dtype=bf, device=dev)
             self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
-            self.b_part = torch.empty(16 * 16 * max(nq, H), dtype=torch.float32, device=dev)
-            self.b_rstd1 = torch.empty(16, dtype=torch.float32, device=dev)
-            self.b_rstd2 = torch.empty(16, dtype=torch.float32, device=dev)
+            self.b_xn = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_part = torch.empty(16 * 16 * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32, device=dev)
         self.slot_prompt_len = [0] * Bm
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.temperature, self.seed = 0.0, 0
@@ -316,21 +316,30 @@ class Qwen2VLEngine:
 
     # ---- batched decode: B in-flight sequences (slots 0..B-1) share every weight read of a step
     def _decode_step_batched(self, B: int) -> None:
+        """Every projection = gemm_decode (weights streamed once for all B sequences, split-K f32 partials) +
+        skinny_finalize (row-wise: sum, bias/residual/SwiGLU, and the RMSNorm of the NEXT projection)."""
         cfg, w = self.cfg, self.w
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         scale, eps = D ** -0.5, cfg.rms_eps
         x, x2, qkv, att, act = self.b_x[:B], self.b_x2[:B], self.b_qkv[:B], self.b_attn[:B], self.b_act[:B]
-        r1, r2, part = self.b_rstd1, self.b_rstd2, self.b_part
+        xn, xn2, part = self.b_xn[:B], self.b_xn2[:B], self.b_part
+        nq = qkv.shape[1]
         hip.gather_rows(w.embed, self.cur_b[:B], x)
-        hip.rows_rstd(x, r1, eps)
+        hip.rmsnorm(x, w.llm[0].ln1_w, eps, out=xn)
+        n_layers = len(w.llm)
         for li, lw in enumerate(w.llm):
-            hip.skinny_gemm(x, lw.qkv_w, qkv, part=part, bias=lw.qkv_b, norm_w=lw.ln1_w, rstd=r1, eps=eps)
+            ks = hip.decode_gemm(xn, lw.qkv_w, part=part)
+            hip.skinny_finalize(part, ks, qkv, nq, bias=lw.qkv_b, eps=eps)
             hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
                             self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
-            hip.skinny_gemm(att, lw.o_w, x2, part=part, residual=x, rstd_out=r2, eps=eps)
-            hip.skinny_gemm(x2, lw.gateup_w, act, norm_w=lw.ln2_w, rstd=r2, act=hip.ACT_SWIGLU, eps=eps)
-            hip.skinny_gemm(act, lw.down_w, x, part=part, residual=x2, rstd_out=r1, eps=eps)
-        hip.skinny_gemm(x, w.lm_head, self.logits_b[:B], norm_w=w.final_norm_w, rstd=r1, eps=eps)
+            ks = hip.decode_gemm(att, lw.o_w, part=part)
+            hip.skinny_finalize(part, ks, x2, cfg.hidden, residual=x, norm_w=lw.ln2_w, yn=xn2, eps=eps)
+            ks = hip.decode_gemm(xn2, lw.gateup_w, part=part)
+            hip.skinny_finalize(part, ks, act, 2 * cfg.intermediate, swiglu=True, eps=eps)
+            ks = hip.decode_gemm(act, lw.down_w, part=part)
+            next_norm = w.llm[li + 1].ln1_w if li + 1 < n_layers else w.final_norm_w
+            hip.skinny_finalize(part, ks, x, cfg.hidden, residual=x2, norm_w=next_norm, yn=xn, eps=eps)
+        hip.decode_gemm(xn, w.lm_head, out=self.logits_b[:B])
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
 

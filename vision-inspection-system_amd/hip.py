@@ -29,9 +29,9 @@ _SIGS = {
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
-    "vis_skinny_ksplit": "ii",
-    "vis_gemm_skinny_bf16": "pppppppp" + "iiiiiiiii" + "p",
-    "vis_skinny_finalize": "ppppp" + "p" + "iiii" + "f" + "p",
+    "vis_gemm_decode_ksplit": "ii",
+    "vis_gemm_decode_bf16": "pppp" + "iiiiiiii" + "p",
+    "vis_skinny_finalize": "p" + "i" + "ppppp" + "iiiiii" + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
@@ -272,47 +272,46 @@ def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tok
     _check(rc, "vis_argmax_f32")
 
 
-def skinny_gemm(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, part: Optional[torch.Tensor] = None,
-                bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-                norm_w: Optional[torch.Tensor] = None, rstd: Optional[torch.Tensor] = None,
-                rstd_out: Optional[torch.Tensor] = None, act: int = ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
-    """Batched-decode projection: out[B, N(/2)] = act(xn @ w.T + bias) + residual for B <= 16 rows.
-
-    Non-SwiGLU bf16 outputs run split-K (f32 partials in ``part``) followed by the finalize kernel, which also
-    emits ``rstd_out`` (statistics of the produced rows for the next fused RMSNorm)."""
-    _bf16(x, "skinny x"); _bf16(w, "skinny w")
+def decode_gemm(x: torch.Tensor, w: torch.Tensor, part: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None, ksplit: int = 0) -> int:
+    """Batched-decode projection, first half: f32 partials part[ks][16][N] = x[B,K] @ w[N,K].T per K-slice
+    (returns the split factor used), or - with ``out`` instead of ``part`` - a direct bf16 / f32 result."""
+    _bf16(x, "decode_gemm x"); _bf16(w, "decode_gemm w")
     B, K = x.shape
     N = w.shape[0]
-    n_out = N // 2 if act == ACT_SWIGLU else N
-    if w.shape[1] != K or out.shape != (B, n_out) or x.stride(1) != 1 or w.stride(1) != 1 or out.stride(1) != 1:
-        raise HipLibraryError("skinny_gemm: bad shapes")
+    if w.shape[1] != K or x.stride(1) != 1 or w.stride(1) != 1 or (part is None) == (out is None):
+        raise HipLibraryError("decode_gemm: bad shapes (give exactly one of part / out)")
     lib = load()
-    f32 = out.dtype == torch.float32
-    split = (act == ACT_NONE) and not f32 and part is not None
-    ks = lib.vis_skinny_ksplit(N, K) if split else 1
-    if split and part.numel() < ks * 16 * N:
-        raise HipLibraryError("skinny_gemm: partial workspace too small")
-    direct = not split or ks == 1
-    rc = lib.vis_gemm_skinny_bf16(_ptr(x), _ptr(w), _ptr(bias) if direct else None,
-                                  _ptr(residual) if direct else None, _ptr(norm_w), _ptr(rstd),
-                                  _ptr(part) if (split and ks > 1) else None, _ptr(out), B, N, K, x.stride(0),
-                                  w.stride(0), residual.stride(0) if residual is not None else 0, out.stride(0),
-                                  act, 1 if f32 else 0, _stream())
-    _check(rc, "vis_gemm_skinny_bf16")
-    if not direct:
-        rc = lib.vis_skinny_finalize(_ptr(part), ks, _ptr(bias), _ptr(residual), _ptr(out), _ptr(rstd_out), B, N,
-                                     residual.stride(0) if residual is not None else 0, out.stride(0), eps, _stream())
-        _check(rc, "vis_skinny_finalize")
-    elif rstd_out is not None:
-        rows_rstd(out, rstd_out, eps)
-    return out
+    if part is not None:
+        ks = ksplit or lib.vis_gemm_decode_ksplit(N, K)
+        if part.dtype != torch.float32 or part.numel() < ks * 16 * N:
+            raise HipLibraryError("decode_gemm: partial workspace too small")
+        rc = lib.vis_gemm_decode_bf16(_ptr(x), _ptr(w), _ptr(part), None, B, N, K, x.stride(0), w.stride(0), 0, ks, 0,
+                                      _stream())
+    else:
+        ks = 1
+        if out.shape != (B, N) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+            raise HipLibraryError("decode_gemm: bad output")
+        rc = lib.vis_gemm_decode_bf16(_ptr(x), _ptr(w), None, _ptr(out), B, N, K, x.stride(0), w.stride(0),
+                                      out.stride(0), 1, 1 if out.dtype == torch.float32 else 0, _stream())
+    _check(rc, "vis_gemm_decode_bf16")
+    return ks
 
 
-def rows_rstd(y: torch.Tensor, rstd_out: torch.Tensor, eps: float) -> None:
-    """rstd_out[b] = rsqrt(mean(y[b]^2) + eps) of finished bf16 rows (statistics pass of vis_skinny_finalize)."""
-    _bf16(y, "rows_rstd y")
-    B, N = y.shape
-    rc = load().vis_skinny_finalize(None, 0, None, None, _ptr(y), _ptr(rstd_out), B, N, 0, y.stride(0), eps, _stream())
+def skinny_finalize(part: torch.Tensor, ksplit: int, y: torch.Tensor, N: int, bias: Optional[torch.Tensor] = None,
+                    residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+                    yn: Optional[torch.Tensor] = None, swiglu: bool = False, eps: float = 1e-6) -> None:
+    """Batched-decode projection, second half (see include/vis_hip.h): y [B, N or N/2], optional normalised yn."""
+    _bf16(y, "finalize y")
+    B = y.shape[0]
+    n_out = N // 2 if swiglu else N
+    if y.shape[1] != n_out or y.stride(1) != 1 or (yn is not None and (yn.shape != y.shape or yn.stride(1) != 1)):
+        raise HipLibraryError("skinny_finalize: bad output shapes")
+    if residual is not None and (residual.shape != y.shape or residual.stride(1) != 1):
+        raise HipLibraryError("skinny_finalize: bad residual")
+    rc = load().vis_skinny_finalize(_ptr(part), ksplit, _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(y), _ptr(yn),
+                                    B, N, residual.stride(0) if residual is not None else 0, y.stride(0),
+                                    yn.stride(0) if yn is not None else 0, 1 if swiglu else 0, eps, _stream())
     _check(rc, "vis_skinny_finalize")
 
 
