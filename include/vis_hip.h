@@ -116,6 +116,20 @@ int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const vo
                         void* yn, int B, int N, int ldr, int ldy, int ldyn, int swiglu, float eps,
                         vis_stream_t stream);
 
+/* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
+ * out[row0 + p][ld_out] in the merge-group order of
+ * TF image_processing_pil_qwen2_vl.py:156-190; mean/stdv are HOST pointers to 3 floats. */
+int vis_patchify_u8(const void* img, void* out, int H, int W, int ld_out, int row0, const float* mean,
+                    const float* stdv, vis_stream_t stream);
+
+/* K12  out[i][:] = table[ids[i]][:] (embedding lookup, ids int32 on device). */
+int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D, int n_table,
+                    vis_stream_t stream);
+
+/* K12  dst[idx[i]][:] = src[i][:] (image-token scatter, TF modeling_qwen2_vl.py:1144-1200). */
+int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
+                     vis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,33 +109,47 @@ class VLMInspectorAgent(_BaseAgent):
     def _validate_and_fix_result(self, result_dict: Dict[str, Any]) -> Dict[str, Any]:
         return validate_and_fix_result(result_dict, logger=self.logger)
 
+    def _messages(self, image_path: Path, context: InspectionContext) -> list:
+        prompt = INSPECTOR_PROMPT.format(criticality=context.criticality, domain=context.domain or "general",
+                                         user_notes=context.user_notes or "None provided")
+        image_data = self._encode_image_optimized(image_path)
+        return [{"role": "user", "content": [{"type": "text", "text": prompt},
+                                             {"type": "image_url", "image_url": {"url": image_data}}]}]
+
+    def _interpret(self, response_text: str, context: InspectionContext) -> VLMAnalysisResult:
+        result = VLMAnalysisResult(**self._validate_and_fix_result(self._parse_json_robust(response_text)))
+        if result.inferred_criticality and result.inferred_criticality != context.criticality:
+            self.logger.info(f"Agent inferred criticality '{result.inferred_criticality}' differs from "
+                             f"user's '{context.criticality}'")
+        self.logger.info(f"Analysis complete: {len(result.defects)} defects found, "
+                         f"confidence: {result.overall_confidence}")
+        return result
+
+    @staticmethod
+    def _failure(e: Exception) -> VLMAnalysisResult:
+        return VLMAnalysisResult(
+            object_identified="unknown", overall_condition="uncertain", defects=[], overall_confidence="low",
+            analysis_reasoning=f"Analysis failed due to error: {str(e)}", analysis_failed=True,
+            failure_reason=f"Inspector analysis failed: {str(e)}")
+
     def analyze(self, image_path: Path, context: InspectionContext) -> VLMAnalysisResult:
         """Image + context -> structured result.  Never raises: any failure becomes an
         ``analysis_failed=True`` result (vlm_inspector.py:515-526)."""
         self.logger.info(f"Starting inspection for image: {context.image_id}")
         try:
-            prompt = INSPECTOR_PROMPT.format(criticality=context.criticality, domain=context.domain or "general",
-                                             user_notes=context.user_notes or "None provided")
-            image_data = self._encode_image_optimized(image_path)
-            messages = [{"role": "user", "content": [{"type": "text", "text": prompt},
-                                                     {"type": "image_url", "image_url": {"url": image_data}}]}]
+            messages = self._messages(image_path, context)
             t0 = time.time()
             response_text = self._call_api_with_retry(messages)
             self.logger.info(f"{self.provider} response received in {time.time() - t0:.2f}s")
-            result_dict = self._validate_and_fix_result(self._parse_json_robust(response_text))
-            result = VLMAnalysisResult(**result_dict)
-            if result.inferred_criticality and result.inferred_criticality != context.criticality:
-                self.logger.info(f"Agent inferred criticality '{result.inferred_criticality}' differs from "
-                                 f"user's '{context.criticality}'")
-            self.logger.info(f"Analysis complete: {len(result.defects)} defects found, "
-                             f"confidence: {result.overall_confidence}")
-            return result
+            return self._interpret(response_text, context)
         except Exception as e:
             self.logger.error(f"Inspector analysis failed: {e}", exc_info=True)
-            return VLMAnalysisResult(
-                object_identified="unknown", overall_condition="uncertain", defects=[], overall_confidence="low",
-                analysis_reasoning=f"Analysis failed due to error: {str(e)}", analysis_failed=True,
-                failure_reason=f"Inspector analysis failed: {str(e)}")
+            return self._failure(e)
+
+    def analyze_many(self, image_paths, contexts) -> list:
+        """Batch form of ``analyze`` for clients that can serve several requests with one shared decode loop
+        (LocalVLMClient.complete_many).  Failures stay per image; never raises."""
+        return _many(self, image_paths, contexts)
 
 
 class VLMAuditorAgent(_BaseAgent):
@@ -179,30 +193,78 @@ class VLMAuditorAgent(_BaseAgent):
     def _validate_and_fix_result(self, result_dict: Dict[str, Any]) -> Dict[str, Any]:
         return validate_and_fix_result(result_dict, logger=self.logger, who="auditor ")
 
+    def _messages(self, image_path: Path, context: InspectionContext) -> list:
+        prompt = AUDITOR_PROMPT.format(criticality=context.criticality, domain=context.domain or "general")
+        image_data = self._encode_image_optimized(image_path)
+        return [{"role": "user", "content": [{"type": "text", "text": prompt},
+                                             {"type": "image_url", "image_url": {"url": image_data}}]}]
+
+    def _interpret(self, response_text: str, context: InspectionContext) -> VLMAnalysisResult:
+        result = VLMAnalysisResult(**self._validate_and_fix_result(self._parse_json_robust(response_text)))
+        self.logger.info(f"Audit complete: {len(result.defects)} defects found, "
+                         f"confidence: {result.overall_confidence}")
+        return result
+
+    @staticmethod
+    def _failure(e: Exception) -> VLMAnalysisResult:
+        return VLMAnalysisResult(
+            object_identified="unknown", overall_condition="uncertain", defects=[], overall_confidence="low",
+            analysis_reasoning=f"Audit verification failed: {str(e)}", analysis_failed=True,
+            failure_reason=f"Auditor verification failed: {str(e)}")
+
     def verify(self, image_path: Path, context: InspectionContext,
                inspector_result: VLMAnalysisResult) -> VLMAnalysisResult:
         """Independent analysis of the same image; ``inspector_result`` is accepted and - as in the
         reference (vlm_auditor.py:187-191) - not shown to the model.  Never raises."""
         self.logger.info(f"Starting audit verification for: {context.image_id}")
         try:
-            prompt = AUDITOR_PROMPT.format(criticality=context.criticality, domain=context.domain or "general")
-            image_data = self._encode_image_optimized(image_path)
-            messages = [{"role": "user", "content": [{"type": "text", "text": prompt},
-                                                     {"type": "image_url", "image_url": {"url": image_data}}]}]
+            messages = self._messages(image_path, context)
             t0 = time.time()
             response_text = self._call_with_retry(messages, 3, classify=False)
             self.logger.info(f"Auditor response received in {time.time() - t0:.2f}s")
-            result_dict = self._validate_and_fix_result(self._parse_json_robust(response_text))
-            result = VLMAnalysisResult(**result_dict)
-            self.logger.info(f"Audit complete: {len(result.defects)} defects found, "
-                             f"confidence: {result.overall_confidence}")
-            return result
+            return self._interpret(response_text, context)
         except Exception as e:
             self.logger.error(f"Auditor verification failed: {e}", exc_info=True)
-            return VLMAnalysisResult(
-                object_identified="unknown", overall_condition="uncertain", defects=[], overall_confidence="low",
-                analysis_reasoning=f"Audit verification failed: {str(e)}", analysis_failed=True,
-                failure_reason=f"Auditor verification failed: {str(e)}")
+            return self._failure(e)
+
+    def verify_many(self, image_paths, contexts, inspector_results=None) -> list:
+        """Batch form of ``verify`` (see VLMInspectorAgent.analyze_many)."""
+        return _many(self, image_paths, contexts)
+
+
+def _many(agent, image_paths, contexts) -> list:
+    """Shared body of analyze_many / verify_many: encode every image (failures stay per image), one
+    ``complete_many`` call when the client offers it (one shared decode loop), per-reply interpretation."""
+    results = [None] * len(image_paths)
+    todo, msgs = [], []
+    for i, (path, ctx) in enumerate(zip(image_paths, contexts)):
+        try:
+            msgs.append(agent._messages(Path(path), ctx))
+            todo.append(i)
+        except Exception as e:
+            agent.logger.error(f"{agent.nickname}: request for {path} failed: {e}")
+            results[i] = agent._failure(e)
+    if todo:
+        try:
+            if hasattr(agent.client, "complete_many"):
+                replies = agent.client.complete_many(agent.model_id, msgs, agent.temperature, agent.max_tokens)
+                texts = [r.choices[0].message.content for r in replies]
+            else:
+                texts = [agent.client.chat.completions.create(model=agent.model_id, messages=m,
+                                                              temperature=agent.temperature,
+                                                              max_tokens=agent.max_tokens).choices[0].message.content
+                         for m in msgs]
+        except Exception as e:
+            agent.logger.error(f"{agent.nickname}: batched call failed: {e}", exc_info=True)
+            for i in todo:
+                results[i] = agent._failure(e)
+            return results
+        for i, text in zip(todo, texts):
+            try:
+                results[i] = agent._interpret(text, contexts[i])
+            except Exception as e:
+                results[i] = agent._failure(e)
+    return results
 
 
 InspectorAgent = VLMInspectorAgent

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import json
 import logging
+import os
 import time
 import uuid
 from datetime import datetime
@@ -29,6 +30,14 @@ from .nodes import run_auditor, run_inspector
 from .schemas import InspectionContext, VLMAnalysisResult
 
 logger = logging.getLogger("vision_inspection_system_amd.batch")
+
+
+def _local_batching() -> bool:
+    """True when both agents are served by the local engine (so requests can share one decode loop)."""
+    from .config import LOCAL_PROVIDER, get_config
+    cfg = get_config()
+    return getattr(cfg, "vlm_inspector_provider", "") == LOCAL_PROVIDER and \
+        getattr(cfg, "vlm_auditor_provider", "") == LOCAL_PROVIDER and os.environ.get("VIS_BATCH_DECODE", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- collective
@@ -92,6 +101,11 @@ def run_inspection(image_path: str, criticality: str = "medium", domain: Optiona
     }
     state = run_inspector(state)
     state = run_auditor(state)
+    return _finish_state(state)
+
+
+def _finish_state(state: Dict[str, Any]) -> Dict[str, Any]:
+    """consensus -> safety gates -> bookkeeping, shared by the single-image and the batched flow."""
     state["current_step"] = "consensus_analysis"
     inspector = VLMAnalysisResult(**state["inspector_result"])
     auditor = VLMAnalysisResult(**state["auditor_result"])
@@ -99,8 +113,7 @@ def run_inspection(image_path: str, criticality: str = "medium", domain: Optiona
     state["consensus"] = consensus.model_dump()
     try:
         from .gates import evaluate_safety
-        context = InspectionContext(**state["context"])
-        verdict = evaluate_safety(consensus, context)
+        verdict = evaluate_safety(consensus, InspectionContext(**state["context"]))
         state["safety_verdict"] = verdict.model_dump()
         state["requires_human_review"] = verdict.requires_human
     except ImportError:
@@ -108,6 +121,42 @@ def run_inspection(image_path: str, criticality: str = "medium", domain: Optiona
     state["current_step"] = "completed"
     state["processing_time"] = time.time() - state["start_time"]
     return state
+
+
+def run_inspections_batched(image_paths: List[str], criticality: str = "medium", domain: Optional[str] = None,
+                            user_notes: Optional[str] = None) -> List[Dict[str, Any]]:
+    """Several images through Inspector -> Auditor with ONE shared decode loop per agent (local provider):
+    the weights are streamed once per generated token for all images in flight.  Returns one state dict per
+    image, same keys as ``run_inspection``.  An image whose batched analysis failed is retried once through the
+    single-image node (the reference's node-level retry, nodes.py:138-181)."""
+    from .agents import get_auditor, get_inspector
+    states = []
+    for p in image_paths:
+        states.append({"image_path": p,
+                       "context": {"image_id": str(uuid.uuid4())[:8], "criticality": criticality, "domain": domain,
+                                   "user_notes": user_notes},
+                       "request_id": str(uuid.uuid4())[:8], "start_time": time.time(), "inspector_result": None,
+                       "auditor_result": None, "consensus": None, "safety_verdict": None, "clean_verification": None,
+                       "requires_human_review": False, "human_decision": None, "human_notes": None,
+                       "explanation": None, "report_path": None, "processing_time": None, "error": None,
+                       "failure_history": [], "has_critical_failure": False, "inspector_retry_count": 0,
+                       "auditor_retry_count": 0, "current_step": "pending"})
+    contexts = [InspectionContext(**s["context"]) for s in states]
+    for res, st in zip(get_inspector().analyze_many(image_paths, contexts), states):
+        if res.analysis_failed:
+            st["inspector_retry_count"] = 1      # the batched attempt was attempt 1; the node makes the final one
+            run_inspector(st)
+        else:
+            st["current_step"] = "inspector_analysis"
+            st["inspector_result"] = res.model_dump()
+    for res, st in zip(get_auditor().verify_many(image_paths, contexts), states):
+        if res.analysis_failed:
+            st["auditor_retry_count"] = 1
+            run_auditor(st)
+        else:
+            st["current_step"] = "auditor_verification"
+            st["auditor_result"] = res.model_dump()
+    return [_finish_state(st) for st in states]
 
 
 def _image_record(image_id: str, image_path: str, result: Dict[str, Any]) -> Dict[str, Any]:
@@ -145,12 +194,25 @@ def run_multi_image_inspection(image_paths: List[str], criticality: str = "mediu
         session_id = box[0]
 
     mine: List[dict] = []
-    for idx in range(rank, len(image_paths), world):
+    my_idx = list(range(rank, len(image_paths), world))
+    pre: Dict[int, Dict[str, Any]] = {}
+    if _inspect is run_inspection and len(my_idx) > 1 and _local_batching():
+        try:  # shared-decode fast path; any problem falls back to the per-image loop below
+            group = int(os.environ.get("VIS_MAX_BATCH", "8"))
+            for g0 in range(0, len(my_idx), group):
+                chunk = my_idx[g0:g0 + group]
+                outs = run_inspections_batched([image_paths[i] for i in chunk], criticality, domain, user_notes)
+                pre.update(dict(zip(chunk, outs)))
+        except Exception as e:
+            logger.error(f"batched inspection failed ({e}); falling back to per-image processing", exc_info=True)
+            pre = {}
+    for idx in my_idx:
         image_path = image_paths[idx]
         image_id = image_id_map[image_path] if image_id_map and image_path in image_id_map \
             else f"{session_id}-{idx:04d}"
         try:
-            result = _inspect(image_path=image_path, criticality=criticality, domain=domain, user_notes=user_notes)
+            result = pre[idx] if idx in pre else _inspect(image_path=image_path, criticality=criticality,
+                                                              domain=domain, user_notes=user_notes)
             rec = _image_record(image_id, image_path, result)
         except Exception as e:
             logger.error(f"Failed to process image {image_path}: {e}", exc_info=True)

@@ -96,6 +96,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
         if key in _ENGINES:
             return _ENGINES[key]
         max_ctx = int(os.environ.get("VIS_MAX_CTX", "4096"))
+        max_batch = max(1, min(16, int(os.environ.get("VIS_MAX_BATCH", "8"))))
         if model_id.startswith("synthetic:"):
             parts = model_id.split(":")
             kind = parts[1]
@@ -119,7 +120,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
             cfg = Qwen2VLConfig.from_hf_dir(path)
             w = W.load_safetensors_dir(cfg, path, device)
             tok = HFTokenizer(path, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
-        lm = LoadedModel(Qwen2VLEngine(cfg, w, device, max_ctx=max_ctx), tok, cfg, model_id)
+        lm = LoadedModel(Qwen2VLEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch), tok, cfg, model_id)
         _ENGINES[key] = lm
         return lm
 
@@ -140,15 +141,11 @@ class LocalVLMClient:
         self.seed = seed
         self.chat = _Chat(self)
 
-    def _complete(self, model, messages, temperature, max_tokens, **kwargs) -> ChatCompletion:
-        import torch
+    def _prepare(self, lm, messages):
+        """messages -> (token ids, resized uint8 frames) for one request."""
         from .image_processing import decode_data_uri, resize_for_model
         from .tokenizer import build_chat_ids
-        model_id = model or self.default_model
-        if not model_id:
-            raise ValueError("no model given")
-        lm = get_model(model_id, self.device)
-        cfg, eng, tok = lm.cfg, lm.engine, lm.tokenizer
+        cfg = lm.cfg
         frames = []
         for m in messages:
             content = m.get("content")
@@ -159,16 +156,36 @@ class LocalVLMClient:
                         frames.append(resize_for_model(decode_data_uri(url), cfg.patch, cfg.merge, cfg.min_pixels,
                                                        cfg.max_pixels))
         counts = [(f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2 for f in frames]
-        ids = build_chat_ids(tok, messages, counts)
+        return build_chat_ids(lm.tokenizer, messages, counts), frames
+
+    def _complete(self, model, messages, temperature, max_tokens, **kwargs) -> ChatCompletion:
+        return self.complete_many(model, [messages], temperature, max_tokens)[0]
+
+    def complete_many(self, model, batch_of_messages, temperature=None, max_tokens=None) -> List[ChatCompletion]:
+        """Several independent requests in one go: per-request prefill, then ONE shared decode loop in which every
+        weight is streamed once per step for all of them (engine.generate_batch).  Groups larger than the
+        engine's max_batch are processed in consecutive chunks.  Extension of the reference's call shape used by
+        the batch path; ``chat.completions.create`` is the single-request form of it."""
+        import torch
+        model_id = model or self.default_model
+        if not model_id:
+            raise ValueError("no model given")
+        lm = get_model(model_id, self.device)
+        eng, tok = lm.engine, lm.tokenizer
         max_new = int(max_tokens) if max_tokens else 512
         temp = float(temperature) if temperature else 0.0
+        out: List[ChatCompletion] = []
+        prepared = [self._prepare(lm, m) for m in batch_of_messages]
         with eng.lock:
-            dev_frames = [torch.from_numpy(f).to(eng.device) for f in frames]
-            out = eng.generate(ids, dev_frames, max_new_tokens=max_new, temperature=temp, seed=self.seed)
-        text = tok.decode(out)
-        return ChatCompletion([_Choice(_Message(text))], model=model_id,
-                              usage={"prompt_tokens": len(ids), "completion_tokens": len(out),
-                                     "total_tokens": len(ids) + len(out)})
+            for i in range(0, len(prepared), eng.max_batch):
+                chunk = prepared[i:i + eng.max_batch]
+                reqs = [(ids, [torch.from_numpy(f).to(eng.device) for f in frames]) for ids, frames in chunk]
+                toks = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed)
+                for (ids, _), t in zip(chunk, toks):
+                    out.append(ChatCompletion([_Choice(_Message(tok.decode(t)))], model=model_id,
+                                              usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
+                                                     "total_tokens": len(ids) + len(t)}))
+        return out
 
 
 class CannedResponseClient:
