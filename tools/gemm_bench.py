@@ -20,4 +20,8 @@ for _ in range(reps):
 e.record()
 torch.cuda.synchronize()
 t = s.elapsed_time(e) / reps * 1e-3
+ref = a.float() @ w.float().t()
+err = (out.float() - ref).abs().max().item()
+print(f"max abs err vs fp32 matmul: {err:.4f} (ref max {ref.abs().max().item():.2f})")
+assert err < 0.06 * max(1.0, ref.abs().max().item()), "GEMM mismatch"
 print(f"gemm {M}x{N}x{K} tile={os.environ.get('VIS_GEMM_TILE','auto')}: {t*1e3:.3f} ms {2.0*M*N*K/t/1e12:.1f} TFLOP/s")

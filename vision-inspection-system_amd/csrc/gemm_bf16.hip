@@ -348,6 +348,161 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x128_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// 256x256x64 tile, 512 threads = 8 waves (2 x 4), each wave a 128x64 output block (8 x 4 MFMA tiles, 128
+// accumulator VGPRs), ONE workgroup per CU, two 64 KiB LDS buffers.  Compared with 64x64 per wave this reads
+// 25 % fewer fragment bytes from LDS per MFMA and stages half the LDS-DMA bytes per FLOP.
+// Per K-step t (fragments double-buffered in registers, one barrier per K-step placed between the two halves):
+//   A:   ds_read F1 = frags(t, k-half 1)   || 32 MFMA on F0 = frags(t, k-half 0)
+//   mid: s_waitcnt lgkmcnt(0)  - every read of buffer t%2 has landed in registers
+//        s_waitcnt vmcnt(0)    - stage t+1 (issued one K-step ago) has landed
+//        s_barrier             - ... for every wave; buffer t%2 is now dead
+//        issue stage t+2 -> buffer t%2   (has phase B(t) + phase A(t+1) to land)
+//        ds_read F0 = frags(t+1, k-half 0) from buffer (t+1)%2
+//   B:   32 MFMA on F1
+#define GEMM4_B 256
+#define GEMM4_STAGE_BYTES (2 * GEMM4_B * GEMM_BK * 2)  // 65536
+#define GEMM4_LDS_BYTES (2 * GEMM4_STAGE_BYTES)        // 131072
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds4[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * GEMM4_B, n0 = tn * GEMM4_B;
+
+  uint32_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 512 + tid;
+    const int row = c >> 3;
+    const int ch = (c & 7) ^ (row & 7);
+    a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
+    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+  }
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
+  constexpr int A_BYTES = GEMM4_B * GEMM_BK * 2;  // 32 KiB
+
+  // K tile kt -> LDS buffer buf.  kt is clamped by the caller, so the call is unconditional (no branch to
+  // split the scheduling region); a redundant trailing stage lands in a dead buffer.
+  auto stage = [&](int buf, int kt) {
+    char* base = lds4 + buf * GEMM4_STAGE_BYTES + wave_base;
+    const char* a_k = a_base + kt * (GEMM_BK * 2);
+    const char* w_k = w_base + kt * (GEMM_BK * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_k + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_k + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8192), 16, 0,
+                                       0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = lane & 7;
+  const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
+  const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
+  const int a_rd = wm * 128 * 128;            // + i * 2048
+  const int w_rd = A_BYTES + wn * 64 * 128;   // + j * 2048
+
+  bf16x8 af0[8], wf0[4], af1[8], wf1[4];
+  auto read_frags = [&](bf16x8 (&af)[8], bf16x8 (&wf)[4], const char* base, int rd) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd);
+  };
+  auto mfma32 = [&](bf16x8 (&wf)[4], bf16x8 (&af)[8], int skip_first) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if ((i | j) >= skip_first)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  };
+
+  const int nk = p.K / GEMM_BK;
+  stage(0, 0);
+  stage(1, min(1, nk - 1));
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(af0, wf0, lds4, rd0);
+  int buf = 0;
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    const char* base = lds4 + buf * GEMM4_STAGE_BYTES;
+    // phase A: first MFMA (the conservative lgkmcnt(0) before the first use of the back-edge-carried F0 must
+    // not wait for F1), then F1 reads interleaved one per MFMA
+    __builtin_amdgcn_s_setprio(1);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf0[0], af0[0], acc[0][0], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    read_frags(af1, wf1, base, rd1);
+    mfma32(wf0, af0, 1);
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 19, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    // mid
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    stage(buf, min(kt + 2, nk - 1));
+    read_frags(af0, wf0, lds4 + (buf ^ 1) * GEMM4_STAGE_BYTES, rd0);
+    // phase B: MFMAs on F1 start at once; the stage issue and the F0 reads ride between them
+    mfma32(wf1, af1, 0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // one VMEM (LDS-DMA)
+    }
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    buf ^= 1;
+  }
+  {  // last K-step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // also drains the redundant trailing stages
+    const char* base = lds4 + buf * GEMM4_STAGE_BYTES;
+    read_frags(af1, wf1, base, rd1);
+    mfma32(wf0, af0, 0);
+    mfma32(wf1, af1, 0);
+  }
+
+  // epilogue: two 64-row halves through the shared 4x4 epilogue
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+    f32x4 sub[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sub[i][j] = acc[hm * 4 + i][j];
+    gemm_epilogue(p, sub, m0 + wm * 128 + hm * 64, n0 + wn * 64, l15, h);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // 32x128x64 tile for the batched decode step (M = in-flight sequences <= 16, padded to one 32-row tile):
 // the weight panel is streamed in FULL cache lines by LDS-DMA exactly like the big tiles (a lane-per-row
 // "fragment shaped" global load is texture-addresser bound at ~2.5 TB/s), four waves split the 128 columns,
@@ -485,6 +640,64 @@ extern "C" int vis_gemm_decode_ksplit(int N, int K) {
   return ks < 1 ? 1 : ks;
 }
 
+// Tile choice, measured on MI355X (tools/gemm_bench.py, tools/kbench.py).  VIS_GEMM_TILE=1|2|4 forces a shape.
+//  * 256x256 (1 WG/CU): best per-tile rate; used when its last round of 256 CUs is at least half full, and for
+//    wide problems (>= 3 rounds) with the ragged remainder columns handed to a second launch (LLM gate/up:
+//    9 x 148 tiles = 5.2 rounds -> 142 columns here + 6 columns below, instead of 6 rounds);
+//  * 256x128 3-stage (1 WG/CU): long-K problems whose grid is one full round (LLM o/down: 9 x 28 = 252 tiles);
+//  * 128x128 (2 WG/CU): everything else.
+static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
+  static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const int M = p.M, N = p.N, K = p.K;
+  const int tn1 = (N + GEMM_BN - 1) / GEMM_BN;
+  const int t2 = ((M + GEMM2_BM - 1) / GEMM2_BM) * tn1;
+  const int tm4 = (M + GEMM4_B - 1) / GEMM4_B, tn4 = (N + GEMM4_B - 1) / GEMM4_B;
+  const int t4 = tm4 * tn4, last = t4 % 256;
+  const bool big = forced ? (forced == 2) : (K >= 2048 && t2 >= 200 && t2 <= 256);
+  bool huge = forced ? (forced == 4) : (!big && K >= 1024 && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128));
+  int cols4 = tn4;  // 256-wide tile columns given to the 256x256 kernel
+  if (!forced && !big && !huge && K >= 1024 && M >= 1024 && t4 >= 768) {
+    cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only
+    huge = cols4 > 0;
+  }
+  if (huge) {
+    static const bool attr4_ok = [] {
+      return hipFuncSetAttribute((const void*)gemm_bf16_256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM4_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr4_ok) return VIS_ERR_LAUNCH;
+    GemmArgs q = p;
+    if (cols4 < tn4) q.N = cols4 * GEMM4_B;
+    q.tiles_m = tm4;
+    q.tiles_n = cols4;
+    hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, q);
+    if (cols4 == tn4) return VIS_OK;
+    // remainder columns [n_off, N): same problem, shifted operands
+    const int n_off = cols4 * GEMM4_B;
+    const int c_off = (p.act == ACT_SWIGLU) ? n_off / 2 : n_off;
+    p.W += (size_t)n_off * p.ldw;
+    if (p.bias) p.bias += n_off;
+    if (p.R) p.R += c_off;
+    p.C += c_off;
+    p.N = N - n_off;
+    return gemm_dispatch(p, stream);
+  }
+  p.tiles_n = tn1;
+  if (big) {
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute((const void*)gemm_bf16_256x128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM2_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr_ok) return VIS_ERR_LAUNCH;
+    p.tiles_m = (M + GEMM2_BM - 1) / GEMM2_BM;
+    hipLaunchKernelGGL(gemm_bf16_256x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM2_LDS_BYTES, stream, p);
+  } else {
+    p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
+    hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
+  }
+  return VIS_OK;
+}
+
 // C-ABI launcher (declared in include/vis_hip.h)
 extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, const void* R, void* C,
                              int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
@@ -506,25 +719,7 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act;
   p.part = nullptr; p.ksplit = 1; p.out_f32 = 0;
-  // tile choice: the 3-stage 256x128 kernel wins on large problems; VIS_GEMM_TILE=1|2 forces a shape (A/B runs)
-  static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
-  // measured on MI355X (tools/kbench.py): the 256x128 kernel wins when its grid is one full round of the 256 CUs
-  // and K is long (LLM o/down projections: 9 x 28 = 252 tiles); the 128x128 kernel (2 WG/CU) wins elsewhere
-  const int t2 = ((M + GEMM2_BM - 1) / GEMM2_BM) * ((N + GEMM_BN - 1) / GEMM_BN);
-  const bool big = forced ? (forced == 2) : (K >= 2048 && t2 >= 200 && t2 <= 256);
-  p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
   vis_clear_error();
-  if (big) {
-    static const bool attr_ok = [] {
-      return hipFuncSetAttribute((const void*)gemm_bf16_256x128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 GEMM2_LDS_BYTES) == hipSuccess;
-    }();
-    if (!attr_ok) return VIS_ERR_LAUNCH;
-    p.tiles_m = (M + GEMM2_BM - 1) / GEMM2_BM;
-    hipLaunchKernelGGL(gemm_bf16_256x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM2_LDS_BYTES, stream, p);
-  } else {
-    p.tiles_m = (M + GEMM_BM - 1) / GEMM_BM;
-    hipLaunchKernelGGL(gemm_bf16_128x128_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, stream, p);
-  }
-  return vis_check_launch();
+  const int st = gemm_dispatch(p, stream);
+  return st != VIS_OK ? st : vis_check_launch();
 }
