@@ -101,9 +101,11 @@ int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* 
  * step_ptr[b]; ws_val / ws_idx need 256 entries per sequence. */
 
 /* K10 (batched decode), first half.  For up to 16 in-flight sequences the weight matrix is streamed from HBM
- * ONCE per step: partial[ks][16][N] (f32) = x[B,K] * W[N,K]^T over K-slice ks of `ksplit` (32x128x64 MFMA tile,
- * LDS-DMA staging in full cache lines, split-K over grid.y for occupancy).  part == NULL: ksplit = 1 and C is
- * written directly (bf16, or f32 logits when out_f32).  vis_gemm_decode_ksplit suggests a split factor. */
+ * ONCE per step by <= 256 persistent workgroups (one per CU, 7-stage LDS-DMA ring, stream-K cut of the
+ * (128-column tile, K-step) sequence).  part[slot][16][N] (f32): `ksplit` slots, ALL written (unused ones
+ * zero-filled), sum over slots = x[B,K] * W[N,K]^T; the slot order is fixed by (N, K) alone, so results are
+ * bitwise reproducible.  ksplit <= 0 means vis_gemm_decode_ksplit(N, K) = the slots the geometry needs (<= 16);
+ * a smaller value is an argument error.  part == NULL: C is written directly (bf16, or f32 logits when out_f32). */
 int vis_gemm_decode_ksplit(int N, int K);
 int vis_gemm_decode_bf16(const void* x, const void* W, void* part, void* C, int B, int N, int K, int ldx, int ldw,
                          int ldc, int ksplit, int out_f32, vis_stream_t stream);

@@ -392,6 +392,11 @@ def test_decode_gemm_split_and_finalize(hip, device, B, N, K):
     hip.decode_gemm(x, w, part=part, ksplit=ks)
     hip.skinny_finalize(part, ks, y2, N, bias=b, residual=r)
     assert torch.equal(y, y2)            # fixed summation order: bitwise reproducible
+    if ks < 16:                          # extra slots are zero-filled, not left as garbage
+        part.fill_(float("nan"))
+        hip.decode_gemm(x, w, part=part, ksplit=ks + 1)
+        hip.skinny_finalize(part, ks + 1, y2, N, bias=b, residual=r)
+        assert torch.equal(y, y2)
 
 
 def test_decode_gemm_swiglu_and_direct_logits(hip, device):

@@ -503,141 +503,247 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------
-// 32x128x64 tile for the batched decode step (M = in-flight sequences <= 16, padded to one 32-row tile):
-// the weight panel is streamed in FULL cache lines by LDS-DMA exactly like the big tiles (a lane-per-row
-// "fragment shaped" global load is texture-addresser bound at ~2.5 TB/s), four waves split the 128 columns,
-// K is split over grid.y so that even N = 3584 launches hundreds of workgroups; partial sums go to
-// part[ks][16][N] (f32) and vis_skinny_finalize applies the epilogue.  ksplit == 1 writes C directly
-// (bf16 via gemm_epilogue, or f32 logits).
+// Batched decode projection (M = in-flight sequences <= 16): a pure weight-streaming problem, so the kernel is
+// built around BYTES IN FLIGHT, not around the MFMA.
+//  * The (128-column tile, 64-wide K-step) pairs of the whole projection form ONE sequence of
+//    T = tiles x K/64 steps, cut into <= 256 equal contiguous ranges - one persistent workgroup per CU
+//    (LDS-limited on purpose), each streaming ~T/256 x 16 KiB of W without a gap at tile seams ("stream-K").
+//  * A ring of 7 stages (7 x (16 KiB of W + 4 KiB of x)) is filled by LDS-DMA in full 128-B lines (a
+//    lane-per-row "fragment shaped" global load is texture-addresser bound at ~2.5 TB/s); up to 6 x 16 KiB of
+//    weights are outstanding per CU, i.e. ~4 us of latency tolerance at the chip's 6 TB/s.  Earlier versions
+//    (one stage in flight per workgroup; then a ring per (tile, K-slice) workgroup whose fill/drain bubble
+//    was paid once per short slice) streamed at 2.3 - 2.9 TB/s.
+//  * Per step: counted s_waitcnt vmcnt (the oldest stage has landed, 5 younger ones stay in flight; stores
+//    of a flush can only make the wait conservative because loads retire in order), ONE s_barrier, refill
+//    of the slot consumed one step ago, 6 ds_read_b128 + 4 MFMAs per wave.
+//  * A workgroup that leaves a tile writes its f32 partial to part[seg][16][N], seg = its rank among the
+//    workgroups touching that tile (<= nslots, fixed by the geometry: results are bitwise reproducible);
+//    the one that finishes the tile zero-fills the unused slots, so vis_skinny_finalize sums a fixed
+//    number of slots.  With part == NULL ranges are whole tiles and C is written directly (bf16 or f32 logits).
 #define GEMM3_BM 32
 #define GEMM3_STAGE_BYTES ((GEMM3_BM + GEMM_BN) * GEMM_BK * 2)  // 20480
+#define GEMM3_DEPTH 7
+#define GEMM3_LDS_BYTES (GEMM3_DEPTH * GEMM3_STAGE_BYTES)      // 143360
+#define GEMM3_PER 5                                             // LDS-DMA instructions per thread per stage
+#define GEMM3_MAX_WG 256                                        // one per CU
+#define GEMM3_MAX_SLOTS 16
 
-__global__ __launch_bounds__(256, 2) void gemm_bf16_32x128_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) char lds3[2 * GEMM3_STAGE_BYTES];
+struct DecGemmArgs {
+  const bf16_t* A;  // [M][lda]
+  const bf16_t* W;  // [N][ldw]
+  float* part;      // [nslots][16][N] or null
+  void* C;          // direct output (part == null)
+  int M, N, lda, ldw, ldc;
+  int nk_all, total, spb, nslots, out_f32;
+};
+
+__device__ __forceinline__ void gemm3_wait_stages(int younger) {
+  // wait until all but `younger` (0..DEPTH-2) most recent stages of this wave have landed
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(25)" ::: "memory"); break;
+  }
+}
+static_assert(GEMM3_DEPTH == 7 && GEMM3_PER == 5, "gemm3_wait_stages encodes (DEPTH-2) x PER");
+
+__global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds3[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wn = tid >> 6;  // wave = 32-column slice
   const int l15 = lane & 15, h = lane >> 4;
-  const int n0 = blockIdx.x * GEMM_BN;
-  const int nk_all = p.K / GEMM_BK;
-  const int kt0 = (int)((long long)nk_all * blockIdx.y / p.ksplit);
-  const int kt1 = (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit);
-  const int nk = kt1 - kt0;
+  const int s0 = blockIdx.x * p.spb;
+  const int nsteps = min(s0 + p.spb, p.total) - s0;
+  if (nsteps <= 0) return;  // whole workgroup
 
-  // staging: A tile 32 rows x 8 chunks = 256 chunks (1 per thread), W tile 128 x 8 = 1024 chunks (4 per thread)
+  // staging slots: x tile 32 rows x 8 chunks (1 per thread; rows >= M repeat row M-1), W tile 128 x 8 (4 per thread)
   uint32_t a_off, w_off[4];
   {
     const int row = tid >> 3, ch = (tid & 7) ^ (row & 7);
     a_off = (uint32_t)min(row, p.M - 1) * (uint32_t)(p.lda * 2) + ch * 16;
   }
+  int p_tile = s0 / p.nk_all, p_kt = s0 - p_tile * p.nk_all;  // producer cursor
+  const char* a_ptr;
+  const char* w_ptr;
+  auto enter_tile = [&](int tile, int kt) {
+    const int n0 = tile * GEMM_BN;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = i * 256 + tid;
-    const int row = c >> 3, ch = (c & 7) ^ (row & 7);
-    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
-  }
-  const char* a_base = (const char*)p.A + (size_t)kt0 * GEMM_BK * 2;
-  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt0 * GEMM_BK * 2;
+    for (int i = 0; i < 4; ++i) {
+      const int c = i * 256 + tid;
+      const int row = c >> 3, ch = (c & 7) ^ (row & 7);
+      w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+    }
+    a_ptr = (const char*)p.A + (size_t)kt * GEMM_BK * 2;
+    w_ptr = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt * GEMM_BK * 2;
+  };
+  enter_tile(p_tile, p_kt);
   const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
   constexpr int A_BYTES = GEMM3_BM * GEMM_BK * 2;  // 4 KiB
 
-  auto stage = [&](int buf) {
-    char* base = lds3 + buf * GEMM3_STAGE_BYTES + wave_base;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off),
+  auto stage = [&](int slot) {  // next step of this workgroup's range -> ring slot
+    char* base = lds3 + slot * GEMM3_STAGE_BYTES + wave_base;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr + a_off),
                                      (__attribute__((address_space(3))) void*)(base), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_off[i]),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr + w_off[i]),
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096), 16, 0, 0);
-    a_base += GEMM_BK * 2;
-    w_base += GEMM_BK * 2;
+    a_ptr += GEMM_BK * 2;
+    w_ptr += GEMM_BK * 2;
+    if (++p_kt == p.nk_all) {
+      p_kt = 0;
+      ++p_tile;
+      enter_tile(p_tile, 0);  // never dereferenced past the last tile: the caller stops issuing at nsteps
+    }
   };
 
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[2];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int sw = lane & 7;
   const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
   const int w_rd = A_BYTES + wn * 32 * 128;
 
-  if (nk > 0) stage(0);
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) stage(cur ^ 1);
-    const char* base = lds3 + cur * GEMM3_STAGE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int rd = ks ? rd1 : rd0;
-      bf16x8 af[2], wf[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(base + i * 2048 + rd);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+  int c_tile = s0 / p.nk_all, c_kt = s0 - c_tile * p.nk_all;  // consumer cursor
+  const int pre = min(GEMM3_DEPTH - 1, nsteps);
+  for (int s = 0; s < pre; ++s) stage(s);
+  int slot = 0, fill = pre % GEMM3_DEPTH;  // slot consumed this step / slot refilled this step
+  for (int st = 0; st < nsteps; ++st) {
+    gemm3_wait_stages(min(GEMM3_DEPTH - 2, nsteps - 1 - st));
+    __builtin_amdgcn_s_barrier();  // stage st visible to all waves; every wave is past compute(st-1)
+    if (st + GEMM3_DEPTH - 1 < nsteps) {
+      stage(fill);
+      fill = (fill + 1 == GEMM3_DEPTH) ? 0 : fill + 1;
     }
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // lane holds D[n = n0 + 32 wn + 16 j + 4 h + r][m = 16 i + l15]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = i * 16 + l15;
-    if (m >= p.M) continue;
+    const char* base = lds3 + slot * GEMM3_STAGE_BYTES;
+    const bf16x8 a0 = *(const bf16x8*)(base + rd0);
+    const bf16x8 a1 = *(const bf16x8*)(base + rd1);
+    bf16x8 wf[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 32 + j * 16 + 4 * h;
-      if (n >= p.N) continue;
-      if (p.part) {
-        *(f32x4*)(p.part + ((size_t)blockIdx.y * 16 + m) * p.N + n) = acc[i][j];
-      } else if (p.out_f32) {
-        *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = acc[i][j];
-      } else {
-        u32x2 o;
-        o[0] = pack2bf(acc[i][j][0], acc[i][j][1]);
-        o[1] = pack2bf(acc[i][j][2], acc[i][j][3]);
-        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+      wf[j][0] = *(const bf16x8*)(base + w_rd + j * 2048 + rd0);
+      wf[j][1] = *(const bf16x8*)(base + w_rd + j * 2048 + rd1);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], a0, acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], a1, acc[j], 0, 0, 0);
+    }
+    slot = (slot + 1 == GEMM3_DEPTH) ? 0 : slot + 1;
+
+    const bool tile_done = (++c_kt == p.nk_all);
+    if (tile_done || st + 1 == nsteps) {
+      // flush: lane holds D[n = n0 + 32 wn + 16 j + 4 h + r][m = l15]
+      const int m = l15;
+      const int nb = c_tile * GEMM_BN + wn * 32 + 4 * h;
+      if (m < p.M) {
+        if (p.part) {
+          const int seg = blockIdx.x - (c_tile * p.nk_all) / p.spb;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = nb + j * 16;
+            if (n >= p.N) continue;
+            *(f32x4*)(p.part + ((size_t)seg * 16 + m) * p.N + n) = acc[j];
+            if (tile_done)
+              for (int z = seg + 1; z < p.nslots; ++z)
+                *(f32x4*)(p.part + ((size_t)z * 16 + m) * p.N + n) = (f32x4){0.f, 0.f, 0.f, 0.f};
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int n = nb + j * 16;
+            if (n >= p.N) continue;
+            if (p.out_f32) {
+              *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = acc[j];
+            } else {
+              u32x2 o;
+              o[0] = pack2bf(acc[j][0], acc[j][1]);
+              o[1] = pack2bf(acc[j][2], acc[j][3]);
+              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            }
+          }
+        }
       }
+      acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (tile_done) { c_kt = 0; ++c_tile; }
     }
   }
 }
 
-// Batched-decode projection, first half: partial[ks][16][N] = x[B,K] * W[N,K]^T over K-slice ks (f32), or with
-// part == NULL a direct C (bf16, or f32 when out_f32).  B <= 16.  ksplit <= 0 picks one automatically.
+// geometry of the stream-K cut for (N, K): steps per workgroup and the number of partial slots a tile can need
+static void gemm3_geometry(int N, int K, bool direct, int* spb, int* nslots, int* nwg) {
+  const int tiles = (N + GEMM_BN - 1) / GEMM_BN, nk = K / GEMM_BK;
+  const long total = (long)tiles * nk;
+  int wg = GEMM3_MAX_WG;
+  for (;;) {
+    long per;
+    if (direct) {
+      const long tpw = (tiles + wg - 1) / wg;  // whole tiles per workgroup
+      per = tpw * nk;
+    } else {
+      per = (total + wg - 1) / wg;
+      if (per < 4) per = total < 4 ? total : 4;  // never cut finer than 4 K-steps
+    }
+    int slots = 1;
+    if (!direct)
+      for (int t = 0; t < tiles; ++t) {
+        const int s = (int)(((long)(t + 1) * nk - 1) / per - ((long)t * nk) / per) + 1;
+        if (s > slots) slots = s;
+      }
+    if (slots <= GEMM3_MAX_SLOTS || wg == 1) {
+      *spb = (int)per;
+      *nslots = slots;
+      *nwg = (int)((total + per - 1) / per);
+      return;
+    }
+    wg = wg / 2;  // fewer, longer ranges -> fewer segments per tile
+  }
+}
+
+// Batched-decode projection, first half: part[slot][16][N] (f32, `ksplit` slots, all written) with
+// sum_slot part = x[B,K] * W[N,K]^T, or with part == NULL a direct C (bf16, or f32 when out_f32).  B <= 16.
+// ksplit <= 0 means vis_gemm_decode_ksplit(N, K); a larger value only adds zero-filled slots.
 extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, void* C, int B, int N, int K, int lda,
                                     int ldw, int ldc, int ksplit, int out_f32, hipStream_t stream) {
   if (!A || !W || (!part && !C) || B <= 0 || B > 16 || N <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % GEMM_BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || (C && ldc % 4 != 0)) return VIS_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)part | (uintptr_t)C) & 15) return VIS_ERR_ARG;
-  const int nkt = K / GEMM_BK;
-  if (!part) ksplit = 1;
-  if (ksplit <= 0 || ksplit > 16 || ksplit > nkt) return VIS_ERR_ARG;
-  GemmArgs p;
-  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = nullptr; p.R = nullptr; p.C = (bf16_t*)C;
-  p.M = B; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.act = ACT_NONE;
-  p.tiles_m = 1; p.tiles_n = (N + GEMM_BN - 1) / GEMM_BN;
-  p.part = (float*)part; p.ksplit = ksplit; p.out_f32 = out_f32;
+  int spb, need, nwg;
+  gemm3_geometry(N, K, part == nullptr, &spb, &need, &nwg);
+  if (part) {
+    if (ksplit <= 0) ksplit = need;
+    if (ksplit < need || ksplit > GEMM3_MAX_SLOTS) return VIS_ERR_ARG;
+  } else {
+    ksplit = 1;
+  }
+  static const bool attr3_ok = [] {
+    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM3_LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr3_ok) return VIS_ERR_LAUNCH;
+  DecGemmArgs p;
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.part = (float*)part; p.C = C;
+  p.M = B; p.N = N; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+  p.nk_all = K / GEMM_BK;
+  p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
+  p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_bf16_32x128_kernel, dim3(p.tiles_n, ksplit), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(gemm_decode_stream_kernel, dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   return vis_check_launch();
 }
 
-// split factor giving >= ~768 workgroups (3 per CU) without K-slices shorter than 4 K-steps
+// number of partial slots vis_gemm_decode_bf16 writes for (N, K): size part as slots x 16 x N floats
 extern "C" int vis_gemm_decode_ksplit(int N, int K) {
   if (N <= 0 || K < GEMM_BK) return 0;
-  const int tiles = (N + GEMM_BN - 1) / GEMM_BN, nkt = K / GEMM_BK;
-  int ks = (768 + tiles - 1) / tiles;
-  if (ks > nkt / 4) ks = nkt / 4;
-  if (ks > 16) ks = 16;
-  return ks < 1 ? 1 : ks;
+  int spb, slots, nwg;
+  gemm3_geometry(N, K, false, &spb, &slots, &nwg);
+  return slots;
 }
 
 // Tile choice, measured on MI355X (tools/gemm_bench.py, tools/kbench.py).  VIS_GEMM_TILE=1|2|4 forces a shape.

@@ -274,8 +274,9 @@ def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tok
 
 def decode_gemm(x: torch.Tensor, w: torch.Tensor, part: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, ksplit: int = 0) -> int:
-    """Batched-decode projection, first half: f32 partials part[ks][16][N] = x[B,K] @ w[N,K].T per K-slice
-    (returns the split factor used), or - with ``out`` instead of ``part`` - a direct bf16 / f32 result."""
+    """Batched-decode projection, first half: f32 partials part[slot][16][N] whose sum over the returned number
+    of slots is x[B,K] @ w[N,K].T (every slot is written), or - with ``out`` instead of ``part`` - a direct
+    bf16 / f32 result."""
     _bf16(x, "decode_gemm x"); _bf16(w, "decode_gemm w")
     B, K = x.shape
     N = w.shape[0]
