@@ -202,7 +202,7 @@ def test_attn_prefill(hip, device, S, Hq, Hkv, HD, causal, segments):
     vt = torch.zeros((Hkv, HD, ld), dtype=torch.bfloat16, device=device)
     vt[:, :, :S] = v.permute(0, 2, 1)
     out = torch.zeros((S, Hq * HD), dtype=torch.bfloat16, device=device)
-    work = hip.make_attn_work(segments, causal, device)
+    work = hip.make_attn_work(segments, causal, device, heads=Hq)
     scale = HD ** -0.5
     hip.attn_prefill(q, k, vt, out, work, causal, scale)
     if S > 1024:  # reference on two heads (each with its own kv head) to keep CPU time down

@@ -7,6 +7,7 @@ from vision_inspection_system_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument("--which", default="vit")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--plan", type=int, default=1, help="0: plain 128-row items; 1: planner (full + half items)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 hip.load()
@@ -16,7 +17,8 @@ k = torch.randn((Hkv, S, HD), device=dev).to(torch.bfloat16)
 ld = (S + 63) // 64 * 64
 vt = torch.randn((Hkv, HD, ld), device=dev).to(torch.bfloat16)
 o = torch.empty((S, Hq * HD), dtype=torch.bfloat16, device=dev)
-work = hip.make_attn_work([(0, S)], causal, dev)
+work = hip.make_attn_work([(0, S)], causal, dev, heads=Hq if a.plan else 0)
+print('items', work.shape[0], 'half', int((work[:, 1] <= 64).sum()))
 for _ in range(2):
     hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
 torch.cuda.synchronize()

@@ -5,14 +5,20 @@
 //  * the LLM: causal GQA prefill, head_dim 128 (TF:...:508-556, :318-340).
 //
 // Work decomposition: the host passes a work list of {q0, qn<=128, k0, k1}
-// tiles (one workgroup each, x heads on grid.y): query rows [q0,q0+qn) attend
-// keys [k0,k1) (and key <= query when causal).  A work item never straddles a
-// segment, so cu_seqlens, windows and plain causal prefill are all the same
-// kernel.
+// tiles (one workgroup each; heads on grid.x, items on grid.y): query rows
+// [q0,q0+qn) attend keys [k0,k1) (and key <= query when causal).  A work item
+// never straddles a segment, so cu_seqlens, windows and plain causal prefill are
+// all the same kernel.  Workgroups are dispatched heads-fastest, i.e. in work-list
+// order: the host lists full 128-row items first and may cut the remainder into
+// cheaper 64-row items that fill the last, partial round of the 512 workgroup
+// slots (ViT, 4900 patches x 16 heads: 624 full items = 2 rounds at 61 %; 512 full
+// + 208 half items = ~1.55 rounds).  With 16 heads and round-robin XCD dispatch an
+// XCD only ever sees two heads' K/V, which fit its L2.
 //
-// Per workgroup: 256 threads = 4 waves, each wave owns 32 query rows (two
-// 16-row blocks) and walks KV tiles of 64 keys that the whole workgroup stages
-// through LDS (double-buffered, register staged, one barrier per tile).
+// Per workgroup: 256 threads = 4 waves; a wave owns 32 query rows (two 16-row
+// blocks) of a 65..128-row item, or 16 rows (one block) of a <= 64-row item, and
+// walks KV tiles of 64 keys that the whole workgroup stages through LDS
+// (double-buffered, register staged, one barrier per tile).
 //
 // MFMA formulation (v_mfma_f32_16x16x32_bf16, f32 accumulate, f32 softmax):
 //  * scores are computed TRANSPOSED,  S^T[key][q] = K * Q^T  (A = K rows from
@@ -33,6 +39,7 @@
 // Output O[s][head*HD + d] is staged through LDS and written as whole 16-B
 // chunks so the following projection GEMM reads a plain row-major matrix.
 #include "common.hip.h"
+#include <type_traits>
 
 struct AttnArgs {
   const bf16_t* Q;   // [Hq][Sq][HD]
@@ -63,13 +70,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
-  const int head = blockIdx.y, hkv = head / p.group;
-  const int4 wk = p.work[blockIdx.x];
+  const int head = blockIdx.x, hkv = head / p.group;
+  const int4 wk = p.work[blockIdx.y];
   const int q0 = wk.x, qn = wk.y, k0 = wk.z;
   const int k1 = CAUSAL ? min(wk.w, q0 + qn) : wk.w;
   const int kt_begin = k0 & ~63;
   const int nt = (k1 - kt_begin + 63) >> 6;
-  const int wq0 = q0 + wave * 32;  // first query row of this wave
+  // 16-row query blocks per wave (workgroup-uniform); the one-block form exists for head_dim 80 only (the
+  // head_dim 128 kernel is at the register limit, and its causal grid already fits one round)
+  const int nqb = (HD == 80 && qn <= 64) ? 1 : 2;
+  const int wrows = 16 * nqb;
+  const int wq0 = q0 + wave * wrows;        // first query row of this wave
 
   const bf16_t* Kh = p.K + (size_t)hkv * p.k_tokens * HD;
   const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
@@ -153,16 +164,17 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     const bool more = (t + 1 < nt);
     if (more) load_tile(kt + 64);
 
-    const bool active = !CAUSAL || (kt <= wq0 + 31);
-    if (active) {
+    const bool active = !CAUSAL || (kt <= wq0 + wrows - 1);
+    auto tile_body = [&](auto nq_tag) {
+      constexpr int NQ = decltype(nq_tag)::value;
       const char* kb = lds + cur * BUF;
       const char* vb = kb + K_BYTES;
       // ---- S^T = K * Q^T
-      f32x4 sacc[4][2];
+      f32x4 sacc[4][NQ];
 #pragma unroll
       for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb) sacc[kbk][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int qb = 0; qb < NQ; ++qb) sacc[kbk][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < DKS; ++ds) {
         bf16x8 kf[4];
@@ -176,32 +188,43 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb)
+          for (int qb = 0; qb < NQ; ++qb)
             sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], sacc[kbk][qb], 0, 0, 0);
       }
 
+      const bool need_mask = (kt < k0) || (kt + 64 > k1) || (CAUSAL && (kt + 63 > wq0));
       // ---- online softmax (query on the lane, keys in registers), log2 domain:
       //      p = exp2(s * scale_log2 - m), one FMA + one raw v_exp_f32 per score
-      const bool need_mask = (kt < k0) || (kt + 64 > k1) || (CAUSAL && (kt + 63 > wq0));
-      float alpha[2];
-      bf16x8 pf[2][2];
+      float alpha[NQ];
+      bf16x8 pf[2][NQ];
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < NQ; ++qb) {
         const int q = wq0 + qb * 16 + l15;
         if (need_mask) {
+          // element (kbk, r) is key kt + 4h + (16 kbk + r): valid iff lo <= 16 kbk + r < hi, with the
+          // compile-time constant on one side of each compare (no per-element index arithmetic)
+          const int kbase = kt + 4 * h;
+          int lo = k0 - kbase;
+          int hi = (CAUSAL ? min(k1, q + 1) : k1) - kbase;
+          // opaque to the optimiser, so the compares/selects stay inside this (uniform, rarely taken) branch
+          // instead of being speculated into every tile
+          asm volatile("" : "+v"(lo), "+v"(hi));
 #pragma unroll
           for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int key = kt + kbk * 16 + 4 * h + r;
-              const bool ok = (key >= k0) && (key < k1) && (!CAUSAL || key <= q);
+              const bool ok = (lo <= 16 * kbk + r) && (hi > 16 * kbk + r);
               sacc[kbk][qb][r] = ok ? sacc[kbk][qb][r] : ATT_NEG;
             }
         }
-        float mx = fmaxf(fmaxf(sacc[0][qb][0], sacc[0][qb][1]), fmaxf(sacc[0][qb][2], sacc[0][qb][3]));
-#pragma unroll
-        for (int kbk = 1; kbk < 4; ++kbk)
-          mx = fmaxf(fmaxf(mx, fmaxf(sacc[kbk][qb][0], sacc[kbk][qb][1])), fmaxf(sacc[kbk][qb][2], sacc[kbk][qb][3]));
+        float mx = fmaxf(fmaxf(sacc[0][qb][0], sacc[0][qb][1]), sacc[0][qb][2]);  // chains -> v_max3_f32
+        mx = fmaxf(fmaxf(mx, sacc[0][qb][3]), sacc[1][qb][0]);
+        mx = fmaxf(fmaxf(mx, sacc[1][qb][1]), sacc[1][qb][2]);
+        mx = fmaxf(fmaxf(mx, sacc[1][qb][3]), sacc[2][qb][0]);
+        mx = fmaxf(fmaxf(mx, sacc[2][qb][1]), sacc[2][qb][2]);
+        mx = fmaxf(fmaxf(mx, sacc[2][qb][3]), sacc[3][qb][0]);
+        mx = fmaxf(fmaxf(mx, sacc[3][qb][1]), sacc[3][qb][2]);
+        mx = fmaxf(mx, sacc[3][qb][3]);
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         // raw scores are masked with -1e30; scaled they stay a huge negative number
@@ -231,10 +254,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       }
 
       // ---- rescale O (rows 4h+r of each q-block) when any running max moved
-      const bool resc = !__all((alpha[0] == 1.0f) && (alpha[1] == 1.0f));
+      const bool resc = !__all((alpha[0] == 1.0f) && (alpha[NQ - 1] == 1.0f));
       if (resc) {
+        asm volatile("" : "+v"(alpha[0]));  // keep this a real (rarely taken) branch: no speculated multiplies
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < NQ; ++qb)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float a = __shfl(alpha[qb], 4 * h + r, 64);
@@ -255,10 +279,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
           const u32x4 vv = (u32x4){lo[0], lo[1], hi[0], hi[1]};
           const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
 #pragma unroll
-          for (int qb = 0; qb < 2; ++qb)
+          for (int qb = 0; qb < NQ; ++qb)
             oacc[qb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], vf, oacc[qb][nb], 0, 0, 0);
         }
       }
+    };
+    if (active) {
+      if (HD != 80 || nqb == 2) tile_body(std::integral_constant<int, 2>{});
+      else tile_body(std::integral_constant<int, 1>{});
     }
 
     if (more) store_tile(cur ^ 1);
@@ -270,6 +298,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   char* ost = lds + wave * 32 * OROW;
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
+    if (qb >= nqb) break;
     float l = lrow[qb];
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
@@ -284,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     }
   }
   __syncthreads();
-  for (int it = lane; it < 32 * KCH; it += 64) {
+  for (int it = lane; it < wrows * KCH; it += 64) {
     const int row = it / KCH, c = it - row * KCH;
     const int q = wq0 + row;
     if (q < q0 + qn) {
@@ -306,7 +335,8 @@ extern "C" int vis_attn_prefill(const void* Q, const void* K, const void* Vt, vo
   p.work = (const int4*)work;
   p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
   p.scale_log2 = scale * 1.4426950408889634f;
-  const dim3 grid(n_work, Hq), block(256);
+  if (n_work > 65535) return VIS_ERR_ARG;
+  const dim3 grid(Hq, n_work), block(256);
   vis_clear_error();
   if (HD == 128) {
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, stream, p);

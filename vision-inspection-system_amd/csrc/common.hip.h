@@ -26,8 +26,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return __builtin_bit_cast(bf16_t, b);
 }
 
+// one v_cvt_pk_bf16_f32 (RNE), lo in bits 0..15 (the scalar form costs two converts + shift + or)
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {

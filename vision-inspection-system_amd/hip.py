@@ -166,18 +166,63 @@ def qkv_rope_split(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, q: t
 
 
 # --------------------------------------------------------------------------- K6 / K7
-def make_attn_work(segments, causal: bool, device, block_q: int = 128) -> torch.Tensor:
+ATTN_SLOTS = 512          # resident attention workgroups on MI355X: 256 CUs x 2
+ATTN_HALF_COST = 0.6      # a 64-row item relative to a 128-row item (same K/V staging, half the MFMAs)
+
+
+def _attn_makespan(n_full: int, n_half: int, slots: int = ATTN_SLOTS) -> float:
+    """Greedy list schedule of n_full unit items followed by n_half cheaper ones on `slots` workgroup slots."""
+    import heapq
+    free = [0.0] * slots
+    for cost, n in ((1.0, n_full), (ATTN_HALF_COST, n_half)):
+        for _ in range(n):
+            heapq.heappush(free, heapq.heappop(free) + cost)
+    return max(free)
+
+
+def plan_attn_items(segments, heads: int, block_q: int = 128):
+    """Non-causal work items [(q0, qn, k0, k1)], full (<= block_q rows) items first, then 64-row halves.
+    Trailing full items are cut in two when that shortens the modelled schedule of items x heads workgroups
+    (the last, partial round of the 512 slots is filled with cheaper items)."""
+    full, half = [], []
+    for (s, e) in segments:
+        for q0 in range(s, e, block_q):
+            qn = min(block_q, e - q0)
+            (half if qn <= block_q // 2 else full).append((q0, qn, s, e))
+    if heads > 0 and len(full) * heads > ATTN_SLOTS:
+        keep = (len(full) * heads // ATTN_SLOTS) * ATTN_SLOTS // heads   # fulls that fill whole rounds
+        best = (_attn_makespan(len(full) * heads, len(half) * heads), len(full))
+        for k in (keep, keep - 1):
+            if 0 < k < len(full):
+                cut = len(full) - k
+                t = _attn_makespan(k * heads, (len(half) + 2 * cut) * heads)
+                if t < best[0] - 1e-9:
+                    best = (t, k)
+        k = best[1]
+        for (q0, qn, s, e) in full[k:]:
+            h1 = (qn + 1) // 2
+            h1 = min(block_q // 2, (h1 + 15) // 16 * 16)
+            half.append((q0, h1, s, e))
+            half.append((q0 + h1, qn - h1, s, e))
+        full = full[:k]
+    return full + half
+
+
+def make_attn_work(segments, causal: bool, device, block_q: int = 128, heads: int = 0) -> torch.Tensor:
     """Work list for attn_prefill: segments = [(start, end)] of independent token ranges.
 
     Each item {q0, qn, k0, k1}: queries [q0, q0+qn) attend keys [k0, k1) (and key <= query
-    when causal).  Heavy (late) causal tiles are listed first so they are dispatched first.
+    when causal).  Workgroups are dispatched in list order (heads fastest).  Causal: heavy (late) tiles
+    first.  Non-causal with ``heads`` given: see plan_attn_items.
     """
-    items = []
-    for (s, e) in segments:
-        for q0 in range(s, e, block_q):
-            items.append((q0, min(block_q, e - q0), s, e))
     if causal:
+        items = []
+        for (s, e) in segments:
+            for q0 in range(s, e, block_q):
+                items.append((q0, min(block_q, e - q0), s, e))
         items.sort(key=lambda it: -(it[0] + it[1]))
+    else:
+        items = plan_attn_items(segments, heads, block_q)
     return torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
 
 
