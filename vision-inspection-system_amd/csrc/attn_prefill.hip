@@ -144,13 +144,18 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     for (int i = 0; i < V_ITERS; ++i) *(u32x4*)(base + v_loff[i]) = vreg[i];
   };
 
-  f32x4 oacc[2][ND];
+  // oacc[qb][ND] is the softmax denominator: P is multiplied by one extra "V column" of ones (a register
+  // constant: B-operand lanes of column 0 hold 1.0), so the row sums come out of the MFMA pipe in the same
+  // layout and with the same rescaling as O instead of costing one VALU add per score.  The denominator
+  // therefore sums the bf16-rounded probabilities - exactly the weights P*V uses.
+  f32x4 oacc[2][ND + 1];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int nb = 0; nb < ND; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrow[2] = {ATT_NEG, ATT_NEG};
-  float lrow[2] = {0.f, 0.f};
+  const uint32_t one2 = (l15 == 0) ? 0x3f803f80u : 0u;
+  const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
 
   if (nt > 0) {
     load_tile(kt_begin);
@@ -225,13 +230,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
         mx = fmaxf(fmaxf(mx, sacc[2][qb][3]), sacc[3][qb][0]);
         mx = fmaxf(fmaxf(mx, sacc[3][qb][1]), sacc[3][qb][2]);
         mx = fmaxf(mx, sacc[3][qb][3]);
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = hmax4(mx);  // over the four 16-lane rows (keys 4h..4h+3): two permlane swaps, no LDS round trip
         // raw scores are masked with -1e30; scaled they stay a huge negative number
         const float mnew = fmaxf(mrow[qb], mx * p.scale_log2);
         alpha[qb] = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
         mrow[qb] = mnew;
-        float ls = 0.f;
         float pv[4][4];
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk)
@@ -239,9 +242,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
           for (int r = 0; r < 4; ++r) {
             const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
             pv[kbk][r] = e;
-            ls += e;
           }
-        lrow[qb] = lrow[qb] * alpha[qb] + ls;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u32x4 pk;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
           for (int r = 0; r < 4; ++r) {
             const float a = __shfl(alpha[qb], 4 * h + r, 64);
 #pragma unroll
-            for (int nb = 0; nb < ND; ++nb) oacc[qb][nb][r] *= a;
+            for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb][r] *= a;
           }
       }
 
@@ -283,6 +284,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
             oacc[qb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], vf, oacc[qb][nb], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb)
+          oacc[qb][ND] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], ones_frag, oacc[qb][ND], 0, 0, 0);
     };
     if (active) {
       if (HD != 80 || nqb == 2) tile_body(std::integral_constant<int, 2>{});
@@ -299,13 +305,10 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     if (qb >= nqb) break;
-    float l = lrow[qb];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = (l > 0.f) ? 1.0f / l : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float a = __shfl(inv, 4 * h + r, 64);
+      const float l = __shfl(oacc[qb][ND][r], 16 * h, 64);  // column 0 of the ones block: row 4h+r's sum
+      const float a = (l > 0.f) ? 1.0f / l : 0.f;
       const int row = qb * 16 + 4 * h + r;
 #pragma unroll
       for (int nb = 0; nb < ND; ++nb)

@@ -49,16 +49,37 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
+// Cross-row exchanges without the LDS crossbar: gfx950's v_permlane16_swap / v_permlane32_swap swap 16- / 32-lane
+// halves between two registers in one VALU op (a ds_bpermute round trip costs ~100+ cycles of latency).
+// With both operands a copy of x: swap16 -> {rows 0,0,2,2 | rows 1,1,3,3}, swap32 -> {low half twice | high half twice}.
+__device__ __forceinline__ float hsum4(float x) {  // sum over lanes l, l^16, l^32, l^48
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const uint32_t v = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+__device__ __forceinline__ float hmax4(float x) {  // max over lanes l, l^16, l^32, l^48
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t v = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return hsum4(v);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return hmax4(v);
 }
 
 // Bijective XCD-aware remap of a linear workgroup id: blocks that share

@@ -193,7 +193,7 @@ class Qwen2VLEngine:
         for c in counts:
             segs.append((s0, s0 + c))
             s0 += c
-        work = hip.make_attn_work(segs, False, dev, heads=vc.heads)
+        work = hip.make_attn_work(segs, False, dev, heads=Hh)
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
