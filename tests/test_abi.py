@@ -69,3 +69,40 @@ def test_product_does_not_import_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{fn} imports the oracle"
             assert "qwen2vl_ref" not in src, f"{fn} references the oracle module"
+
+
+def test_decode_gemm_slot_geometry_without_gpu(lib_path):
+    """vis_gemm_decode_ksplit is host-only arithmetic: the partial-slot count the stream-K cut needs."""
+    from vision_inspection_system_amd import hip
+    lib = hip.load()
+    for N, K in [(4608, 3584), (3584, 3584), (37888, 3584), (3584, 18944), (152064, 3584), (512, 256), (1000, 704)]:
+        slots = lib.vis_gemm_decode_ksplit(N, K)
+        assert 1 <= slots <= 16, (N, K, slots)
+    assert lib.vis_gemm_decode_ksplit(0, 64) == 0 and lib.vis_gemm_decode_ksplit(128, 32) == 0
+    # fewer slots than the geometry needs is an argument error (checked before any HIP call)
+    need = lib.vis_gemm_decode_ksplit(3584, 18944)
+    assert need > 1
+    assert lib.vis_gemm_decode_bf16(16, 16, 16, None, 8, 3584, 18944, 18944, 18944, 0, need - 1, 0, None) == 1
+
+
+def test_attention_work_planner_partitions_rows():
+    """plan_attn_items (host): every query row of every segment is covered exactly once, items never straddle a
+    segment, 128-row items come first, and the ViT single-image case trades trailing full items for halves."""
+    from vision_inspection_system_amd import hip
+    cases = [([(0, 4900)], 16), ([(0, 100), (100, 356)], 4), ([(i * 64, (i + 1) * 64) for i in range(5)], 4),
+             ([(0, 4900), (4900, 9800), (9800, 11000)], 16), ([(0, 37)], 16), ([(0, 4900)], 0)]
+    for segs, heads in cases:
+        items = hip.plan_attn_items(segs, heads)
+        seen = {}
+        for (q0, qn, k0, k1) in items:
+            assert 0 < qn <= 128 and (k0, k1) in segs and k0 <= q0 and q0 + qn <= k1
+            for r in range(q0, q0 + qn):
+                assert r not in seen
+                seen[r] = 1
+        assert len(seen) == sum(e - s for s, e in segs)
+        sizes = [it[1] > 64 for it in items]
+        assert sizes == sorted(sizes, reverse=True)          # full items first
+    vit = hip.plan_attn_items([(0, 4900)], 16)
+    assert sum(1 for it in vit if it[1] > 64) * 16 == hip.ATTN_SLOTS   # fulls fill exactly one round
+    assert hip.plan_attn_items([(0, 4900)], 0) == [(q, min(128, 4900 - q), 0, 4900) for q in range(0, 4864, 128)] + \
+        [(4864, 36, 0, 4900)]
