@@ -118,6 +118,16 @@ int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const vo
                         void* yn, int B, int N, int ldr, int ldy, int ldyn, int swiglu, float eps,
                         vis_stream_t stream);
 
+/* Row f3: bicubic resample of the decoded RGB frame, bit-exact with Pillow's 8-bit ImagingResample (the
+ * resampler behind the HF Qwen2-VL processor's resize(resample=BICUBIC),
+ * TF:models/qwen2_vl/image_processing_qwen2_vl.py:62-89,:165-198; replaces the host-side PIL call of the service
+ * half of reference step a3, src/agents/vlm_inspector.py:46-88).  src u8 [in_h][in_w][3] -> dst u8
+ * [out_h][out_w][3], tmp u8 [in_h][out_w][3].  kx int32 [out_w][ksx] / bx int32 [out_w][2] = {first column,
+ * taps}: fixed-point (22 fractional bits) filter rows of the horizontal pass; ky/by the same for the vertical pass
+ * (built on the host by image_processing.resample_coeffs).  All pointers are device pointers. */
+int vis_resize_rgb_u8(const void* src, void* tmp, void* dst, int in_h, int in_w, int out_h, int out_w,
+                      const void* kx, const void* bx, int ksx, const void* ky, const void* by, int ksy, void* stream);
+
 /* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
  * out[row0 + p][ld_out] in the merge-group order of
  * TF image_processing_pil_qwen2_vl.py:156-190; mean/stdv are HOST pointers to 3 floats. */

@@ -55,6 +55,22 @@ def test_chat_completions_shape(local_cfg, images):
     assert get_model("synthetic:tiny") is get_model("synthetic:tiny")
 
 
+def test_gpu_resize_path_equals_host_pil_path(local_cfg, images, monkeypatch):
+    """Row f3: with the bicubic resample on the GPU (default) the reply is identical to the host-PIL path,
+    because the frames are bit-identical."""
+    from vision_inspection_system_amd.client import LocalVLMClient
+    from vision_inspection_system_amd.image_processing import encode_image_optimized
+    c = LocalVLMClient()
+    for path in images:
+        msgs = [{"role": "user", "content": [{"type": "text", "text": "Inspect."},
+                                             {"type": "image_url", "image_url": {"url": encode_image_optimized(path, 256)}}]}]
+        monkeypatch.setenv("VIS_GPU_RESIZE", "1")
+        a = c.chat.completions.create(model="synthetic:tiny", messages=msgs, temperature=0.0, max_tokens=12)
+        monkeypatch.setenv("VIS_GPU_RESIZE", "0")
+        b = c.chat.completions.create(model="synthetic:tiny", messages=msgs, temperature=0.0, max_tokens=12)
+        assert a.choices[0].message.content == b.choices[0].message.content and a.usage == b.usage
+
+
 def test_agents_nodes_batch_on_gpu(local_cfg, images):
     from vision_inspection_system_amd.agents import VLMAuditorAgent, VLMInspectorAgent
     from vision_inspection_system_amd.batch import run_batch_inspection

@@ -142,10 +142,14 @@ class LocalVLMClient:
         self.chat = _Chat(self)
 
     def _prepare(self, lm, messages):
-        """messages -> (token ids, resized uint8 frames) for one request."""
-        from .image_processing import decode_data_uri, resize_for_model
+        """messages -> (token ids, [(decoded uint8 RGB frame, (target_h, target_w))]) for one request.
+        The JPEG is decoded on the host; the bicubic resample to the smart_resize target runs on the GPU
+        (hip.resize_rgb, bit-exact with PIL) unless VIS_GPU_RESIZE=0 asks for the host PIL path."""
+        import numpy as np
+        from .image_processing import decode_data_uri, resize_for_model, target_size
         from .tokenizer import build_chat_ids
         cfg = lm.cfg
+        gpu_resize = os.environ.get("VIS_GPU_RESIZE", "1") != "0"
         frames = []
         for m in messages:
             content = m.get("content")
@@ -153,9 +157,14 @@ class LocalVLMClient:
                 for part in content:
                     if part.get("type") == "image_url":
                         url = part["image_url"]["url"] if isinstance(part.get("image_url"), dict) else part["image_url"]
-                        frames.append(resize_for_model(decode_data_uri(url), cfg.patch, cfg.merge, cfg.min_pixels,
-                                                       cfg.max_pixels))
-        counts = [(f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2 for f in frames]
+                        img = decode_data_uri(url)
+                        th, tw = target_size(img.size, cfg.patch, cfg.merge, cfg.min_pixels, cfg.max_pixels)
+                        if gpu_resize:
+                            frames.append((np.array(img, dtype=np.uint8), (th, tw)))
+                        else:
+                            frames.append((resize_for_model(img, cfg.patch, cfg.merge, cfg.min_pixels,
+                                                            cfg.max_pixels), (th, tw)))
+        counts = [(th // cfg.patch) * (tw // cfg.patch) // cfg.merge ** 2 for _, (th, tw) in frames]
         return build_chat_ids(lm.tokenizer, messages, counts), frames
 
     def _complete(self, model, messages, temperature, max_tokens, **kwargs) -> ChatCompletion:
@@ -179,7 +188,9 @@ class LocalVLMClient:
         with eng.lock:
             for i in range(0, len(prepared), eng.max_batch):
                 chunk = prepared[i:i + eng.max_batch]
-                reqs = [(ids, [torch.from_numpy(f).to(eng.device) for f in frames]) for ids, frames in chunk]
+                from . import hip
+                reqs = [(ids, [hip.resize_rgb(torch.from_numpy(f).to(eng.device), th, tw) for f, (th, tw) in frames])
+                        for ids, frames in chunk]
                 toks = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed)
                 for (ids, _), t in zip(chunk, toks):
                     out.append(ChatCompletion([_Choice(_Message(tok.decode(t)))], model=model_id,

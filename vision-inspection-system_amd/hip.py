@@ -33,6 +33,7 @@ _SIGS = {
     "vis_gemm_decode_bf16": "pppp" + "iiiiiiii" + "p",
     "vis_skinny_finalize": "p" + "i" + "ppppp" + "iiiiii" + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
+    "vis_resize_rgb_u8": "ppp" + "iiii" + "ppi" + "ppi" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
 }
@@ -363,6 +364,35 @@ def skinny_finalize(part: torch.Tensor, ksplit: int, y: torch.Tensor, N: int, bi
 
 _MEAN = (ctypes.c_float * 3)()
 _STD = (ctypes.c_float * 3)()
+
+
+_RESIZE_TABLES: dict = {}
+
+
+def resize_rgb(frame: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
+    """uint8 [H, W, 3] device frame -> uint8 [out_h, out_w, 3], bit-exact with PIL's BICUBIC resize."""
+    from .image_processing import resample_coeffs
+    if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3 or not frame.is_contiguous():
+        raise HipLibraryError("resize_rgb: contiguous uint8 [H, W, 3] frame required")
+    in_h, in_w = int(frame.shape[0]), int(frame.shape[1])
+    if (in_h, in_w) == (out_h, out_w):
+        return frame
+    key = (in_h, in_w, out_h, out_w, str(frame.device))
+    tabs = _RESIZE_TABLES.get(key)
+    if tabs is None:
+        bx, kx = resample_coeffs(in_w, out_w)
+        by, ky = resample_coeffs(in_h, out_h)
+        tabs = tuple(torch.from_numpy(a).to(frame.device) for a in (kx, bx, ky, by))
+        if len(_RESIZE_TABLES) > 32:
+            _RESIZE_TABLES.pop(next(iter(_RESIZE_TABLES)))
+        _RESIZE_TABLES[key] = tabs
+    kx, bx, ky, by = tabs
+    tmp = torch.empty((in_h, out_w, 3), dtype=torch.uint8, device=frame.device)
+    dst = torch.empty((out_h, out_w, 3), dtype=torch.uint8, device=frame.device)
+    rc = load().vis_resize_rgb_u8(_ptr(frame), _ptr(tmp), _ptr(dst), in_h, in_w, out_h, out_w, _ptr(kx), _ptr(bx),
+                                  kx.shape[1], _ptr(ky), _ptr(by), ky.shape[1], _stream())
+    _check(rc, "vis_resize_rgb_u8")
+    return dst
 
 
 def patchify(img_u8: torch.Tensor, out: torch.Tensor, row0: int, mean, std) -> None:

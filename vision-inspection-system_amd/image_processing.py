@@ -92,6 +92,84 @@ def resize_for_model(img: Image.Image, patch: int = 14, merge: int = 2, min_pixe
     return np.array(img, dtype=np.uint8)  # writable copy
 
 
+# ----------------------------------------------------------------------------- resampling tables (row f3)
+_PRECISION_BITS = 32 - 8 - 2  # Pillow's fixed-point format for 8-bit resampling
+
+
+def _bicubic(x: float) -> float:
+    """Keys cubic, a = -0.5 (Pillow's BICUBIC filter, support 2.0), same operation order as the C code."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Per-output-coordinate windows and fixed-point weights of Pillow's 8-bit bicubic resampling
+    (Pillow 12.2 src/libImaging/Resample.c, precompute_coeffs + normalize_coeffs_8bpc; restated in float64 with
+    the same operation order, so the integers are identical).  Returns (bounds int32 [out,2] = {first, taps},
+    kk int32 [out, ksize])."""
+    support_f = 2.0
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = support_f * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    one = float(1 << _PRECISION_BITS)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for v in w:
+            ww += v
+        for x in range(xmax):
+            v = w[x] / ww if ww != 0.0 else w[x]
+            kk[xx, x] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
+        bounds[xx, 0] = xmin
+        bounds[xx, 1] = xmax
+    return bounds, kk
+
+
+def resample_u8_reference(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+    """numpy statement of the two integer passes the GPU kernels perform (host logic check, tests only)."""
+    in_h, in_w, _ = img.shape
+
+    def one_pass(a: np.ndarray, in_size: int, out_size: int) -> np.ndarray:   # resamples axis 1
+        if in_size == out_size:
+            return a
+        b, k = resample_coeffs(in_size, out_size)
+        out = np.empty((a.shape[0], out_size, a.shape[2]), dtype=np.uint8)
+        for o in range(out_size):
+            x0, n = int(b[o, 0]), int(b[o, 1])
+            acc = (a[:, x0:x0 + n, :].astype(np.int64) * k[o, :n].astype(np.int64)[None, :, None]).sum(axis=1)
+            out[:, o, :] = np.clip((acc + (1 << (_PRECISION_BITS - 1))) >> _PRECISION_BITS, 0, 255)
+        return out
+
+    tmp = one_pass(img, in_w, out_w)
+    return one_pass(tmp.transpose(1, 0, 2), in_h, out_h).transpose(1, 0, 2).copy()
+
+
+def target_size(img_size: Tuple[int, int], patch: int = 14, merge: int = 2, min_pixels: int = 56 * 56,
+                max_pixels: int = 28 * 28 * 1280) -> Tuple[int, int]:
+    """(w, h) of a PIL image -> (target_h, target_w) of the model frame."""
+    w, h = img_size
+    return smart_resize(h, w, patch * merge, min_pixels, max_pixels)
+
+
 def grid_of(frame_u8: np.ndarray, patch: int = 14) -> Tuple[int, int, int]:
     h, w, _ = frame_u8.shape
     return (1, h // patch, w // patch)
