@@ -1,0 +1,285 @@
+"""Row f2: the Auditor's fallback model, Llama-3.2-11B-Vision ("mllama"): configuration,
+checkpoint tensor names/shapes, deterministic synthetic weights and the HBM layouts the kernels read.
+
+Reference: src/agents/vlm_auditor.py:81-83 (``meta-llama/Llama-3.2-11B-Vision-Instruct`` when Groq is absent).
+Tensor names follow the published checkpoint as transformers 5.15 loads it (``model.vision_model.*``,
+``model.language_model.*``, ``model.multi_modal_projector.*``, ``lm_head.weight``).
+
+Layout decisions on top of weights.py's (everything [out, in] bf16, fused qkv, 16-row interleaved gate/up):
+  * every tanh gate is a scalar known at load time, so it is FOLDED into the projection that feeds the gated
+    residual add (vision global layers: o_proj / fc2 (+bias); text cross layers: cross o_proj / down_proj) -
+    no kernel knows about gates;
+  * the three vision embedding tables (pre-tile, gated position + tile position, post-tile) are combined on the
+    host into two per-aspect-ratio tables [max_ar+1][tiles][tile_tokens][E] / [max_ar+1][tiles][E] in f32 -> bf16;
+  * cross-attention K/V projections of a layer are one [2*Hkv*D, hidden] matrix (one GEMM over the vision
+    tokens), their K/V stay resident per request ("cross cache");
+  * the patch-embed Conv2d weight [E, 3, 14, 14] is flattened to [E, 588] and zero-padded to 640 columns.
+"""
+from __future__ import annotations
+
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .weights import _hash_uniform, interleave_gate_up, pad_cols
+
+
+@dataclass
+class MllamaConfig:
+    # text
+    hidden: int = 4096
+    layers: int = 40
+    heads: int = 32
+    kv_heads: int = 8
+    intermediate: int = 14336
+    vocab: int = 128256
+    rms_eps: float = 1e-5
+    rope_theta: float = 500000.0
+    rope_factor: float = 8.0
+    rope_low_freq: float = 1.0
+    rope_high_freq: float = 4.0
+    rope_orig_ctx: int = 8192
+    cross_layers: Tuple[int, ...] = (3, 8, 13, 18, 23, 28, 33, 38)
+    image_token_id: int = 128256
+    eos_ids: Tuple[int, ...] = (128001, 128008, 128009)
+    # vision
+    v_hidden: int = 1280
+    v_heads: int = 16
+    v_layers: int = 32
+    v_global_layers: int = 8
+    v_mlp: int = 5120
+    v_inter: Tuple[int, ...] = (3, 7, 15, 23, 30)
+    v_eps: float = 1e-5
+    image_size: int = 560
+    patch: int = 14
+    max_tiles: int = 4
+    name: str = "llama-3.2-11b-vision"
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.heads
+
+    @property
+    def v_head_dim(self) -> int:
+        return self.v_hidden // self.v_heads
+
+    @property
+    def tile_tokens(self) -> int:
+        return (self.image_size // self.patch) ** 2 + 1
+
+    @property
+    def v_out(self) -> int:
+        return self.v_hidden * (1 + len(self.v_inter))
+
+    @property
+    def max_ar_id(self) -> int:
+        return len([(w, h) for w in range(1, self.max_tiles + 1) for h in range(1, self.max_tiles + 1)
+                    if w * h <= self.max_tiles])
+
+    @classmethod
+    def mllama_11b(cls) -> "MllamaConfig":
+        return cls()
+
+    @classmethod
+    def tiny(cls) -> "MllamaConfig":
+        """Kernel-compatible miniature (head dims 128 / 80 like the real model) for parity tests."""
+        return cls(hidden=256, layers=5, heads=2, kv_heads=1, intermediate=704, vocab=512, cross_layers=(1, 3),
+                   image_token_id=512, eos_ids=(2,), rope_orig_ctx=64, v_hidden=320, v_heads=4, v_layers=4,
+                   v_global_layers=2, v_mlp=1280, v_inter=(1, 3), image_size=56, name="mllama-tiny")
+
+    def validate_for_kernels(self) -> None:
+        if self.head_dim != 128 or self.v_head_dim != 80:
+            raise ValueError("kernels are specialised for head_dim 128 (text) and 80 (vision)")
+        if self.hidden % 64 or self.v_hidden % 64 or self.intermediate % 64 or self.v_mlp % 64 or self.v_out % 64:
+            raise ValueError("GEMM K dimensions must be multiples of 64")
+        if self.intermediate % 16 or self.heads % self.kv_heads or self.heads // self.kv_heads not in (1, 2, 4, 7, 8):
+            raise ValueError("unsupported GQA group / intermediate size")
+
+
+# ----------------------------------------------------------------------------- names / shapes
+def tensor_shapes(cfg: MllamaConfig) -> Dict[str, tuple]:
+    E, H, D = cfg.v_hidden, cfg.hidden, cfg.head_dim
+    T, P = cfg.max_tiles, cfg.tile_tokens
+    A = cfg.max_ar_id + 1
+    V = "model.vision_model."
+    s: Dict[str, tuple] = {
+        V + "patch_embedding.weight": (E, 3, cfg.patch, cfg.patch),
+        V + "class_embedding": (E,),
+        V + "gated_positional_embedding.gate": (1,),
+        V + "gated_positional_embedding.embedding": (P, E),
+        V + "gated_positional_embedding.tile_embedding.weight": (A, T * P * E),
+        V + "pre_tile_positional_embedding.embedding.weight": (A, T * E),
+        V + "pre_tile_positional_embedding.gate": (1,),
+        V + "post_tile_positional_embedding.embedding.weight": (A, T * E),
+        V + "post_tile_positional_embedding.gate": (1,),
+        V + "layernorm_pre.weight": (E,), V + "layernorm_pre.bias": (E,),
+        V + "layernorm_post.weight": (E,), V + "layernorm_post.bias": (E,),
+    }
+    for stack, n, gated in (("transformer", cfg.v_layers, False), ("global_transformer", cfg.v_global_layers, True)):
+        for i in range(n):
+            p = f"{V}{stack}.layers.{i}."
+            if gated:
+                s[p + "gate_attn"] = (1,); s[p + "gate_ffn"] = (1,)
+            for nm in ("q", "k", "v", "o"):
+                s[p + f"self_attn.{nm}_proj.weight"] = (E, E)
+            s[p + "mlp.fc1.weight"] = (cfg.v_mlp, E); s[p + "mlp.fc1.bias"] = (cfg.v_mlp,)
+            s[p + "mlp.fc2.weight"] = (E, cfg.v_mlp); s[p + "mlp.fc2.bias"] = (E,)
+            s[p + "input_layernorm.weight"] = (E,); s[p + "input_layernorm.bias"] = (E,)
+            s[p + "post_attention_layernorm.weight"] = (E,); s[p + "post_attention_layernorm.bias"] = (E,)
+    L = "model.language_model."
+    s[L + "embed_tokens.weight"] = (cfg.vocab + 8, H)
+    for i in range(cfg.layers):
+        p = f"{L}layers.{i}."
+        a = "cross_attn" if i in cfg.cross_layers else "self_attn"
+        if i in cfg.cross_layers:
+            s[p + "cross_attn_attn_gate"] = (1,); s[p + "cross_attn_mlp_gate"] = (1,)
+            s[p + "cross_attn.q_norm.weight"] = (D,); s[p + "cross_attn.k_norm.weight"] = (D,)
+        s[p + f"{a}.q_proj.weight"] = (cfg.heads * D, H)
+        s[p + f"{a}.k_proj.weight"] = (cfg.kv_heads * D, H)
+        s[p + f"{a}.v_proj.weight"] = (cfg.kv_heads * D, H)
+        s[p + f"{a}.o_proj.weight"] = (H, cfg.heads * D)
+        s[p + "mlp.gate_proj.weight"] = (cfg.intermediate, H)
+        s[p + "mlp.up_proj.weight"] = (cfg.intermediate, H)
+        s[p + "mlp.down_proj.weight"] = (H, cfg.intermediate)
+        s[p + "input_layernorm.weight"] = (H,)
+        s[p + "post_attention_layernorm.weight"] = (H,)
+    s[L + "norm.weight"] = (H,)
+    s["model.multi_modal_projector.weight"] = (H, cfg.v_out)
+    s["model.multi_modal_projector.bias"] = (H,)
+    s["lm_head.weight"] = (cfg.vocab, H)
+    return s
+
+
+def synth_state_dict(cfg: MllamaConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Deterministic fp32 CPU weights in checkpoint naming, rounded to bf16-representable values (the oracle, the
+    transformers golden generator and the HIP engine all consume exactly these numbers).  Gates are non-trivial
+    (|gate| up to 0.8) so every gated path is exercised."""
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in tensor_shapes(cfg).items():
+        n = int(np.prod(shape))
+        u = _hash_uniform(n, seed * 100003 + (zlib.crc32(name.encode()) & 0xFFFFFFF))
+        if name.endswith("layernorm.weight") or name.endswith("norm.weight") or name.endswith("layernorm_pre.weight") \
+                or name.endswith("layernorm_post.weight"):
+            v = 1.0 + 0.1 * u
+        elif name.endswith(".bias"):
+            v = 0.1 * u
+        elif name.endswith("gate") or name.endswith("gate_attn") or name.endswith("gate_ffn"):
+            v = 0.3 + 0.5 * u
+        elif name.endswith("embed_tokens.weight"):
+            v = u * np.sqrt(3.0)
+        elif "positional_embedding" in name or name.endswith("class_embedding"):
+            v = 0.5 * u
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = u * np.sqrt(3.0 / fan_in)
+        out[name] = torch.from_numpy(v.astype(np.float32).reshape(shape)).to(torch.bfloat16).float()
+    return out
+
+
+# ----------------------------------------------------------------------------- device layouts
+@dataclass
+class MllamaVisionLayer:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    qkv_w: torch.Tensor; o_w: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor; fc2_w: torch.Tensor; fc2_b: torch.Tensor
+
+
+@dataclass
+class MllamaTextLayer:
+    cross: bool
+    ln1_w: torch.Tensor; ln2_w: torch.Tensor
+    qkv_w: Optional[torch.Tensor]      # self: [Hq*D + 2*Hkv*D, H]; cross: q_proj only [Hq*D, H]
+    kv_w: Optional[torch.Tensor]       # cross: [2*Hkv*D, H] applied to the vision tokens
+    q_norm: Optional[torch.Tensor]; k_norm: Optional[torch.Tensor]
+    o_w: torch.Tensor                  # cross: pre-multiplied by tanh(attn gate)
+    gateup_w: torch.Tensor
+    down_w: torch.Tensor               # cross: pre-multiplied by tanh(mlp gate)
+
+
+@dataclass
+class MllamaDeviceWeights:
+    patch_w: torch.Tensor                       # [E, 640]
+    cls_pos: torch.Tensor                       # [A][T][P][E] bf16: everything added to the patch/CLS rows before ln_pre
+    post_tile: torch.Tensor                     # [A][T][E] bf16 (gated)
+    ln_pre_w: torch.Tensor; ln_pre_b: torch.Tensor; ln_post_w: torch.Tensor; ln_post_b: torch.Tensor
+    v_layers: List[MllamaVisionLayer] = field(default_factory=list)
+    v_global: List[MllamaVisionLayer] = field(default_factory=list)
+    proj_w: torch.Tensor = None; proj_b: torch.Tensor = None      # projector over the PERMUTED feature order
+    embed: torch.Tensor = None
+    layers: List[MllamaTextLayer] = field(default_factory=list)
+    norm_w: torch.Tensor = None
+    lm_head: torch.Tensor = None
+
+
+def pack_device_weights(cfg: MllamaConfig, sd: Dict[str, torch.Tensor], device) -> MllamaDeviceWeights:
+    """fp32 checkpoint-named tensors -> bf16 device tensors in kernel layouts (see module docstring)."""
+    bf = torch.bfloat16
+    dev = torch.device(device)
+    V, L = "model.vision_model.", "model.language_model."
+    E, T, P, A = cfg.v_hidden, cfg.max_tiles, cfg.tile_tokens, cfg.max_ar_id + 1
+
+    def d(t):
+        return t.to(bf).contiguous().to(dev)
+
+    # embeddings added before layernorm_pre: row 0 of a tile = class embedding, rows 1.. = conv output
+    g = torch.tanh(sd[V + "gated_positional_embedding.gate"].float())
+    pre = sd[V + "pre_tile_positional_embedding.embedding.weight"].float().view(A, T, 1, E) * \
+        torch.tanh(sd[V + "pre_tile_positional_embedding.gate"].float())
+    pos = (1 - g) * sd[V + "gated_positional_embedding.embedding"].float().view(1, 1, P, E) + \
+        g * sd[V + "gated_positional_embedding.tile_embedding.weight"].float().view(A, T, P, E)
+    cls_pos = pos.clone()
+    cls_pos[:, :, 1:] += pre                                   # patches get the pre-tile embedding, CLS does not
+    cls_pos[:, :, 0] += sd[V + "class_embedding"].float().view(1, 1, E)
+    post = sd[V + "post_tile_positional_embedding.embedding.weight"].float().view(A, T, E) * \
+        torch.tanh(sd[V + "post_tile_positional_embedding.gate"].float())
+
+    def vlayer(p, gated):
+        ga = torch.tanh(sd[p + "gate_attn"].float()) if gated else 1.0
+        gf = torch.tanh(sd[p + "gate_ffn"].float()) if gated else 1.0
+        qkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0)
+        return MllamaVisionLayer(
+            ln1_w=d(sd[p + "input_layernorm.weight"]), ln1_b=d(sd[p + "input_layernorm.bias"]),
+            ln2_w=d(sd[p + "post_attention_layernorm.weight"]), ln2_b=d(sd[p + "post_attention_layernorm.bias"]),
+            qkv_w=d(qkv), o_w=d(sd[p + "self_attn.o_proj.weight"].float() * ga),
+            fc1_w=d(sd[p + "mlp.fc1.weight"]), fc1_b=d(sd[p + "mlp.fc1.bias"]),
+            fc2_w=d(sd[p + "mlp.fc2.weight"].float() * gf), fc2_b=d(sd[p + "mlp.fc2.bias"].float() * gf))
+
+    w = MllamaDeviceWeights(
+        patch_w=d(pad_cols(sd[V + "patch_embedding.weight"].reshape(E, -1), 64)),
+        cls_pos=d(cls_pos), post_tile=d(post),
+        ln_pre_w=d(sd[V + "layernorm_pre.weight"]), ln_pre_b=d(sd[V + "layernorm_pre.bias"]),
+        ln_post_w=d(sd[V + "layernorm_post.weight"]), ln_post_b=d(sd[V + "layernorm_post.bias"]))
+    w.v_layers = [vlayer(f"{V}transformer.layers.{i}.", False) for i in range(cfg.v_layers)]
+    w.v_global = [vlayer(f"{V}global_transformer.layers.{i}.", True) for i in range(cfg.v_global_layers)]
+    # projector: HF feature order is [final E | (e, i) interleaved]; the engine concatenates [final | inter_0 | inter_1 ...]
+    ni = len(cfg.v_inter)
+    pw = sd["model.multi_modal_projector.weight"].float()
+    inter = pw[:, E:].view(cfg.hidden, E, ni).permute(0, 2, 1).reshape(cfg.hidden, E * ni)
+    w.proj_w = d(torch.cat([pw[:, :E], inter], dim=1))
+    w.proj_b = d(sd["model.multi_modal_projector.bias"])
+    w.embed = d(sd[L + "embed_tokens.weight"])
+    for i in range(cfg.layers):
+        p = f"{L}layers.{i}."
+        gu = interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"])
+        if i in cfg.cross_layers:
+            ga = torch.tanh(sd[p + "cross_attn_attn_gate"].float())
+            gm = torch.tanh(sd[p + "cross_attn_mlp_gate"].float())
+            kv = torch.cat([sd[p + "cross_attn.k_proj.weight"], sd[p + "cross_attn.v_proj.weight"]], dim=0)
+            w.layers.append(MllamaTextLayer(
+                cross=True, ln1_w=d(sd[p + "input_layernorm.weight"]), ln2_w=d(sd[p + "post_attention_layernorm.weight"]),
+                qkv_w=d(sd[p + "cross_attn.q_proj.weight"]), kv_w=d(kv),
+                q_norm=d(sd[p + "cross_attn.q_norm.weight"]), k_norm=d(sd[p + "cross_attn.k_norm.weight"]),
+                o_w=d(sd[p + "cross_attn.o_proj.weight"].float() * ga), gateup_w=d(gu),
+                down_w=d(sd[p + "mlp.down_proj.weight"].float() * gm)))
+        else:
+            qkv = torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0)
+            w.layers.append(MllamaTextLayer(
+                cross=False, ln1_w=d(sd[p + "input_layernorm.weight"]), ln2_w=d(sd[p + "post_attention_layernorm.weight"]),
+                qkv_w=d(qkv), kv_w=None, q_norm=None, k_norm=None, o_w=d(sd[p + "self_attn.o_proj.weight"]),
+                gateup_w=d(gu), down_w=d(sd[p + "mlp.down_proj.weight"])))
+    w.norm_w = d(sd[L + "norm.weight"])
+    w.lm_head = d(sd["lm_head.weight"])
+    return w
