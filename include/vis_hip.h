@@ -59,7 +59,9 @@ int vis_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int
  * qkv[S, (Hq+2Hkv)*HD] packed projections; cos/sin [S, HD] f32 rows (M-RoPE sections already
  * selected per channel, TF modeling_qwen2_vl.py:180-222; ViT 2-D rope :225-236).
  * q -> [Hq][S][HD]; k,v -> [Hkv][k_tokens][HD] rows k_pos0.. (v may be NULL);
- * vt -> [Hkv][HD][vt_ld] keys contiguous (may be NULL).  HD in {128, 80}. */
+ * vt -> [Hkv][HD][vt_ld] keys contiguous (may be NULL).  HD in {128, 80}.
+ * Hq == 0 (k/v only) or Hkv == 0 (q only) give a partial split; cosv == sinv == NULL means no rotation (mllama
+ * vision tower and cross-attention operands, TF:models/mllama/modeling_mllama.py:234-268,:411-440). */
 int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void* q, void* k, void* v,
                        void* vt, int S, int ld_qkv, int Hq, int Hkv, int HD, int k_tokens, int k_pos0,
                        int vt_ld, vis_stream_t stream);
@@ -141,6 +143,26 @@ int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D,
 /* K12  dst[idx[i]][:] = src[i][:] (image-token scatter, TF modeling_qwen2_vl.py:1144-1200). */
 int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
                      vis_stream_t stream);
+
+/* ---- Row f2: Llama-3.2-11B-Vision ("mllama") Auditor, reference src/agents/vlm_auditor.py:81-83,:152-158 ---- */
+
+/* Resized RGB frame -> patch rows of the tile canvas (zero padding applied to RAW pixels, then rescale/normalise;
+ * TF:models/mllama/image_processing_pil_mllama.py pad/split_to_tiles_np; Conv2d feature order (c, ph, pw),
+ * TF:models/mllama/modeling_mllama.py:833-840).  Row of tile t, patch (py, px): t*((tile/14)^2+1) + 1 + py*(tile/14) + px;
+ * CLS rows and absent tiles are not written (the caller zero-fills). */
+int vis_patchify_tiles_u8(const void* img, void* out, int H, int W, int tiles_h, int tiles_w, int tile, int ld_out,
+                          const float* mean, const float* stdv, vis_stream_t stream);
+
+/* x[i][:] += table[idx[i]][:] (bf16, f32 add): per-tile embeddings broadcast over a tile's tokens
+ * (TF:models/mllama/modeling_mllama.py:102-122). */
+int vis_add_rows_bf16(void* x, const void* table, const void* idx, int n, int D, int ldx, int n_table,
+                      vis_stream_t stream);
+
+/* Decode-step cross-attention over a static key/value set (TF:models/mllama/modeling_mllama.py:384-466): q [Hq*128]
+ * from the q projection (per-head q_norm applied inside), k/v [Hkv][key_tokens][128], *nkeys_m1 = valid keys - 1. */
+int vis_decode_cross_attn(const void* q, const void* q_norm_w, const void* k, const void* v, const void* nkeys_m1,
+                          void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int key_tokens,
+                          int nsplit, float scale, float eps, vis_stream_t stream);
 
 #ifdef __cplusplus
 }

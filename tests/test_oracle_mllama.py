@@ -65,3 +65,18 @@ def test_masked_rows_and_shapes(tiny):
     big = tensor_shapes(MllamaConfig.mllama_11b())
     n = sum(int(np.prod(s)) for s in big.values())
     assert 10.5e9 < n < 10.8e9          # Llama-3.2-11B-Vision: 10.67 B parameters
+
+
+def test_product_host_logic_matches_processor_and_oracle(tiny):
+    """The engine's own host-side geometry / rope tables (it may not import the oracle) against the recorded
+    processor decisions and the oracle's tables."""
+    from vision_inspection_system_amd import mllama_engine as E
+    cfg, rc, _, g = tiny
+    for h, w, ch, cw, nh, nw in g["canvas_cases"].tolist():
+        assert E.optimal_canvas(h, w, 4, 560) == (ch, cw), (h, w)
+        assert E.fit_to_canvas(h, w, ch, cw, 560) == (nh, nw), (h, w)
+    assert E.supported_aspect_ratios(4) == R.supported_aspect_ratios(4)
+    for c, r in ((cfg, rc), (MllamaConfig.mllama_11b(), ref_cfg(MllamaConfig.mllama_11b()))):
+        cos, sin = E.llama3_rope_tables(c, 300)
+        rcos, rsin = R.rope_cos_sin(r, torch.arange(300))
+        assert np.abs(cos - rcos.numpy()).max() < 2e-5 and np.abs(sin - rsin.numpy()).max() < 2e-5

@@ -18,8 +18,9 @@ SIZES = [  # in_h, in_w, out_h, out_w
 ]
 
 
-def _pil(img, oh, ow):
-    return np.array(Image.fromarray(img).resize((ow, oh), resample=Image.Resampling.BICUBIC))
+def _pil(img, oh, ow, kind="bicubic"):
+    rs = Image.Resampling.BICUBIC if kind == "bicubic" else Image.Resampling.BILINEAR
+    return np.array(Image.fromarray(img).resize((ow, oh), resample=rs))
 
 
 def _frame(h, w, seed):
@@ -29,10 +30,11 @@ def _frame(h, w, seed):
     return img
 
 
+@pytest.mark.parametrize("kind", ["bicubic", "bilinear"])
 @pytest.mark.parametrize("ih,iw,oh,ow", SIZES)
-def test_host_tables_reproduce_pillow_exactly(ih, iw, oh, ow):
+def test_host_tables_reproduce_pillow_exactly(ih, iw, oh, ow, kind):
     img = _frame(ih, iw, 1)
-    assert np.array_equal(resample_u8_reference(img, oh, ow), _pil(img, oh, ow))
+    assert np.array_equal(resample_u8_reference(img, oh, ow, kind), _pil(img, oh, ow, kind))
 
 
 def test_tables_shape_and_normalisation():
@@ -51,14 +53,15 @@ def test_target_size_matches_resize_for_model():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["bicubic", "bilinear"])
 @pytest.mark.parametrize("ih,iw,oh,ow", SIZES)
-def test_gpu_resize_bit_exact_with_pillow(ih, iw, oh, ow):
+def test_gpu_resize_bit_exact_with_pillow(ih, iw, oh, ow, kind):
     import torch
     from vision_inspection_system_amd import hip
     img = _frame(ih, iw, 2)
-    got = hip.resize_rgb(torch.from_numpy(img).to("cuda:0"), oh, ow).cpu().numpy()
+    got = hip.resize_rgb(torch.from_numpy(img).to("cuda:0"), oh, ow, kind).cpu().numpy()
     assert got.shape == (oh, ow, 3)
-    assert np.array_equal(got, _pil(img, oh, ow))
+    assert np.array_equal(got, _pil(img, oh, ow, kind))
 
 
 @pytest.mark.gpu

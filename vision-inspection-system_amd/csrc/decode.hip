@@ -228,6 +228,11 @@ struct DecAttnArgs {
   float scale_log2;
   // batch (blockIdx.z = sequence): element strides between sequences
   long long qkv_bs, cache_bs, tab_bs;
+  // cross-attention mode (mllama, TF:models/mllama/modeling_mllama.py:384-466): `qkv` holds only the Hq query heads,
+  // the cache is a static set of keys/values (no rope, no append), *step_ptr = number of keys - 1, and the
+  // per-head RMSNorm of q (q_norm) is applied while q is staged.
+  const bf16_t* q_norm_w;  // [128] or null (self-attention mode)
+  float q_eps;
 };
 
 // Structure (no cross-lane reductions inside a wave):
@@ -286,27 +291,46 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   const int ke = min(ks + DA_MAXKEYS, ctx);
   const int nk = ke - ks;
 
-  // ---- rotate q (G heads) and the new k; stage them as bf16 (exactly what later steps read back)
-  const float* cr = p.cos_t + (size_t)slot * HD;
-  const float* sr = p.sin_t + (size_t)slot * HD;
-  for (int it = tid; it < (G + 1) * HALF; it += 256) {
-    const int g = it / HALF, d = it - g * HALF;
-    const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
-    const float a = bf2f(p.qkv[head * HD + d]), b = bf2f(p.qkv[head * HD + HALF + d]);
-    const bf16_t oa = f2bf(a * cr[d] - b * sr[d]);
-    const bf16_t ob = f2bf(b * cr[HALF + d] + a * sr[HALF + d]);
-    bf16_t* dst = (g < G) ? q_s[g] : knew_s;
-    dst[d] = oa;
-    dst[HALF + d] = ob;
+  const bool cross = p.q_norm_w != nullptr;  // workgroup-uniform
+  bool owner = false;
+  if (!cross) {
+    // ---- rotate q (G heads) and the new k; stage them as bf16 (exactly what later steps read back)
+    const float* cr = p.cos_t + (size_t)slot * HD;
+    const float* sr = p.sin_t + (size_t)slot * HD;
+    for (int it = tid; it < (G + 1) * HALF; it += 256) {
+      const int g = it / HALF, d = it - g * HALF;
+      const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
+      const float a = bf2f(p.qkv[head * HD + d]), b = bf2f(p.qkv[head * HD + HALF + d]);
+      const bf16_t oa = f2bf(a * cr[d] - b * sr[d]);
+      const bf16_t ob = f2bf(b * cr[HALF + d] + a * sr[HALF + d]);
+      bf16_t* dst = (g < G) ? q_s[g] : knew_s;
+      dst[d] = oa;
+      dst[HALF + d] = ob;
+    }
+    for (int it = tid; it < (16 - G) * HD; it += 256) q_s[G + it / HD][it % HD] = 0;
+    if (tid < HD) vnew_s[tid] = p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid];
+    __syncthreads();
+    owner = (slot >= ks) && (slot < ke);
+    if (owner && tid < HD) {  // KV-cache append (no other block reads this row in this launch)
+      Kh[(size_t)slot * HD + tid] = knew_s[tid];
+      Vh[(size_t)slot * HD + tid] = vnew_s[tid];
+    }
+  } else {
+    // ---- cross-attention: q_norm (RMSNorm over the 128 dims of each head, HF rounding: normalised value to
+    //      bf16, then times the weight), one wave per head
+    for (int g = wave; g < G; g += 4) {
+      const bf16_t* qh = p.qkv + (size_t)(hkv * G + g) * HD;
+      const float a = bf2f(qh[lane]), b = bf2f(qh[lane + 64]);
+      const float ss = wave_sum(a * a + b * b);
+      const float rstd = rsqrtf(ss * (1.0f / HD) + p.q_eps);
+      q_s[g][lane] = f2bf(bf2f(f2bf(a * rstd)) * bf2f(p.q_norm_w[lane]));
+      q_s[g][lane + 64] = f2bf(bf2f(f2bf(b * rstd)) * bf2f(p.q_norm_w[lane + 64]));
+    }
+    for (int it = tid; it < (16 - G) * HD; it += 256) q_s[G + it / HD][it % HD] = 0;
+    if (tid < HD) { knew_s[tid] = 0; vnew_s[tid] = 0; }
+    __syncthreads();
   }
-  for (int it = tid; it < (16 - G) * HD; it += 256) q_s[G + it / HD][it % HD] = 0;
-  if (tid < HD) vnew_s[tid] = p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid];
-  __syncthreads();
-  const bool owner = (slot >= ks) && (slot < ke);
-  if (owner && tid < HD) {  // KV-cache append (no other block reads this row in this launch)
-    Kh[(size_t)slot * HD + tid] = knew_s[tid];
-    Vh[(size_t)slot * HD + tid] = vnew_s[tid];
-  }
+  const int new_row = cross ? -1 : slot;  // the cache row whose value is still only in knew_s / vnew_s
 
   // ---- scores on the MFMA
   bf16x8 qf[4];
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   for (int gi = 0; gi < KGRP; ++gi) {
     const int kbase = (wave + 4 * gi) * 16;
     if (kbase < nk) {  // wave-uniform
-      const bool is_new = (ks + kbase + l15 == slot);
+      const bool is_new = (ks + kbase + l15 == new_row);
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) {
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   for (int i = 0; i < VROWS; ++i) {
     const int kk = wave + 4 * i;
     if (kk < nk) {  // wave-uniform
-      const uint32_t raw = (ks + kk == slot) ? vnew : vreg[i];
+      const uint32_t raw = (ks + kk == new_row) ? vnew : vreg[i];
       const float v0 = __uint_as_float(raw << 16), v1 = __uint_as_float(raw & 0xffff0000u);
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -445,6 +469,22 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
   }
 }
 
+static int decode_attn_launch(const DecAttnArgs& p, void* out, int batch, hipStream_t stream) {
+  const int G = p.Hq / p.Hkv;
+  vis_clear_error();
+  const dim3 grid(p.Hkv, p.nsplit, batch), block(256);
+  switch (G) {
+    case 1: hipLaunchKernelGGL(decode_attn_fused_kernel<1>, grid, block, 0, stream, p); break;
+    case 2: hipLaunchKernelGGL(decode_attn_fused_kernel<2>, grid, block, 0, stream, p); break;
+    case 4: hipLaunchKernelGGL(decode_attn_fused_kernel<4>, grid, block, 0, stream, p); break;
+    case 7: hipLaunchKernelGGL(decode_attn_fused_kernel<7>, grid, block, 0, stream, p); break;
+    default: hipLaunchKernelGGL(decode_attn_fused_kernel<8>, grid, block, 0, stream, p); break;
+  }
+  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(p.Hq, batch), dim3(256), 0, stream, (const float*)p.part_o,
+                     (const float*)p.part_ml, (bf16_t*)out, p.nsplit, p.step_ptr, p.cache_tokens);
+  return vis_check_launch();
+}
+
 extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
                                const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
                                int cache_tokens, int nsplit, float scale, int batch, long long qkv_bs,
@@ -466,18 +506,31 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
   p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.nsplit = nsplit;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.qkv_bs = qkv_bs; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
-  vis_clear_error();
-  const dim3 grid(Hkv, nsplit, batch), block(256);
-  switch (G) {
-    case 1: hipLaunchKernelGGL(decode_attn_fused_kernel<1>, grid, block, 0, stream, p); break;
-    case 2: hipLaunchKernelGGL(decode_attn_fused_kernel<2>, grid, block, 0, stream, p); break;
-    case 4: hipLaunchKernelGGL(decode_attn_fused_kernel<4>, grid, block, 0, stream, p); break;
-    case 7: hipLaunchKernelGGL(decode_attn_fused_kernel<7>, grid, block, 0, stream, p); break;
-    default: hipLaunchKernelGGL(decode_attn_fused_kernel<8>, grid, block, 0, stream, p); break;
-  }
-  hipLaunchKernelGGL(decode_attn_combine_kernel, dim3(Hq, batch), dim3(256), 0, stream, (const float*)part_o,
-                     (const float*)part_ml, (bf16_t*)out, nsplit, (const int*)step_ptr, cache_tokens);
-  return vis_check_launch();
+  p.q_norm_w = nullptr; p.q_eps = 0.f;
+  return decode_attn_launch(p, out, batch, stream);
+}
+
+// Cross-attention of one new token over a static key/value set (mllama cross layers, decode): q [Hq*128] straight
+// from the q projection (q_norm applied inside), keys/values [Hkv][key_tokens][128] written once per request by
+// the prefill; *nkeys_m1 (device int) = number of valid keys - 1.  Same split/combine machinery as vis_decode_attn.
+extern "C" int vis_decode_cross_attn(const void* q, const void* q_norm_w, const void* k, const void* v,
+                                     const void* nkeys_m1, void* part_o, void* part_ml, void* out, int Hq, int Hkv,
+                                     int HD, int key_tokens, int nsplit, float scale, float eps, hipStream_t stream) {
+  if (!q || !q_norm_w || !k || !v || !nkeys_m1 || !part_o || !part_ml || !out) return VIS_ERR_ARG;
+  if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  const int G = Hq / Hkv;
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;
+  if (nsplit <= 0 || nsplit > 256 || key_tokens <= 0 || (long long)nsplit * DA_MAXKEYS < key_tokens) return VIS_ERR_ARG;
+  if (((uintptr_t)k | (uintptr_t)v) & 15) return VIS_ERR_ARG;
+  DecAttnArgs p;
+  p.qkv = (const bf16_t*)q; p.cos_t = nullptr; p.sin_t = nullptr;
+  p.k_cache = (bf16_t*)k; p.v_cache = (bf16_t*)v; p.step_ptr = (const int*)nkeys_m1;
+  p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
+  p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = key_tokens; p.nsplit = nsplit;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.qkv_bs = 0; p.cache_bs = 0; p.tab_bs = 0;
+  p.q_norm_w = (const bf16_t*)q_norm_w; p.q_eps = eps;
+  return decode_attn_launch(p, out, 1, stream);
 }
 
 // ---------------------------------------------------------------------------

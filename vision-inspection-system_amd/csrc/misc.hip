@@ -117,3 +117,101 @@ extern "C" int vis_scatter_rows(const void* src, const void* idx, void* dst, int
 }
 
 extern "C" int vis_abi_version(void) { return 1; }
+
+// ---------------------------------------------------------------------------
+// Row f2 (mllama): vis_patchify_tiles_u8 - the resized RGB frame [H][W][3] u8, zero-padded on the right/bottom to
+// the tile canvas (TF:models/mllama/image_processing_pil_mllama.py pad(): the padding is applied to RAW pixels,
+// i.e. before rescale/normalise, so padded pixels become (0 - mean) / std), split into tiles_h x tiles_w tiles of
+// `tile` x `tile` pixels (split_to_tiles_np) and cut into 14x14 patches in the Conv2d feature order
+// f = (c*14 + ph)*14 + pw (TF:models/mllama/modeling_mllama.py:833-840,:912-914).  Output row of tile t, patch
+// (py, px):  t * tokens_per_tile + 1 + py * (tile/14) + px   (row 0 of every tile is the CLS slot and is left
+// untouched, like the rows of absent tiles - the caller zero-fills the buffer).
+struct TilePatchArgs {
+  const uint8_t* img;
+  bf16_t* out;
+  int H, W, tiles_h, tiles_w, tile, ld_out;
+  float mean[3], istd[3];
+};
+
+__global__ __launch_bounds__(256) void patchify_tiles_u8_kernel(TilePatchArgs p) {
+  constexpr int P = 14, F = 3 * P * P;  // 588
+  const int G = p.tile / P;             // patches per tile side
+  const int chunks = p.ld_out >> 3;
+  const int per_tile = G * G;
+  const long long total = (long long)p.tiles_h * p.tiles_w * per_tile * chunks;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int ch = (int)(it % chunks);
+    const int pidx = (int)(it / chunks);
+    const int t = pidx / per_tile, pp = pidx - t * per_tile;
+    const int ty = t / p.tiles_w, tx = t - ty * p.tiles_w;
+    const int py = pp / G, px = pp - py * G;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int f = ch * 8 + e;
+      float v = 0.f;
+      if (f < F) {
+        const int c = f / (P * P), rem = f - c * (P * P);
+        const int ph = rem / P, pw = rem - ph * P;
+        const int y = ty * p.tile + py * P + ph, x = tx * p.tile + px * P + pw;
+        const float u = (y < p.H && x < p.W) ? (float)p.img[((size_t)y * p.W + x) * 3 + c] : 0.f;
+        v = (u * (1.0f / 255.0f) - p.mean[c]) * p.istd[c];
+      }
+      o[e] = v;
+    }
+    const size_t row = (size_t)t * (per_tile + 1) + 1 + pp;
+    *(u32x4*)(p.out + row * p.ld_out + ch * 8) = pack8(o);
+  }
+}
+
+extern "C" int vis_patchify_tiles_u8(const void* img, void* out, int H, int W, int tiles_h, int tiles_w, int tile,
+                                     int ld_out, const float* mean, const float* stdv, hipStream_t stream) {
+  if (!img || !out || !mean || !stdv || H <= 0 || W <= 0 || tiles_h <= 0 || tiles_w <= 0) return VIS_ERR_ARG;
+  if (tile <= 0 || tile % 14 != 0 || H > tiles_h * tile || W > tiles_w * tile) return VIS_ERR_ARG;
+  if (ld_out % 8 != 0 || ld_out < 588 || ((uintptr_t)out & 15)) return VIS_ERR_ARG;
+  TilePatchArgs p;
+  p.img = (const uint8_t*)img; p.out = (bf16_t*)out; p.H = H; p.W = W; p.tiles_h = tiles_h; p.tiles_w = tiles_w;
+  p.tile = tile; p.ld_out = ld_out;
+  for (int c = 0; c < 3; ++c) {
+    if (!(stdv[c] > 0.f)) return VIS_ERR_ARG;
+    p.mean[c] = mean[c];
+    p.istd[c] = 1.0f / stdv[c];
+  }
+  const long long total = (long long)tiles_h * tiles_w * (tile / 14) * (tile / 14) * (ld_out / 8);
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  vis_clear_error();
+  hipLaunchKernelGGL(patchify_tiles_u8_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  return vis_check_launch();
+}
+
+// vis_add_rows_bf16: x[i][:] += table[idx[i]][:]  (f32 add, one rounding) - the per-tile embedding added to every
+// token of a tile (mllama post_tile_positional_embedding, TF:models/mllama/modeling_mllama.py:102-122,:958-961)
+__global__ __launch_bounds__(256) void add_rows_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ table,
+                                                       const int* __restrict__ idx, int n, int D, int ldx,
+                                                       int n_table) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= n) return;
+  int id = idx[row];
+  id = id < 0 ? 0 : (id >= n_table ? n_table - 1 : id);
+  bf16_t* xr = x + (size_t)row * ldx;
+  const bf16_t* tr = table + (size_t)id * D;
+  for (int c = lane; c < (D >> 3); c += 64) {
+    float a[8], b[8];
+    unpack8(*(const u32x4*)(xr + c * 8), a);
+    unpack8(*(const u32x4*)(tr + c * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    *(u32x4*)(xr + c * 8) = pack8(a);
+  }
+}
+
+extern "C" int vis_add_rows_bf16(void* x, const void* table, const void* idx, int n, int D, int ldx, int n_table,
+                                 hipStream_t stream) {
+  if (!x || !table || !idx || n <= 0 || D <= 0 || D % 8 != 0 || ldx % 8 != 0 || ldx < D || n_table <= 0)
+    return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)table) & 15) return VIS_ERR_ARG;
+  vis_clear_error();
+  hipLaunchKernelGGL(add_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, (bf16_t*)x, (const bf16_t*)table,
+                     (const int*)idx, n, D, ldx, n_table);
+  return vis_check_launch();
+}

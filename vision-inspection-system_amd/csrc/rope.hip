@@ -12,6 +12,7 @@
 // Input  : packed projection rows  qkv[S, (Hq+2*Hkv)*HD]  (bias already added
 //          by the GEMM epilogue).
 // Outputs: Q  [Hq ][S][HD]                     (rotated, head-major for attention)
+//          (Hq == 0 or Hkv == 0 select a k/v-only or q-only split; cos == NULL skips the rotation)
 //          K  [Hkv][k_tokens][HD] at row k_pos0+s (rotated; the LLM passes its
 //             KV-cache layer here so prefill writes the cache in place)
 //          V  [Hkv][k_tokens][HD] at row k_pos0+s (optional row-major copy: KV cache)
@@ -58,14 +59,19 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p) {
       float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
       unpack8(*(const u32x4*)(src + d0), a);
       unpack8(*(const u32x4*)(src + HALF + d0), b);
-      const float* cr = p.cosv + (size_t)s * HD;
-      const float* sr = p.sinv + (size_t)s * HD;
+      if (p.cosv) {
+        const float* cr = p.cosv + (size_t)s * HD;
+        const float* sr = p.sinv + (size_t)s * HD;
 #pragma unroll
-      for (int e = 0; e < 8; e += 4) {
-        *(f32x4*)(ca + e) = *(const f32x4*)(cr + d0 + e);
-        *(f32x4*)(sa + e) = *(const f32x4*)(sr + d0 + e);
-        *(f32x4*)(cb + e) = *(const f32x4*)(cr + HALF + d0 + e);
-        *(f32x4*)(sb + e) = *(const f32x4*)(sr + HALF + d0 + e);
+        for (int e = 0; e < 8; e += 4) {
+          *(f32x4*)(ca + e) = *(const f32x4*)(cr + d0 + e);
+          *(f32x4*)(sa + e) = *(const f32x4*)(sr + d0 + e);
+          *(f32x4*)(cb + e) = *(const f32x4*)(cr + HALF + d0 + e);
+          *(f32x4*)(sb + e) = *(const f32x4*)(sr + HALF + d0 + e);
+        }
+      } else {  // no rotary embedding (mllama vision tower, cross-attention q / k): pure head split
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 1.f; sa[e] = 0.f; sb[e] = 0.f; }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -109,10 +115,13 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p) {
 extern "C" int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void* q, void* k,
                                   void* v, void* vt, int S, int ld_qkv, int Hq, int Hkv, int HD,
                                   int k_tokens, int k_pos0, int vt_ld, hipStream_t stream) {
-  if (!qkv || !cosv || !sinv || !q || !k || S <= 0 || Hq <= 0 || Hkv <= 0) return VIS_ERR_ARG;
+  // Hq == 0 (k/v only: cross-attention keys) and Hkv == 0 (q only) are allowed; cos == sin == NULL means no rotation
+  if (!qkv || S <= 0 || Hq < 0 || Hkv < 0 || Hq + Hkv == 0) return VIS_ERR_ARG;
+  if ((cosv == nullptr) != (sinv == nullptr)) return VIS_ERR_ARG;
+  if ((Hq > 0 && !q) || (Hkv > 0 && !k)) return VIS_ERR_ARG;
   if (HD != 128 && HD != 80) return VIS_ERR_ARG;
   if (ld_qkv % 8 != 0 || ld_qkv < (Hq + 2 * Hkv) * HD) return VIS_ERR_ARG;
-  if (k_pos0 < 0 || k_pos0 + S > k_tokens) return VIS_ERR_ARG;
+  if (Hkv > 0 && (k_pos0 < 0 || k_pos0 + S > k_tokens)) return VIS_ERR_ARG;
   if (vt && (vt_ld % 64 != 0 || vt_ld < ((S + 63) / 64) * 64)) return VIS_ERR_ARG;
   if (((uintptr_t)qkv | (uintptr_t)cosv | (uintptr_t)sinv | (uintptr_t)q | (uintptr_t)k | (uintptr_t)v |
        (uintptr_t)vt) & 15)

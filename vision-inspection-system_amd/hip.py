@@ -34,6 +34,9 @@ _SIGS = {
     "vis_skinny_finalize": "p" + "i" + "ppppp" + "iiiiii" + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_resize_rgb_u8": "ppp" + "iiii" + "ppi" + "ppi" + "p",
+    "vis_patchify_tiles_u8": "pp" + "iiiiii" + "pp" + "p",
+    "vis_add_rows_bf16": "ppp" + "iiii" + "p",
+    "vis_decode_cross_attn": "pppppppp" + "iiiii" + "ff" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
 }
@@ -142,19 +145,25 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
 
 
 # --------------------------------------------------------------------------- K4
-def qkv_rope_split(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, q: torch.Tensor,
-                   k: torch.Tensor, v: Optional[torch.Tensor], vt: Optional[torch.Tensor],
-                   n_q: int, n_kv: int, head_dim: int, k_pos0: int = 0) -> None:
-    """qkv [S, (Hq+2Hkv)*HD] -> q [Hq,S,HD], k/v [Hkv,T,HD] rows k_pos0.., vt [Hkv,HD,ld]."""
+def qkv_rope_split(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
+                   q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Optional[torch.Tensor],
+                   vt: Optional[torch.Tensor], n_q: int, n_kv: int, head_dim: int, k_pos0: int = 0) -> None:
+    """qkv [S, (Hq+2Hkv)*HD] -> q [Hq,S,HD], k/v [Hkv,T,HD] rows k_pos0.., vt [Hkv,HD,ld].
+    n_q == 0 (k/v only) or n_kv == 0 (q only) give a partial split; cos = sin = None means no rotation."""
     _bf16(qkv, "qkv")
     S = qkv.shape[0]
-    if cos.dtype != torch.float32 or cos.shape != (S, head_dim) or sin.shape != (S, head_dim):
-        raise HipLibraryError("qkv_rope_split: cos/sin must be f32 [S, head_dim]")
-    if not (cos.is_contiguous() and sin.is_contiguous() and q.is_contiguous() and k.is_contiguous()):
-        raise HipLibraryError("qkv_rope_split: contiguous tensors required")
-    if q.shape != (n_q, S, head_dim) or k.shape[0] != n_kv or k.shape[2] != head_dim:
-        raise HipLibraryError("qkv_rope_split: bad q/k shapes")
-    if v is not None and (v.shape != k.shape or not v.is_contiguous()):
+    if (cos is None) != (sin is None):
+        raise HipLibraryError("qkv_rope_split: give both cos and sin or neither")
+    if cos is not None:
+        if cos.dtype != torch.float32 or cos.shape != (S, head_dim) or sin.shape != (S, head_dim):
+            raise HipLibraryError("qkv_rope_split: cos/sin must be f32 [S, head_dim]")
+        if not (cos.is_contiguous() and sin.is_contiguous()):
+            raise HipLibraryError("qkv_rope_split: contiguous tensors required")
+    if n_q > 0 and (q is None or q.shape != (n_q, S, head_dim) or not q.is_contiguous()):
+        raise HipLibraryError("qkv_rope_split: bad q shape")
+    if n_kv > 0 and (k is None or k.shape[0] != n_kv or k.shape[2] != head_dim or not k.is_contiguous()):
+        raise HipLibraryError("qkv_rope_split: bad k shape")
+    if v is not None and (k is None or v.shape != k.shape or not v.is_contiguous()):
         raise HipLibraryError("qkv_rope_split: bad v shape")
     vt_ld = 0
     if vt is not None:
@@ -162,7 +171,8 @@ def qkv_rope_split(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, q: t
             raise HipLibraryError("qkv_rope_split: bad vt shape")
         vt_ld = vt.shape[2]
     rc = load().vis_qkv_rope_split(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(q), _ptr(k), _ptr(v), _ptr(vt),
-                                   S, qkv.stride(0), n_q, n_kv, head_dim, k.shape[1], k_pos0, vt_ld, _stream())
+                                   S, qkv.stride(0), n_q, n_kv, head_dim, k.shape[1] if k is not None else 0,
+                                   k_pos0, vt_ld, _stream())
     _check(rc, "vis_qkv_rope_split")
 
 
@@ -369,19 +379,19 @@ _STD = (ctypes.c_float * 3)()
 _RESIZE_TABLES: dict = {}
 
 
-def resize_rgb(frame: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
-    """uint8 [H, W, 3] device frame -> uint8 [out_h, out_w, 3], bit-exact with PIL's BICUBIC resize."""
+def resize_rgb(frame: torch.Tensor, out_h: int, out_w: int, kind: str = "bicubic") -> torch.Tensor:
+    """uint8 [H, W, 3] device frame -> uint8 [out_h, out_w, 3], bit-exact with PIL's BICUBIC / BILINEAR resize."""
     from .image_processing import resample_coeffs
     if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3 or not frame.is_contiguous():
         raise HipLibraryError("resize_rgb: contiguous uint8 [H, W, 3] frame required")
     in_h, in_w = int(frame.shape[0]), int(frame.shape[1])
     if (in_h, in_w) == (out_h, out_w):
         return frame
-    key = (in_h, in_w, out_h, out_w, str(frame.device))
+    key = (in_h, in_w, out_h, out_w, kind, str(frame.device))
     tabs = _RESIZE_TABLES.get(key)
     if tabs is None:
-        bx, kx = resample_coeffs(in_w, out_w)
-        by, ky = resample_coeffs(in_h, out_h)
+        bx, kx = resample_coeffs(in_w, out_w, kind)
+        by, ky = resample_coeffs(in_h, out_h, kind)
         tabs = tuple(torch.from_numpy(a).to(frame.device) for a in (kx, bx, ky, by))
         if len(_RESIZE_TABLES) > 32:
             _RESIZE_TABLES.pop(next(iter(_RESIZE_TABLES)))
@@ -393,6 +403,50 @@ def resize_rgb(frame: torch.Tensor, out_h: int, out_w: int) -> torch.Tensor:
                                   kx.shape[1], _ptr(ky), _ptr(by), ky.shape[1], _stream())
     _check(rc, "vis_resize_rgb_u8")
     return dst
+
+
+def patchify_tiles(frame: torch.Tensor, out: torch.Tensor, tiles_h: int, tiles_w: int, tile: int, mean, std) -> None:
+    """mllama: resized uint8 [H, W, 3] frame -> patch rows of the (zero-padded) tiles_h x tiles_w canvas."""
+    if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3 or not frame.is_contiguous():
+        raise HipLibraryError("patchify_tiles: contiguous uint8 [H, W, 3] frame required")
+    _bf16(out, "patchify_tiles out")
+    per = (tile // 14) ** 2 + 1
+    if out.dim() != 2 or out.shape[0] < tiles_h * tiles_w * per or out.stride(1) != 1:
+        raise HipLibraryError("patchify_tiles: output too small")
+    m = (ctypes.c_float * 3)(*mean)
+    sd = (ctypes.c_float * 3)(*std)
+    rc = load().vis_patchify_tiles_u8(_ptr(frame), _ptr(out), frame.shape[0], frame.shape[1], tiles_h, tiles_w, tile,
+                                      out.stride(0), ctypes.cast(m, ctypes.c_void_p), ctypes.cast(sd, ctypes.c_void_p),
+                                      _stream())
+    _check(rc, "vis_patchify_tiles_u8")
+
+
+def add_rows(x: torch.Tensor, table: torch.Tensor, idx: torch.Tensor) -> None:
+    """x[i] += table[idx[i]] (bf16 rows, int32 device indices)."""
+    _bf16(x, "add_rows x"); _bf16(table, "add_rows table")
+    if idx.dtype != torch.int32 or idx.numel() != x.shape[0] or table.shape[1] != x.shape[1] or x.stride(1) != 1 \
+            or not table.is_contiguous():
+        raise HipLibraryError("add_rows: bad shapes")
+    rc = load().vis_add_rows_bf16(_ptr(x), _ptr(table), _ptr(idx), x.shape[0], x.shape[1], x.stride(0),
+                                  table.shape[0], _stream())
+    _check(rc, "vis_add_rows_bf16")
+
+
+def decode_cross_attn(q: torch.Tensor, q_norm_w: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                      nkeys_m1: torch.Tensor, part_o: torch.Tensor, part_ml: torch.Tensor, out: torch.Tensor,
+                      n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float, eps: float) -> None:
+    """One new token's cross-attention over static keys/values k, v [Hkv, T, 128] (q_norm applied inside)."""
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(v, "v")
+    if k.shape != v.shape or k.shape[0] != n_kv or k.shape[2] != head_dim or not (k.is_contiguous() and v.is_contiguous()):
+        raise HipLibraryError("decode_cross_attn: bad k/v")
+    if q.numel() != n_q * head_dim or out.numel() != n_q * head_dim or nkeys_m1.dtype != torch.int32:
+        raise HipLibraryError("decode_cross_attn: bad q/out/nkeys")
+    if part_o.numel() < n_q * nsplit * head_dim or part_ml.numel() < n_q * nsplit * 2:
+        raise HipLibraryError("decode_cross_attn: workspace too small")
+    rc = load().vis_decode_cross_attn(_ptr(q), _ptr(q_norm_w), _ptr(k), _ptr(v), _ptr(nkeys_m1), _ptr(part_o),
+                                      _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, k.shape[1], nsplit, scale, eps,
+                                      _stream())
+    _check(rc, "vis_decode_cross_attn")
 
 
 def patchify(img_u8: torch.Tensor, out: torch.Tensor, row0: int, mean, std) -> None:

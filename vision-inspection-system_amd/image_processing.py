@@ -108,12 +108,24 @@ def _bicubic(x: float) -> float:
     return 0.0
 
 
-def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray]:
-    """Per-output-coordinate windows and fixed-point weights of Pillow's 8-bit bicubic resampling
+def _bilinear(x: float) -> float:
+    """Triangle filter (Pillow's BILINEAR, support 1.0) - what the HF mllama image processor resamples with."""
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return 1.0 - x
+    return 0.0
+
+
+_FILTERS = {"bicubic": (_bicubic, 2.0), "bilinear": (_bilinear, 1.0)}
+
+
+def resample_coeffs(in_size: int, out_size: int, kind: str = "bicubic") -> Tuple[np.ndarray, np.ndarray]:
+    """Per-output-coordinate windows and fixed-point weights of Pillow's 8-bit bicubic / bilinear resampling
     (Pillow 12.2 src/libImaging/Resample.c, precompute_coeffs + normalize_coeffs_8bpc; restated in float64 with
     the same operation order, so the integers are identical).  Returns (bounds int32 [out,2] = {first, taps},
     kk int32 [out, ksize])."""
-    support_f = 2.0
+    filt, support_f = _FILTERS[kind]
     scale = filterscale = in_size / out_size
     if filterscale < 1.0:
         filterscale = 1.0
@@ -132,7 +144,7 @@ def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray
         if xmax > in_size:
             xmax = in_size
         xmax -= xmin
-        w = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        w = [filt((x + xmin - center + 0.5) * ss) for x in range(xmax)]
         ww = 0.0
         for v in w:
             ww += v
@@ -144,14 +156,14 @@ def resample_coeffs(in_size: int, out_size: int) -> Tuple[np.ndarray, np.ndarray
     return bounds, kk
 
 
-def resample_u8_reference(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
+def resample_u8_reference(img: np.ndarray, out_h: int, out_w: int, kind: str = "bicubic") -> np.ndarray:
     """numpy statement of the two integer passes the GPU kernels perform (host logic check, tests only)."""
     in_h, in_w, _ = img.shape
 
     def one_pass(a: np.ndarray, in_size: int, out_size: int) -> np.ndarray:   # resamples axis 1
         if in_size == out_size:
             return a
-        b, k = resample_coeffs(in_size, out_size)
+        b, k = resample_coeffs(in_size, out_size, kind)
         out = np.empty((a.shape[0], out_size, a.shape[2]), dtype=np.uint8)
         for o in range(out_size):
             x0, n = int(b[o, 0]), int(b[o, 1])
