@@ -95,3 +95,29 @@ def test_agents_nodes_batch_on_gpu(local_cfg, images):
         if v["inspector_result"]["analysis_failed"]:
             assert v["safety_verdict"]["verdict"] == "UNSAFE" and "GATE_0_ERROR_STATE" in v["safety_verdict"]["triggered_gates"]
     json.dumps(out, default=str)
+
+
+def test_mllama_backend_through_the_client_and_auditor(local_cfg, images):
+    """Row f2: the Auditor pointed at the mllama family (the reference's HF fallback model) through the same
+    chat.completions seam; tiny synthetic weights -> noise text -> documented failure path, never an exception."""
+    from vision_inspection_system_amd import config as C
+    from vision_inspection_system_amd.agents import VLMAuditorAgent, VLMInspectorAgent
+    from vision_inspection_system_amd.client import LocalVLMClient, get_model
+    from vision_inspection_system_amd.image_processing import encode_image_optimized
+    from vision_inspection_system_amd.schemas import InspectionContext, VLMAnalysisResult
+    c = LocalVLMClient()
+    url = encode_image_optimized(images[2], 256)
+    msgs = [{"role": "user", "content": [{"type": "text", "text": "Verify."},
+                                         {"type": "image_url", "image_url": {"url": url}}]}]
+    r1 = c.chat.completions.create(model="synthetic:mllama-tiny", messages=msgs, temperature=0.0, max_tokens=10)
+    r2 = c.chat.completions.create(model="synthetic:mllama-tiny", messages=msgs, temperature=0.0, max_tokens=10)
+    assert r1.choices[0].message.content == r2.choices[0].message.content
+    assert r1.usage["completion_tokens"] <= 10 and get_model("synthetic:mllama-tiny").family == "mllama"
+    r3 = c.chat.completions.create(model="synthetic:mllama-tiny", messages=[{"role": "user", "content": "OK?"}], max_tokens=5)
+    assert isinstance(r3.choices[0].message.content, str)
+    cfg = C.get_config()
+    cfg.vlm_auditor_model = "synthetic:mllama-tiny"
+    ctx = InspectionContext(image_id="a", criticality="medium")
+    insp = VLMInspectorAgent().analyze(images[0], ctx)
+    aud = VLMAuditorAgent().verify(images[0], ctx, insp)
+    assert isinstance(aud, VLMAnalysisResult)

@@ -64,8 +64,9 @@ _ENGINES_LOCK = threading.Lock()
 class LoadedModel:
     engine: Any
     tokenizer: Any
-    cfg: Qwen2VLConfig
+    cfg: Any
     model_id: str
+    family: str = "qwen2_vl"      # or "mllama" (row f2: the Auditor's Llama-3.2-11B-Vision fallback)
 
 
 def resolve_model_dir(model_id: str) -> Optional[str]:
@@ -97,6 +98,10 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
             return _ENGINES[key]
         max_ctx = int(os.environ.get("VIS_MAX_CTX", "4096"))
         max_batch = max(1, min(16, int(os.environ.get("VIS_MAX_BATCH", "8"))))
+        mllama = _load_mllama(model_id, device, max_ctx)
+        if mllama is not None:
+            _ENGINES[key] = mllama
+            return mllama
         if model_id.startswith("synthetic:"):
             parts = model_id.split(":")
             kind = parts[1]
@@ -123,6 +128,39 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
         lm = LoadedModel(Qwen2VLEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch), tok, cfg, model_id)
         _ENGINES[key] = lm
         return lm
+
+
+def _load_mllama(model_id: str, device, max_ctx: int) -> Optional[LoadedModel]:
+    """mllama family (synthetic:mllama-tiny[:seed], synthetic:mllama-11b, or a local directory whose config.json
+    says model_type "mllama"); None when ``model_id`` is not an mllama model."""
+    import json
+    from . import mllama_weights as MW
+    from .mllama_engine import MllamaEngine
+    from .tokenizer import LlamaByteTokenizer, LlamaHFTokenizer
+    if model_id.startswith("synthetic:mllama"):
+        parts = model_id.split(":")
+        seed = int(parts[2]) if len(parts) > 2 else 0
+        if parts[1] == "mllama-tiny":
+            cfg = MW.MllamaConfig.tiny()
+            w = MW.pack_device_weights(cfg, MW.synth_state_dict(cfg, seed), device)
+            max_ctx = min(max_ctx, 1024)
+        elif parts[1] in ("mllama-11b", "mllama"):
+            cfg = MW.MllamaConfig.mllama_11b()
+            w = MW.random_device_weights(cfg, device, seed)
+        else:
+            raise ValueError(f"unknown synthetic model {parts[1]!r}")
+        tok = LlamaByteTokenizer(cfg.vocab, cfg.image_token_id, cfg.eos_ids)
+        return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx), tok, cfg, model_id, "mllama")
+    path = resolve_model_dir(model_id)
+    if path is None or not os.path.exists(os.path.join(path, "config.json")):
+        return None
+    with open(os.path.join(path, "config.json")) as f:
+        if json.load(f).get("model_type") != "mllama":
+            return None
+    cfg = MW.config_from_hf_dir(path)
+    w = MW.load_safetensors_dir(cfg, path, device)
+    tok = LlamaHFTokenizer(path, cfg.image_token_id, cfg.eos_ids)
+    return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx), tok, cfg, model_id, "mllama")
 
 
 def drop_models() -> None:
@@ -184,6 +222,8 @@ class LocalVLMClient:
         max_new = int(max_tokens) if max_tokens else 512
         temp = float(temperature) if temperature else 0.0
         out: List[ChatCompletion] = []
+        if lm.family == "mllama":
+            return [self._complete_mllama(lm, m, temp, max_new) for m in batch_of_messages]
         prepared = [self._prepare(lm, m) for m in batch_of_messages]
         with eng.lock:
             for i in range(0, len(prepared), eng.max_batch):
@@ -197,6 +237,33 @@ class LocalVLMClient:
                                               usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
                                                      "total_tokens": len(ids) + len(t)}))
         return out
+
+
+    def _complete_mllama(self, lm, messages, temp: float, max_new: int) -> ChatCompletion:
+        """One request through the mllama engine: the JPEG is decoded on the host, the tile canvas is chosen on the
+        host, bilinear resample / normalise / patchify and everything after run on the GPU."""
+        import numpy as np
+        import torch
+        from .image_processing import decode_data_uri
+        from .tokenizer import build_llama_chat_ids
+        frames = []
+        for m in messages:
+            content = m.get("content")
+            if isinstance(content, list):
+                for part in content:
+                    if part.get("type") == "image_url":
+                        url = part["image_url"]["url"] if isinstance(part.get("image_url"), dict) else part["image_url"]
+                        frames.append(np.array(decode_data_uri(url), dtype=np.uint8))
+        if len(frames) > 1:
+            raise ValueError("the mllama backend takes one image per request (what the reference sends)")
+        ids = build_llama_chat_ids(lm.tokenizer, messages, len(frames))
+        eng = lm.engine
+        with eng.lock:
+            frame = torch.from_numpy(frames[0]).to(eng.device) if frames else None
+            toks = eng.generate(ids, frame, max_new_tokens=max_new, temperature=temp, seed=self.seed)
+        return ChatCompletion([_Choice(_Message(lm.tokenizer.decode(toks)))], model=lm.model_id,
+                              usage={"prompt_tokens": len(ids), "completion_tokens": len(toks),
+                                     "total_tokens": len(ids) + len(toks)})
 
 
 class CannedResponseClient:

@@ -283,3 +283,97 @@ def pack_device_weights(cfg: MllamaConfig, sd: Dict[str, torch.Tensor], device) 
     w.norm_w = d(sd[L + "norm.weight"])
     w.lm_head = d(sd["lm_head.weight"])
     return w
+
+
+# ----------------------------------------------------------------------------- other weight sources
+def random_device_weights(cfg: MllamaConfig, device, seed: int = 0, std: float = 0.02) -> MllamaDeviceWeights:
+    """Seeded normal(0, std) bf16 weights generated ON the device at the exact shapes of ``cfg`` (throughput runs:
+    no checkpoint exists offline; timing is valid, generated text is noise).  Norm weights are 1, gates tanh(0.5)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    bf = torch.bfloat16
+
+    def rn(*shape, s=std):
+        return (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * s).to(bf)
+
+    def ones(n):
+        return torch.ones(n, dtype=bf, device=device)
+
+    def zeros(n):
+        return torch.zeros(n, dtype=bf, device=device)
+
+    E, H, D = cfg.v_hidden, cfg.hidden, cfg.head_dim
+    T, P, A = cfg.max_tiles, cfg.tile_tokens, cfg.max_ar_id + 1
+
+    def vlayer():
+        return MllamaVisionLayer(ones(E), zeros(E), ones(E), zeros(E), rn(3 * E, E), rn(E, E), rn(cfg.v_mlp, E),
+                                 rn(cfg.v_mlp), rn(E, cfg.v_mlp), rn(E))
+
+    w = MllamaDeviceWeights(patch_w=pad_cols(rn(E, 3 * cfg.patch * cfg.patch), 64), cls_pos=rn(A, T, P, E),
+                            post_tile=rn(A, T, E), ln_pre_w=ones(E), ln_pre_b=zeros(E), ln_post_w=ones(E),
+                            ln_post_b=zeros(E))
+    w.v_layers = [vlayer() for _ in range(cfg.v_layers)]
+    w.v_global = [vlayer() for _ in range(cfg.v_global_layers)]
+    w.proj_w, w.proj_b = rn(H, cfg.v_out), rn(H)
+    w.embed = rn(cfg.vocab + 8, H)
+    for i in range(cfg.layers):
+        if i in cfg.cross_layers:
+            w.layers.append(MllamaTextLayer(True, ones(H), ones(H), rn(cfg.heads * D, H), rn(2 * cfg.kv_heads * D, H),
+                                            ones(D), ones(D), rn(H, cfg.heads * D), rn(2 * cfg.intermediate, H),
+                                            rn(H, cfg.intermediate)))
+        else:
+            w.layers.append(MllamaTextLayer(False, ones(H), ones(H), rn((cfg.heads + 2 * cfg.kv_heads) * D, H), None,
+                                            None, None, rn(H, cfg.heads * D), rn(2 * cfg.intermediate, H),
+                                            rn(H, cfg.intermediate)))
+    w.norm_w = ones(H)
+    w.lm_head = rn(cfg.vocab, H)
+    return w
+
+
+def config_from_hf_dir(path: str) -> MllamaConfig:
+    """MllamaConfig from a LOCAL HF model directory's config.json (model_type "mllama")."""
+    import json
+    import os
+    with open(os.path.join(path, "config.json")) as f:
+        c = json.load(f)
+    if c.get("model_type") != "mllama":
+        raise ValueError(f"{path}: not an mllama checkpoint (model_type={c.get('model_type')!r})")
+    t, v = c["text_config"], c["vision_config"]
+    rope = t.get("rope_scaling") or t.get("rope_parameters") or {}
+    eos = t.get("eos_token_id", c.get("eos_token_id", [128001, 128008, 128009]))
+    return MllamaConfig(
+        hidden=t["hidden_size"], layers=t["num_hidden_layers"], heads=t["num_attention_heads"],
+        kv_heads=t["num_key_value_heads"], intermediate=t["intermediate_size"], vocab=t["vocab_size"],
+        rms_eps=t.get("rms_norm_eps", 1e-5), rope_theta=t.get("rope_theta", rope.get("rope_theta", 500000.0)),
+        rope_factor=rope.get("factor", 8.0), rope_low_freq=rope.get("low_freq_factor", 1.0),
+        rope_high_freq=rope.get("high_freq_factor", 4.0),
+        rope_orig_ctx=rope.get("original_max_position_embeddings", 8192),
+        cross_layers=tuple(t["cross_attention_layers"]), image_token_id=c.get("image_token_index", 128256),
+        eos_ids=tuple(eos) if isinstance(eos, (list, tuple)) else (eos,),
+        v_hidden=v["hidden_size"], v_heads=v["attention_heads"], v_layers=v["num_hidden_layers"],
+        v_global_layers=v["num_global_layers"], v_mlp=v["intermediate_size"],
+        v_inter=tuple(v["intermediate_layers_indices"]), v_eps=v.get("norm_eps", 1e-5), image_size=v["image_size"],
+        patch=v["patch_size"], max_tiles=v["max_num_tiles"], name=os.path.basename(os.path.normpath(path)))
+
+
+def load_safetensors_dir(cfg: MllamaConfig, path: str, device) -> MllamaDeviceWeights:
+    """Load ``*.safetensors`` shards from a LOCAL model directory (no hub access, ever)."""
+    import glob
+    import os
+    from safetensors import safe_open
+    files = sorted(glob.glob(os.path.join(path, "*.safetensors")))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path} (the local backend only loads local files)")
+    sd: Dict[str, torch.Tensor] = {}
+    for fpath in files:
+        with safe_open(fpath, framework="pt", device="cpu") as f:
+            for k in f.keys():
+                name = k
+                if not k.startswith("model.") and not k.startswith("lm_head"):   # older checkpoints: no "model." prefix
+                    name = "model." + k
+                if name.startswith("model.language_model.model."):
+                    name = "model.language_model." + name[len("model.language_model.model."):]
+                if name == "model.language_model.lm_head.weight":
+                    name = "lm_head.weight"
+                sd[name] = f.get_tensor(k)
+    return pack_device_weights(cfg, sd, device)
