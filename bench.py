@@ -251,8 +251,7 @@ def main():
         e = torch.cuda.Event(enable_timing=True)
         B = args.batch
         s.record()
-        for b in range(B):
-            engine.prefill(ids, [frame], ids_dev=ids_dev, max_new_tokens=new, slot=b)
+        engine.prefill_many([(ids, [frame])] * B, max_new_tokens=new, ids_dev=[ids_dev] * B)
         m.record()
         g = engine._ensure_graph(B) if not args.no_graph else None
         for _ in range(new - 1):

@@ -16,6 +16,7 @@ Stages (kernel ids as in SURVEY.md section 8a):
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -159,6 +160,7 @@ class Qwen2VLEngine:
             self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_part = torch.empty(16 * 16 * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32, device=dev)
         self.slot_prompt_len = [0] * Bm
+        self._prefill_streams: List[torch.cuda.Stream] = []
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -289,12 +291,42 @@ class Qwen2VLEngine:
         if taps is not None:
             taps["first_logits"] = logits.clone()
         step.fill_(S - 1)
-        hip.argmax(logits, self.ws_val, self.ws_idx, tokens, cur_token, step, self.temperature,
-                   self.seed + 0x9E3779B9 * slot)
+        hip.argmax(logits, self.ws_val[256 * slot:256 * (slot + 1)], self.ws_idx[256 * slot:256 * (slot + 1)], tokens,
+                   cur_token, step, self.temperature, self.seed + 0x9E3779B9 * slot)   # per-slot workspace: prefills
+        # of different slots may run concurrently on different streams
         self.slot_prompt_len[slot] = S
         if slot == 0:
             self.prompt_len = S
             self._decoded = 0
+
+    def prefill_many(self, requests: Sequence[Tuple[Sequence[int], Sequence[torch.Tensor]]], temperature: float = 0.0,
+                     seed: int = 0, max_new_tokens: Optional[int] = None,
+                     ids_dev: Optional[Sequence[torch.Tensor]] = None) -> None:
+        """Prefill request b into slot b.  The prefills are independent kernel chains: they are issued round-robin
+        on a few HIP streams (VIS_PREFILL_STREAMS, default 2: 418 -> 381 ms for 8 images) so that the ragged last round of one image's GEMM /
+        attention grids is filled by another image's workgroups.  Returns with the current stream ordered after
+        all of them."""
+        B = len(requests)
+        n_streams = max(1, min(B, int(os.environ.get("VIS_PREFILL_STREAMS", "2"))))
+        if n_streams == 1:
+            for b, (ids, frames) in enumerate(requests):
+                self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
+                             max_new_tokens=max_new_tokens, slot=b)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        if len(self._prefill_streams) < n_streams:
+            self._prefill_streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
+        for st in self._prefill_streams[:n_streams]:
+            st.wait_stream(cur)
+        for b, (ids, frames) in enumerate(requests):
+            st = self._prefill_streams[b % n_streams]
+            with torch.cuda.stream(st):
+                for f in frames:
+                    f.record_stream(st)
+                self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
+                             max_new_tokens=max_new_tokens, slot=b)
+        for st in self._prefill_streams[:n_streams]:
+            cur.wait_stream(st)
 
     # ------------------------------------------------------------------ decode
     def _decode_step(self) -> None:
@@ -424,8 +456,7 @@ class Qwen2VLEngine:
             return [self.generate(ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)]
         longest = max(len(r[0]) for r in requests)
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - longest - 1))
-        for b, (ids, frames) in enumerate(requests):
-            self.prefill(ids, frames, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens, slot=b)
+        self.prefill_many(requests, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
         eos = set(self.cfg.eos_ids)
         starts = [self.slot_prompt_len[b] - 1 for b in range(B)]
 
