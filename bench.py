@@ -91,6 +91,16 @@ def measure_gemv(engine, reps: int = 5):
 
     def gemvs():
         x, x2 = engine.d_x, engine.d_x2
+        if engine.decode_weights == "fp8":
+            for lw, q in zip(w.llm, engine.q8):
+                hip.gemv_fp8(x[0], *q["qkv_w"], engine.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+                hip.gemv_fp8(engine.d_attn, *q["o_w"], x2[0], residual=x[0])
+                hip.gemv_fp8(x2[0], *q["gateup_w"], engine.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
+                hip.gemv_fp8(engine.d_act, *q["down_w"], x[0], residual=x2[0])
+                n[0] += 4
+            hip.gemv_fp8(x[0], *engine.q8_lm_head, engine.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+            n[0] += 1
+            return
         for lw in w.llm:
             hip.gemv(x[0], lw.qkv_w, engine.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
             hip.gemv(engine.d_attn, lw.o_w, x2[0], residual=x[0])
@@ -209,6 +219,9 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: BASELINE configs[4] slice (e4m3 weights for the single-sequence decode GEMVs) - NOT the "
+                         "headline precision; the JSON says so in dtype/config")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per step per GPU; > 1 uses the batched decode path (BASELINE configs[3]/[4] style "
                          "batch inspection) - NOT the headline single-image configuration")
@@ -232,7 +245,8 @@ def main():
 
     cfg = Qwen2VLConfig.qwen2_vl_7b() if args.model == "7b" else Qwen2VLConfig.tiny()
     weights = random_device_weights(cfg, dev, seed=0)
-    engine = Qwen2VLEngine(cfg, weights, dev, max_ctx=4096 if args.model == "7b" else 1024, max_batch=args.batch)
+    engine = Qwen2VLEngine(cfg, weights, dev, max_ctx=4096 if args.model == "7b" else 1024, max_batch=args.batch,
+                           decode_weights=args.decode_weights)
 
     frame_np = synthetic_frame(rank, args.image_size)
     n_patches = (frame_np.shape[0] // cfg.patch) * (frame_np.shape[1] // cfg.patch)
@@ -304,16 +318,22 @@ def main():
         t_pre = sum(s.elapsed_time(m) for s, m, e in pre_ev) / len(pre_ev) * 1e-3
         t_dec = sum(m.elapsed_time(e) for s, m, e in pre_ev) / len(pre_ev) * 1e-3
         gemv_avg, gemv_launches = measure_gemv(engine)
-        bytes_per_launch = gemv_bytes_per_step(cfg) / gemv_launches
+        fp8 = args.decode_weights == "fp8"
+        step_bytes = gemv_bytes_per_step(cfg) / (2 if fp8 else 1)
+        bytes_per_launch = step_bytes / gemv_launches
         achieved = bytes_per_launch / gemv_avg / 1e9
         flops = prefill_flops(cfg, n_patches, S)
         out = {
             "metric": "inspected images/sec (1024x1024, Qwen2-VL-7B)" if args.model == "7b" else "images/sec (tiny)",
             "value": world * args.steps * args.batch / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else "bf16 prefill / fp8-e4m3 decode weights",
+            "data": "synthetic",
             "config": {"workload": (f"configs[1]: Qwen2-VL-7B Inspector bf16, single {args.image_size}x"
                                     f"{args.image_size} image per step per GPU, greedy decode {new} tok")
+                       if args.batch == 1 and not fp8 else
+                       (f"configs[4] slice (NOT the headline precision): Qwen2-VL-7B, bf16 prefill, fp8-e4m3 weights in "
+                        f"the decode GEMVs, single {args.image_size}x{args.image_size} image, greedy decode {new} tok")
                        if args.batch == 1 else
                        (f"batch inspection: {args.batch} x {args.image_size}x{args.image_size} images per step per GPU, "
                         f"per-image prefill + batched decode {new} tok (NOT the headline configuration)"),
@@ -321,14 +341,15 @@ def main():
                        "image_px": args.image_size, "resized_px": list(frame_np.shape[:2]),
                        "image_tokens": n_img_tok, "prompt_tokens": S, "new_tokens": new,
                        "weights": "seeded random bf16 at exact 7B shapes", "parallelism": f"dp{world} (whole images)"},
-            "roofline": {"bound": "hbm", "kernel": "gemv_bf16_kernel (decode weight streaming)",
+            "roofline": {"bound": "hbm", "kernel": ("gemv_fp8w_kernel" if fp8 else "gemv_bf16_kernel") +
+                         " (decode weight streaming)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(), "bytes_per_launch": bytes_per_launch, "avg_launch_us": gemv_avg * 1e6,
+                         "traffic": None if fp8 else measured_traffic(), "bytes_per_launch": bytes_per_launch, "avg_launch_us": gemv_avg * 1e6,
                          "launches_per_token": gemv_launches},
             "prefill_mfma": {"flops": flops, "ms": t_pre * 1e3, "achieved": flops / t_pre / 1e12,
                              "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t_pre / 1e12 / MFMA_BF16_PEAK_TF},
             "decode": {"ms": t_dec * 1e3, "ms_per_token": t_dec / (new - 1) * 1e3,
-                       "weight_GBps": gemv_bytes_per_step(cfg) * (new - 1) / t_dec / 1e9,
+                       "weight_GBps": step_bytes * (new - 1) / t_dec / 1e9,
                        "sequences_per_step": args.batch},
         }
         if not args.no_cpu_baseline and args.model == "7b":

@@ -144,6 +144,14 @@ int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D,
 int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
                      vis_stream_t stream);
 
+/* BASELINE configs[4] slice - fp8 weights for the HBM-bound decode projections ("W8A16"):
+ * y = act((Wq x) * scale + bias) + R with Wq OCP e4m3 bytes [N][ldw] and a per-output-row f32 scale; x bf16 with the
+ * same fused RMSNorm prologue / bias / residual / SwiGLU (16-row interleaved gate/up) / f32-output options as
+ * vis_gemv_bf16.  Halves the bytes per generated token (14.14 GB -> 7.07 GB at 7B). */
+int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* bias, const void* R,
+                  const void* norm_w, void* y, int N, int K, int ldw, int act, int out_f32, float eps,
+                  vis_stream_t stream);
+
 /* ---- Row f2: Llama-3.2-11B-Vision ("mllama") Auditor, reference src/agents/vlm_auditor.py:81-83,:152-158 ---- */
 
 /* Resized RGB frame -> patch rows of the tile canvas (zero padding applied to RAW pixels, then rescale/normalise;

@@ -282,8 +282,11 @@ def embed_inputs(cfg: RefConfig, sd, input_ids: Sequence[int], image_embeds: Opt
 
 def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[int],
              pixel_values: Optional[torch.Tensor], grids, max_new_tokens: int,
-             eos_ids: Sequence[int] = (), taps: Optional[dict] = None):
-    """Greedy decode.  Returns (tokens, per-step logits list [vocab] - entry t produced token t)."""
+             eos_ids: Sequence[int] = (), taps: Optional[dict] = None,
+             decode_sd: Optional[Dict[str, torch.Tensor]] = None):
+    """Greedy decode.  Returns (tokens, per-step logits list [vocab] - entry t produced token t).
+    ``decode_sd``: a second state dict used for the per-token steps only (the prompt still runs on ``sd``) - how the
+    fp8-decode-weights configuration is checked: decode_sd holds the de-quantised e4m3 projections."""
     img = vision_forward(cfg, sd, pixel_values, grids, taps) if pixel_values is not None else None
     x = embed_inputs(cfg, sd, input_ids, img)
     pos3, next_pos = rope_index(cfg, input_ids, grids or [])
@@ -306,6 +309,7 @@ def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[in
             break
         p = torch.full((3, 1), next_pos + t, dtype=torch.long)
         c, s = mrope_cos_sin(cfg, p)
-        h = text_forward(cfg, sd, sd["model.embed_tokens.weight"][tok][None, :], c, s, cache)
-        logits = h[-1] @ sd["lm_head.weight"].t()
+        dsd = decode_sd if decode_sd is not None else sd
+        h = text_forward(cfg, dsd, dsd["model.embed_tokens.weight"][tok][None, :], c, s, cache)
+        logits = h[-1] @ dsd["lm_head.weight"].t()
     return out, all_logits

@@ -126,3 +126,50 @@ def test_batched_generation_matches_single(device):
     # a second batch after the first reuses the captured graph and the slots
     again = eng.generate_batch(reqs[:2], max_new_tokens=6, ignore_eos=True)
     assert again[0] == batch[0][:6] and again[1] == batch[1][:6]
+
+
+def test_fp8_decode_weights_match_oracle_with_dequantised_weights(setup, device):
+    """BASELINE configs[4] slice: decode GEMVs on e4m3 weights.  The oracle runs the prompt on the original weights
+    and the per-token steps on the DE-QUANTISED weights (same quantiser, CPU), so the comparison isolates the kernel:
+    logits of the first fp8 step within LOGIT_TOL, tokens equal up to a near-tie."""
+    from oracle import qwen2vl_ref as R
+    from vision_inspection_system_amd import hip
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import interleave_gate_up, pack_device_weights
+    cfg, sd, _ = setup
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, decode_splits=4,
+                        decode_weights="fp8")
+    g = load_golden()
+    ids = g["ids_a"].tolist()
+    fr = [g["frame_a"]]
+
+    def dq(w):                     # the engine's quantiser, on the CPU
+        q, s = hip.quantize_fp8_rows(w.to(torch.bfloat16))
+        return q.view(torch.float8_e4m3fn).float() * s[:, None]
+
+    dsd = dict(sd)
+    for i in range(cfg.layers):
+        p = f"model.layers.{i}."
+        qkv = dq(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0))
+        nq, nk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+        dsd[p + "self_attn.q_proj.weight"], dsd[p + "self_attn.k_proj.weight"], dsd[p + "self_attn.v_proj.weight"] = \
+            qkv[:nq], qkv[nq:nq + nk], qkv[nq + nk:]
+        dsd[p + "self_attn.o_proj.weight"] = dq(sd[p + "self_attn.o_proj.weight"])
+        gu = dq(interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]))
+        gu = gu.view(cfg.intermediate // 16, 2, 16, cfg.hidden)
+        dsd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(cfg.intermediate, cfg.hidden)
+        dsd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(cfg.intermediate, cfg.hidden)
+        dsd[p + "mlp.down_proj.weight"] = dq(sd[p + "mlp.down_proj.weight"])
+    dsd["lm_head.weight"] = dq(sd["lm_head.weight"])
+    pv, grids = oracle_inputs(fr)
+    ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, pv, grids, 12, decode_sd=dsd)
+    eng.prefill(ids, [torch.from_numpy(f).to(device) for f in fr])
+    eng.decode(1, use_graph=False)
+    assert np.abs(eng.logits.float().cpu().numpy() - ref_logits[1].numpy()).max() < LOGIT_TOL
+    toks = eng.generate(ids, [torch.from_numpy(f).to(device) for f in fr], max_new_tokens=12, ignore_eos=True)
+    assert _check_tokens(toks, ref_toks, ref_logits) >= 4
+    # and fp8 really changes the arithmetic: the bf16 engine's second-step logits differ measurably
+    _, _, eng16 = setup
+    eng16.prefill(ids, [torch.from_numpy(f).to(device) for f in fr])
+    eng16.decode(1, use_graph=False)
+    assert (eng16.logits - eng.logits).abs().max() > 1e-3

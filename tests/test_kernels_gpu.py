@@ -276,6 +276,51 @@ def test_gemv_swiglu(hip, device):
     _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="gemv swiglu")
 
 
+# ----------------------------------------------------------------------------- K10 with fp8 weights (configs[4] slice)
+def _dequant(wq, scale):
+    return wq.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1002, 704), (152064, 3584)])
+def test_gemv_fp8_weights(hip, device, N, K):
+    """Against the SAME quantised weights dequantised in fp32: the kernel's only rounding is bf16 x and f32 sums."""
+    x = _randn((K,), device, 160)
+    w = _randn((N, K), device, 161, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 162)
+    r = _randn((N,), device, 163)
+    wq, sc = hip.quantize_fp8_rows(w)
+    assert wq.dtype == torch.uint8 and wq.shape == (N, K) and sc.shape == (N,)
+    out = torch.empty((N,), dtype=torch.bfloat16, device=device)
+    hip.gemv_fp8(x, wq, sc, out, bias=b, residual=r)
+    ref = _dequant(wq, sc) @ x.float() + b.float() + r.float()
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what="gemv fp8")
+    # and the quantisation itself stays within e4m3's half-ulp of the bf16 weights (relative 2^-4 of the row max)
+    assert ((_dequant(wq, sc) - w.float()).abs().amax(dim=1) <= w.float().abs().amax(dim=1) / 16 + 1e-6).all()
+
+
+def test_gemv_fp8_fused_rmsnorm_swiglu_f32(hip, device):
+    from vision_inspection_system_amd.weights import interleave_gate_up
+    K, I = 256, 704
+    x = _randn((K,), device, 164, 2.0)
+    nw = _randn((K,), device, 165)
+    wg = _randn((I, K), device, 166, 1.0 / math.sqrt(K))
+    wu = _randn((I, K), device, 167, 1.0 / math.sqrt(K))
+    wq, sc = hip.quantize_fp8_rows(interleave_gate_up(wg, wu))
+    out = torch.empty((I,), dtype=torch.bfloat16, device=device)
+    hip.gemv_fp8(x, wq, sc, out, norm_w=nw, act=hip.ACT_SWIGLU, eps=1e-6)
+    xf = x.float()
+    xn = ((xf * torch.rsqrt(xf.pow(2).mean() + 1e-6)).to(torch.bfloat16).float() * nw.float()).to(torch.bfloat16).float()
+    d = _dequant(wq, sc).view(I // 16, 2, 16, K)
+    g, u = d[:, 0].reshape(I, K) @ xn, d[:, 1].reshape(I, K) @ xn
+    _assert_close(out, torch.nn.functional.silu(g) * u, atol=2e-2, rtol=1e-2, what="gemv fp8 swiglu")
+    N = 1536
+    w = _randn((N, K), device, 168, 1.0 / math.sqrt(K))
+    wq, sc = hip.quantize_fp8_rows(w)
+    o32 = torch.empty((N,), dtype=torch.float32, device=device)
+    hip.gemv_fp8(x, wq, sc, o32, norm_w=nw, eps=1e-6)
+    _assert_close(o32, _dequant(wq, sc) @ xn, atol=2e-2, rtol=1e-2, what="gemv fp8 f32 out")
+
+
 # ----------------------------------------------------------------------------- K4/K11 fused decode attention
 @pytest.mark.parametrize("Hq,Hkv,ctx0,steps,T", [(2, 1, 37, 3, 128), (28, 4, 2249, 2, 4096), (28, 4, 127, 3, 256)])
 def test_decode_attention_fused(hip, device, Hq, Hkv, ctx0, steps, T):

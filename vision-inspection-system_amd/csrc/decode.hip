@@ -113,6 +113,21 @@ __device__ __forceinline__ void gv_finish(const GemvArgs& p, bool swiglu, int pa
   }
 }
 
+// x -> LDS for long inputs (K > 8192), all global loads of a thread issued before the first LDS store (K = 18944:
+// 10 chunks per thread; a plain load/store loop serialises ~10 L2 round trips in front of the weight stream).  Unconditional clamped
+// loads (a predicated load makes hipcc drain vmcnt per branch); chunks past the end are simply not stored.
+#define GV_STAGE_MAX 15  // 15 x 256 x 8 = 30720 elements >= the 60 KiB LDS limit of the launchers
+__device__ __forceinline__ void gv_stage_x(const bf16_t* __restrict__ x, bf16_t* xs, int nch, int tid) {
+  u32x4 v[GV_STAGE_MAX];
+#pragma unroll
+  for (int i = 0; i < GV_STAGE_MAX; ++i) v[i] = *(const u32x4*)(x + (size_t)min(tid + i * 256, nch - 1) * 8);
+#pragma unroll
+  for (int i = 0; i < GV_STAGE_MAX; ++i) {
+    const int c = tid + i * 256;
+    if (c < nch) *(u32x4*)(xs + c * 8) = v[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;
@@ -153,6 +168,8 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
       for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f[e] * rstd)) * w[e];
       *(u32x4*)(xs + c * 8) = pack8(o);
     }
+  } else if (nch > 1024) {
+    gv_stage_x(p.x, xs, nch, tid);
   } else {
     for (int c = tid; c < nch; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(p.x + c * 8);
   }
@@ -199,6 +216,227 @@ extern "C" int vis_gemv_bf16(const void* x, const void* W, const void* bias, con
   if (blocks > 2048) blocks = 2048;
   vis_clear_error();
   hipLaunchKernelGGL(gemv_bf16_kernel, dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
+  return vis_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// vis_gemv_fp8w (BASELINE configs[4] slice: fp8 weights for the HBM-bound decode GEMVs, "W8A16"):
+//   y = act((Wq x) * scale + bias) + R,   Wq = OCP e4m3 bytes [N][ldw], scale f32 [N] (per output row)
+// Same structure as vis_gemv_bf16 (x in LDS as bf16, optional fused RMSNorm prologue, weights streamed exactly
+// once with non-temporal 16-byte loads, two register sets in flight), but a 16-byte load now carries 16 weights:
+// v_cvt_scalef32_pk_bf16_fp8 turns each fp8 pair into a bf16 pair EXACTLY (e4m3 has 3 mantissa bits), which feeds
+// the same v_dot2c_f32_bf16.  A task is FOUR rows (two row pairs / two SwiGLU outputs) x 4 chunks per lane, so the
+// bytes in flight per lane match the bf16 kernel although a row is half as long.
+// Algorithmic bytes per launch: N*K (weights) + 4 N (scales).
+// Task shape <ROWS, SEG>: ROWS weight rows x SEG 16-byte chunks per lane per register set.  Short rows (K = 3584:
+// 3.5 chunks per lane) use <4, 4>; projections with few, long rows (down: N = 3584, K = 18944) use <2, 8> so that
+// the grid still has ~7 waves per CU.
+
+struct GemvF8Args {
+  const bf16_t* x;
+  const uint8_t* W;
+  const float* scale;
+  const bf16_t* bias;
+  const bf16_t* R;
+  const bf16_t* norm_w;
+  void* y;
+  int N, K, ldw;
+  int act, out_f32;
+  float eps;
+};
+
+template <int ROWS, int SEG>
+struct GfBuf {
+  u32x4 w[ROWS][SEG];
+};
+
+template <int ROWS>
+__device__ __forceinline__ void gf_rows(const GemvF8Args& p, bool swiglu, int quad, int* r) {
+  if (swiglu) {  // ROWS/2 consecutive outputs of one 16-group: gate rows r[0], r[2], ..., up rows r[1], r[3], ...
+    const int o = (ROWS / 2) * quad;
+    const int g0 = ((o >> 4) << 5) + (o & 15);
+#pragma unroll
+    for (int i = 0; i < ROWS / 2; ++i) { r[2 * i] = g0 + i; r[2 * i + 1] = g0 + 16 + i; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) r[i] = min(ROWS * quad + i, p.N - 1);
+  }
+}
+
+template <int ROWS, int SEG>
+__device__ __forceinline__ void gf_load(GfBuf<ROWS, SEG>& b, const GemvF8Args& p, bool swiglu, int quad, int seg,
+                                        int lane, int nch) {
+  int r[ROWS];
+  gf_rows<ROWS>(p, swiglu, quad, r);
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const uint8_t* w = p.W + (size_t)r[i] * p.ldw;
+#pragma unroll
+    for (int u = 0; u < SEG; ++u) {
+      const int c = min(lane + 64 * (seg * SEG + u), nch - 1);  // unconditional, clamped (see gv_load)
+      b.w[i][u] = __builtin_nontemporal_load((const u32x4*)(w + c * 16));
+    }
+  }
+}
+
+__device__ __forceinline__ float dot16_f8(const u32x4& w, const u32x4& xlo, const u32x4& xhi, float acc) {
+  const bf16x8 xa = __builtin_bit_cast(bf16x8, xlo), xb = __builtin_bit_cast(bf16x8, xhi);
+  // word i of w holds weights 4i..4i+3: low half -> k = 4i, 4i+1; high half -> k = 4i+2, 4i+3
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[0], 1.0f, false), __builtin_shufflevector(xa, xa, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[0], 1.0f, true), __builtin_shufflevector(xa, xa, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[1], 1.0f, false), __builtin_shufflevector(xa, xa, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[1], 1.0f, true), __builtin_shufflevector(xa, xa, 6, 7), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[2], 1.0f, false), __builtin_shufflevector(xb, xb, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[2], 1.0f, true), __builtin_shufflevector(xb, xb, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[3], 1.0f, false), __builtin_shufflevector(xb, xb, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[3], 1.0f, true), __builtin_shufflevector(xb, xb, 6, 7), acc, false);
+  return acc;
+}
+
+template <int ROWS, int SEG>
+__device__ __forceinline__ void gf_consume(const GfBuf<ROWS, SEG>& b, const bf16_t* xs, int seg, int lane, int nch,
+                                           float* a) {
+#pragma unroll
+  for (int u = 0; u < SEG; ++u) {
+    const int c = lane + 64 * (seg * SEG + u);
+    const int cc = min(c, nch - 1);
+    u32x4 xlo = *(const u32x4*)(xs + cc * 16);
+    u32x4 xhi = *(const u32x4*)(xs + cc * 16 + 8);
+    if (c >= nch) { xlo = (u32x4){0u, 0u, 0u, 0u}; xhi = xlo; }  // clamped duplicate chunk contributes nothing
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) a[i] = dot16_f8(b.w[i][u], xlo, xhi, a[i]);
+  }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void gf_finish(const GemvF8Args& p, bool swiglu, int quad, int lane, float* a) {
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) a[i] = wave_sum(a[i]);
+  if (lane != 0) return;
+  int r[ROWS];
+  gf_rows<ROWS>(p, swiglu, quad, r);
+  if (swiglu) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 2; ++i) {
+      const float g = a[2 * i] * p.scale[r[2 * i]], u = a[2 * i + 1] * p.scale[r[2 * i + 1]];
+      ((bf16_t*)p.y)[(ROWS / 2) * quad + i] = f2bf(g / (1.0f + __expf(-g)) * u);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+    const int o = ROWS * quad + i;
+    if (o >= p.N) break;
+    float v = a[i] * p.scale[o];
+    if (p.bias) v += bf2f(p.bias[o]);
+    if (p.R) v += bf2f(p.R[o]);
+    if (p.out_f32) ((float*)p.y)[o] = v;
+    else ((bf16_t*)p.y)[o] = f2bf(v);
+  }
+}
+
+template <int ROWS, int SEG>
+__global__ __launch_bounds__(256) void gemv_fp8w_kernel(GemvF8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* xs = (bf16_t*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nch8 = p.K >> 3;   // 16-byte chunks of x (bf16)
+  const int nch = p.K >> 4;    // 16-byte chunks of a weight row (fp8)
+  const bool swiglu = (p.act == GV_ACT_SWIGLU);
+  const int n_out = swiglu ? (p.N >> 1) : p.N;
+  const int n_quads = swiglu ? (n_out / (ROWS / 2)) : ((n_out + ROWS - 1) / ROWS);
+  const int n_waves = gridDim.x * 4;
+  const int wid = blockIdx.x * 4 + wave;
+  const int q_begin = (int)((long long)n_quads * wid / n_waves);
+  const int q_end = (int)((long long)n_quads * (wid + 1) / n_waves);
+  const int nseg = ((nch + 63) / 64 + SEG - 1) / SEG;
+  const int n_tasks = (q_end - q_begin) * nseg;
+
+  GfBuf<ROWS, SEG> A, B;
+  if (n_tasks > 0) gf_load(A, p, swiglu, q_begin, 0, lane, nch);  // in flight while x is staged
+
+  if (p.norm_w) {
+    float ss = 0.f;
+    for (int c = tid; c < nch8; c += 256) {
+      float f[8];
+      unpack8(*(const u32x4*)(p.x + c * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+    }
+    ss = wave_sum(ss);
+    __shared__ float red[4];
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
+    for (int c = tid; c < nch8; c += 256) {
+      float f[8], w[8], o[8];
+      unpack8(*(const u32x4*)(p.x + c * 8), f);
+      unpack8(*(const u32x4*)(p.norm_w + c * 8), w);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f[e] * rstd)) * w[e];
+      *(u32x4*)(xs + c * 8) = pack8(o);
+    }
+  } else if (nch8 > 1024) {
+    gv_stage_x(p.x, xs, nch8, tid);
+  } else {
+    for (int c = tid; c < nch8; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(p.x + c * 8);
+  }
+  __syncthreads();
+
+  float acc[ROWS];
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+  int quad = q_begin, seg = 0;
+  for (int t = 0; t < n_tasks; t += 2) {
+    int quad1 = quad, seg1 = seg + 1;
+    if (seg1 == nseg) { seg1 = 0; ++quad1; }
+    if (t + 1 < n_tasks) gf_load(B, p, swiglu, quad1, seg1, lane, nch);
+    gf_consume(A, xs, seg, lane, nch, acc);
+    if (seg == nseg - 1) {
+      gf_finish<ROWS>(p, swiglu, quad, lane, acc);
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+    }
+    if (t + 1 >= n_tasks) break;
+    int quad2 = quad1, seg2 = seg1 + 1;
+    if (seg2 == nseg) { seg2 = 0; ++quad2; }
+    if (t + 2 < n_tasks) gf_load(A, p, swiglu, quad2, seg2, lane, nch);
+    gf_consume(B, xs, seg1, lane, nch, acc);
+    if (seg1 == nseg - 1) {
+      gf_finish<ROWS>(p, swiglu, quad1, lane, acc);
+#pragma unroll
+      for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+    }
+    quad = quad2;
+    seg = seg2;
+  }
+}
+
+extern "C" int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* bias, const void* R,
+                             const void* norm_w, void* y, int N, int K, int ldw, int act, int out_f32, float eps,
+                             hipStream_t stream) {
+  if (!x || !Wq || !scale || !y || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % 16 != 0 || ldw % 16 != 0 || ldw < K || K * 2 > 60 * 1024) return VIS_ERR_ARG;
+  if (act != GV_ACT_NONE && act != GV_ACT_SWIGLU) return VIS_ERR_ARG;
+  if (act == GV_ACT_SWIGLU && (N % 64 != 0 || bias || R || out_f32)) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)Wq | (uintptr_t)norm_w) & 15) return VIS_ERR_ARG;
+  if ((uintptr_t)scale & 3) return VIS_ERR_ARG;
+  GemvF8Args p;
+  p.x = (const bf16_t*)x; p.W = (const uint8_t*)Wq; p.scale = (const float*)scale; p.bias = (const bf16_t*)bias;
+  p.R = (const bf16_t*)R; p.norm_w = (const bf16_t*)norm_w; p.y = y;
+  p.N = N; p.K = K; p.ldw = ldw; p.act = act; p.out_f32 = out_f32; p.eps = eps;
+  const int n_out = (act == GV_ACT_SWIGLU) ? N / 2 : N;
+  static const int forced = [] { const char* e = getenv("VIS_GEMV8_SHAPE"); return e ? atoi(e) : 0; }();
+  // long rows and few of them -> 2 rows x 8 chunks per task (more waves); otherwise 4 rows x 4 chunks
+  const bool two = forced ? (forced == 2) : (K >= 8192 || n_out <= 8192);
+  const int rows = two ? 2 : 4;
+  const int n_quads = (act == GV_ACT_SWIGLU) ? n_out / (rows / 2) : (n_out + rows - 1) / rows;
+  int blocks = (n_quads + 3) / 4;   // one task row-group per wave until ~4096 waves, then several per wave
+  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
+  if (blocks > 2048) blocks = 2048;
+  vis_clear_error();
+  if (two) hipLaunchKernelGGL((gemv_fp8w_kernel<2, 8>), dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
+  else hipLaunchKernelGGL((gemv_fp8w_kernel<4, 4>), dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
   return vis_check_launch();
 }
 

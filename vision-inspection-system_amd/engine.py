@@ -112,7 +112,10 @@ class Qwen2VLEngine:
     """One model replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
 
     def __init__(self, cfg: Qwen2VLConfig, weights: DeviceWeights, device, max_ctx: int = 4096,
-                 decode_splits: int = 0, max_batch: int = 1):
+                 decode_splits: int = 0, max_batch: int = 1, decode_weights: str = "bf16"):
+        """decode_weights="fp8" (BASELINE configs[4] slice, also VIS_DECODE_WEIGHTS=fp8): the single-sequence decode
+        step streams OCP-e4m3 copies of the LLM projections and the lm_head (per-output-row f32 scales,
+        hip.quantize_fp8_rows at load time) through vis_gemv_fp8w; prefill and the batched decode keep bf16."""
         cfg.validate_for_kernels()
         hip.load()  # fail loudly when the gfx950 library is missing: there is no other path
         if not torch.cuda.is_available():
@@ -159,6 +162,14 @@ class Qwen2VLEngine:
             self.b_xn = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_part = torch.empty(16 * 16 * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32, device=dev)
+        self.decode_weights = decode_weights
+        if decode_weights not in ("bf16", "fp8"):
+            raise ValueError("decode_weights must be 'bf16' or 'fp8'")
+        self.q8: List[dict] = []
+        if decode_weights == "fp8":
+            for lw in weights.llm:
+                self.q8.append({n: hip.quantize_fp8_rows(getattr(lw, n)) for n in ("qkv_w", "o_w", "gateup_w", "down_w")})
+            self.q8_lm_head = hip.quantize_fp8_rows(weights.lm_head)
         self.slot_prompt_len = [0] * Bm
         self._prefill_streams: List[torch.cuda.Stream] = []
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
@@ -335,6 +346,19 @@ class Qwen2VLEngine:
         scale = D ** -0.5
         hip.gather_rows(w.embed, self.cur_token, self.d_x)
         x, x2 = self.d_x, self.d_x2
+        if self.decode_weights == "fp8":
+            for li, lw in enumerate(w.llm):
+                q = self.q8[li]
+                hip.gemv_fp8(x[0], *q["qkv_w"], self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+                hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
+                                self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
+                hip.gemv_fp8(self.d_attn, *q["o_w"], x2[0], residual=x[0])
+                hip.gemv_fp8(x2[0], *q["gateup_w"], self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
+                hip.gemv_fp8(self.d_act, *q["down_w"], x[0], residual=x2[0])
+            hip.gemv_fp8(x[0], *self.q8_lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+            hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
+                       self.temperature, self.seed)
+            return
         for li, lw in enumerate(w.llm):
             hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
             hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,

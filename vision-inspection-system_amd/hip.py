@@ -27,6 +27,7 @@ _SIGS = {
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
+    "vis_gemv_fp8w": "ppppppp" + "iiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
     "vis_gemm_decode_ksplit": "ii",
@@ -269,6 +270,32 @@ def gemv(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[tor
     rc = load().vis_gemv_bf16(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(out), N, K,
                               w.stride(0), act, 1 if out.dtype == torch.float32 else 0, eps, _stream())
     _check(rc, "vis_gemv_bf16")
+    return out
+
+
+def quantize_fp8_rows(w: torch.Tensor):
+    """bf16/f32 [N, K] -> (OCP e4m3 bytes [N, K] as uint8, f32 per-row scale [N]); scale = amax / 448, RNE cast.
+    Load-time plumbing (torch), not part of the per-token path."""
+    wf = w.float()
+    scale = (wf.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8).contiguous(), scale.contiguous()
+
+
+def gemv_fp8(x: torch.Tensor, wq: torch.Tensor, scale: torch.Tensor, out: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             norm_w: Optional[torch.Tensor] = None, act: int = ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
+    """gemv with fp8 (e4m3) weights + per-row scales; same options as gemv."""
+    _bf16(x, "gemv_fp8 x")
+    N, K = wq.shape
+    if wq.dtype != torch.uint8 or scale.dtype != torch.float32 or scale.numel() != N or x.numel() != K or wq.stride(1) != 1:
+        raise HipLibraryError("gemv_fp8: bad shapes / dtypes")
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if out.numel() != n_out or out.dtype not in (torch.bfloat16, torch.float32):
+        raise HipLibraryError("gemv_fp8: bad output")
+    rc = load().vis_gemv_fp8w(_ptr(x), _ptr(wq), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(out), N, K,
+                              wq.stride(0), act, 1 if out.dtype == torch.float32 else 0, eps, _stream())
+    _check(rc, "vis_gemv_fp8w")
     return out
 
 
