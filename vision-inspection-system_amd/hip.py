@@ -148,8 +148,10 @@ def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
 # --------------------------------------------------------------------------- K4
 def qkv_rope_split(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor],
                    q: Optional[torch.Tensor], k: Optional[torch.Tensor], v: Optional[torch.Tensor],
-                   vt: Optional[torch.Tensor], n_q: int, n_kv: int, head_dim: int, k_pos0: int = 0) -> None:
-    """qkv [S, (Hq+2Hkv)*HD] -> q [Hq,S,HD], k/v [Hkv,T,HD] rows k_pos0.., vt [Hkv,HD,ld].
+                   vt: Optional[torch.Tensor], n_q: int, n_kv: int, head_dim: int, k_pos0: int = 0,
+                   vt_col0: int = 0) -> None:
+    """qkv [S, (Hq+2Hkv)*HD] -> q [Hq,S,HD], k/v [Hkv,T,HD] rows k_pos0.., vt [Hkv,HD,ld] columns vt_col0.. (a
+    multiple of 64: a row-range of a longer sequence writes its own 64-key column blocks).
     n_q == 0 (k/v only) or n_kv == 0 (q only) give a partial split; cos = sin = None means no rotation."""
     _bf16(qkv, "qkv")
     S = qkv.shape[0]
@@ -171,7 +173,10 @@ def qkv_rope_split(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional
         if vt.shape[0] != n_kv or vt.shape[1] != head_dim or not vt.is_contiguous():
             raise HipLibraryError("qkv_rope_split: bad vt shape")
         vt_ld = vt.shape[2]
-    rc = load().vis_qkv_rope_split(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(q), _ptr(k), _ptr(v), _ptr(vt),
+        if vt_col0 % 64 or vt_col0 + (S + 63) // 64 * 64 > vt_ld:
+            raise HipLibraryError("qkv_rope_split: bad vt column offset")
+    vt_ptr = (_ptr(vt) + 2 * vt_col0) if vt is not None else None
+    rc = load().vis_qkv_rope_split(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(q), _ptr(k), _ptr(v), vt_ptr,
                                    S, qkv.stride(0), n_q, n_kv, head_dim, k.shape[1] if k is not None else 0,
                                    k_pos0, vt_ld, _stream())
     _check(rc, "vis_qkv_rope_split")
