@@ -144,6 +144,12 @@ int vis_gather_rows(const void* table, const void* ids, void* out, int n, int D,
 int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, int n_dst,
                      vis_stream_t stream);
 
+/* K2, split-K form for long-K problems whose 256x256 tile count cannot fill the chip (LLM down projection: 126 tiles,
+ * K = 18944): `ksplit` (2..8) K-slices run as independent tiles, f32 partials go to `work` (ksplit*M*N floats), a
+ * second launch sums them in a fixed order and applies bias / act (0..2) / residual.  N % 8 == 0, no SwiGLU. */
+int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* R, void* C, void* work, int M, int N,
+                         int K, int lda, int ldw, int ldc, int ldr, int act, int ksplit, vis_stream_t stream);
+
 /* BASELINE configs[4] slice - fp8 weights for the HBM-bound decode projections ("W8A16"):
  * y = act((Wq x) * scale + bias) + R with Wq OCP e4m3 bytes [N][ldw] and a per-output-row f32 scale; x bf16 with the
  * same fused RMSNorm prologue / bias / residual / SwiGLU (16-row interleaved gate/up) / f32-output options as

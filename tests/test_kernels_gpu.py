@@ -236,6 +236,19 @@ def test_attn_prefill_spiked_max(hip, device):
     _assert_close(out, ref, atol=2e-2, rtol=2e-2, what="attn spiked max")
 
 
+@pytest.mark.parametrize("M,N,K,ks", [(300, 520, 1024, 2), (2249, 3584, 18944, 2), (700, 256, 768, 3)])
+def test_gemm_splitk(hip, device, M, N, K, ks):
+    a = _randn((M, K), device, 30)
+    w = _randn((N, K), device, 31, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 32)
+    r = _randn((M, N), device, 33)
+    work = torch.empty(ks * M * N, dtype=torch.float32, device=device)
+    out = hip.gemm_splitk(a, w, work, ks, bias=b, residual=r)
+    ref = a.float() @ w.float().t() + b.float() + r.float()
+    _assert_close(out, ref, atol=4e-2, rtol=1e-2, what="split-K gemm")
+    assert torch.equal(out, hip.gemm_splitk(a, w, work, ks, bias=b, residual=r))     # fixed order: reproducible
+
+
 # ----------------------------------------------------------------------------- K10 GEMV
 @pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1000, 704)])
 def test_gemv_plain(hip, device, N, K):

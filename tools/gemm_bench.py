@@ -24,4 +24,17 @@ ref = a.float() @ w.float().t()
 err = (out.float() - ref).abs().max().item()
 print(f"max abs err vs fp32 matmul: {err:.4f} (ref max {ref.abs().max().item():.2f})")
 assert err < 0.06 * max(1.0, ref.abs().max().item()), "GEMM mismatch"
+if os.environ.get("VIS_SPLITK"):
+    ks = int(os.environ["VIS_SPLITK"])
+    work = torch.empty(ks * M * N, dtype=torch.float32, device=dev)
+    out2 = torch.empty_like(out)
+    for _ in range(2):
+        hip.gemm_splitk(a, w, work, ks, out=out2)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        hip.gemm_splitk(a, w, work, ks, out=out2)
+    e.record(); torch.cuda.synchronize()
+    t2 = s.elapsed_time(e) / reps * 1e-3
+    print(f"split-K {ks}: {t2*1e3:.3f} ms {2.0*M*N*K/t2/1e12:.1f} TFLOP/s  max diff vs plain {(out2.float()-out.float()).abs().max().item():.4f}")
 print(f"gemm {M}x{N}x{K} tile={os.environ.get('VIS_GEMM_TILE','auto')}: {t*1e3:.3f} ms {2.0*M*N*K/t/1e12:.1f} TFLOP/s")

@@ -385,8 +385,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
     a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
     w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
   }
-  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
-  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  // split-K (p.part != null): grid.y slices of the K range, f32 partial tiles to part[slice][M][N]
+  const int nk_all = p.K / GEMM_BK;
+  const int kt0 = p.part ? (int)((long long)nk_all * blockIdx.y / p.ksplit) : 0;
+  const int kt1 = p.part ? (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit) : nk_all;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda) + (size_t)kt0 * GEMM_BK * 2;
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt0 * GEMM_BK * 2;
   const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
   constexpr int A_BYTES = GEMM4_B * GEMM_BK * 2;  // 32 KiB
 
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
 
-  const int nk = p.K / GEMM_BK;
+  const int nk = kt1 - kt0;
   stage(0, 0);
   stage(1, min(1, nk - 1));
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -490,6 +494,20 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
     mfma32(wf1, af1, 0);
   }
 
+  if (p.part) {  // split-K: raw f32 partial sums, 16-byte stores (lane holds 4 consecutive columns)
+    float* dst = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * h;
+        if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   // epilogue: two 64-row halves through the shared 4x4 epilogue
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
@@ -746,6 +764,42 @@ extern "C" int vis_gemm_decode_ksplit(int N, int K) {
   return slots;
 }
 
+// Split-K second half: C = act(sum_slices part + bias) + R, bf16 out; 8 columns per thread, coalesced.
+__global__ __launch_bounds__(256) void gemm_splitk_finalize_kernel(GemmArgs p) {
+  const int chunks = p.N >> 3;
+  const long long total = (long long)p.M * chunks;
+  const size_t slice = (size_t)p.M * p.N;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int m = (int)(it / chunks), n = (int)(it - (long long)m * chunks) * 8;
+    const float* src = p.part + (size_t)m * p.N + n;
+    float v[8];
+    *(f32x4*)v = *(const f32x4*)src;
+    *(f32x4*)(v + 4) = *(const f32x4*)(src + 4);
+    for (int ks = 1; ks < p.ksplit; ++ks) {
+      const f32x4 a = *(const f32x4*)(src + ks * slice), b = *(const f32x4*)(src + ks * slice + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    if (p.bias) {
+      float f[8];
+      unpack8(*(const u32x4*)(p.bias + n), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+    if (p.act != ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], p.act);
+    }
+    if (p.R) {
+      float f[8];
+      unpack8(*(const u32x4*)(p.R + (size_t)m * p.ldr + n), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+    *(u32x4*)(p.C + (size_t)m * p.ldc + n) = pack8(v);
+  }
+}
+
 // Tile choice, measured on MI355X (tools/gemm_bench.py, tools/kbench.py).  VIS_GEMM_TILE=1|2|4 forces a shape.
 //  * 256x256 (1 WG/CU): best per-tile rate; used when its last round of 256 CUs is at least half full, and for
 //    wide problems (>= 3 rounds) with the ragged remainder columns handed to a second launch (LLM gate/up:
@@ -828,4 +882,36 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   vis_clear_error();
   const int st = gemm_dispatch(p, stream);
   return st != VIS_OK ? st : vis_check_launch();
+}
+
+// Split-K form of vis_gemm_bf16 for long-K problems whose 256x256 tile count is too small to fill the chip
+// (LLM down projection: 9 x 14 = 126 tiles, K = 18944): `ksplit` K-slices run as independent 256x256 tiles
+// (126 x 2 = 252 workgroups), f32 partials go to `work` (ksplit x M x N floats), a second launch sums them and
+// applies bias / activation / residual.  SwiGLU is not supported here.
+extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* R, void* C, void* work,
+                                    int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act, int ksplit,
+                                    hipStream_t stream) {
+  if (!A || !W || !C || !work || M <= 0 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % GEMM_BK != 0 || N % 8 != 0) return VIS_ERR_ARG;
+  if (lda % 8 != 0 || ldw % 8 != 0 || ldc % 8 != 0 || (R && ldr % 8 != 0)) return VIS_ERR_ARG;
+  if (act < ACT_NONE || act >= ACT_SWIGLU) return VIS_ERR_ARG;
+  if (ksplit < 2 || ksplit > 8 || K / GEMM_BK < 2 * ksplit) return VIS_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)R | (uintptr_t)work) & 15) return VIS_ERR_ARG;
+  static const bool attr4_ok = [] {
+    return hipFuncSetAttribute((const void*)gemm_bf16_256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM4_LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr4_ok) return VIS_ERR_LAUNCH;
+  GemmArgs p;
+  p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R; p.C = (bf16_t*)C;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
+  p.part = (float*)work; p.ksplit = ksplit; p.out_f32 = 0;
+  p.tiles_m = (M + GEMM4_B - 1) / GEMM4_B;
+  p.tiles_n = (N + GEMM4_B - 1) / GEMM4_B;
+  vis_clear_error();
+  hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM4_LDS_BYTES, stream, p);
+  const long long total = (long long)M * (N / 8);
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gemm_splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  return vis_check_launch();
 }

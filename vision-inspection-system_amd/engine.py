@@ -341,6 +341,10 @@ class Qwen2VLEngine:
         att = torch.empty((S, Hq * D), dtype=bf, device=dev)
         act = torch.empty((S, cfg.intermediate), dtype=bf, device=dev)
         scale = D ** -0.5
+        tiles4 = ((S + 255) // 256) * ((H + 255) // 256)
+        splitk_work = None
+        if S >= 1024 and cfg.intermediate >= 8192 and 96 <= tiles4 <= 128 and H % 8 == 0:
+            splitk_work = torch.empty(2 * S * H, dtype=torch.float32, device=dev)
         for li, lw in enumerate(w.llm):
             hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
             hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
@@ -349,7 +353,10 @@ class Qwen2VLEngine:
             hip.gemm(att, lw.o_w, residual=x, out=x)
             hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
             hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
-            hip.gemm(act, lw.down_w, residual=x, out=x)
+            if splitk_work is not None:      # long K, too few 256x256 tiles for the chip: two K-slices per tile
+                hip.gemm_splitk(act, lw.down_w, splitk_work, 2, residual=x, out=x)
+            else:
+                hip.gemm(act, lw.down_w, residual=x, out=x)
             if taps is not None and li == 0:
                 taps["layer0"] = x.clone()
         # first token: final norm fused into the lm_head GEMV of the last position only

@@ -22,6 +22,7 @@ ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 _SIGS = {
     "vis_abi_version": "",
     "vis_gemm_bf16": "ppppp" + "iiiiiiii" + "p",
+    "vis_gemm_bf16_splitk": "pppppp" + "iiiiiiiii" + "p",
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
@@ -119,6 +120,26 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
                               a.stride(0), w.stride(0), out.stride(0),
                               residual.stride(0) if residual is not None else 0, act, _stream())
     _check(rc, "vis_gemm_bf16")
+    return out
+
+
+def gemm_splitk(a: torch.Tensor, w: torch.Tensor, work: torch.Tensor, ksplit: int = 2,
+                bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Split-K GEMM (256x256 tiles, f32 partials in ``work``, fixed-order finalisation)."""
+    _bf16(a, "gemm a"); _bf16(w, "gemm w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or a.stride(1) != 1 or w.stride(1) != 1 or act == ACT_SWIGLU:
+        raise HipLibraryError("gemm_splitk: bad operands")
+    if work.dtype != torch.float32 or work.numel() < ksplit * M * N:
+        raise HipLibraryError("gemm_splitk: workspace too small")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.bfloat16, device=a.device)
+    rc = load().vis_gemm_bf16_splitk(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _ptr(work), M, N, K,
+                                     a.stride(0), w.stride(0), out.stride(0),
+                                     residual.stride(0) if residual is not None else 0, act, ksplit, _stream())
+    _check(rc, "vis_gemm_bf16_splitk")
     return out
 
 
