@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] slice (e4m3 weights for the single-sequence decode GEMVs) - NOT the "
                          "headline precision; the JSON says so in dtype/config")
+    ap.add_argument("--prefill-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: BASELINE configs[4] (LLM prompt-pass projections on the fp8 MFMA) - NOT the headline precision")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per step per GPU; > 1 uses the batched decode path (BASELINE configs[3]/[4] style "
                          "batch inspection) - NOT the headline single-image configuration")
@@ -246,7 +248,7 @@ def main():
     cfg = Qwen2VLConfig.qwen2_vl_7b() if args.model == "7b" else Qwen2VLConfig.tiny()
     weights = random_device_weights(cfg, dev, seed=0)
     engine = Qwen2VLEngine(cfg, weights, dev, max_ctx=4096 if args.model == "7b" else 1024, max_batch=args.batch,
-                           decode_weights=args.decode_weights)
+                           decode_weights=args.decode_weights, prefill_dtype=args.prefill_dtype)
 
     frame_np = synthetic_frame(rank, args.image_size)
     n_patches = (frame_np.shape[0] // cfg.patch) * (frame_np.shape[1] // cfg.patch)
@@ -319,6 +321,7 @@ def main():
         t_dec = sum(m.elapsed_time(e) for s, m, e in pre_ev) / len(pre_ev) * 1e-3
         gemv_avg, gemv_launches = measure_gemv(engine)
         fp8 = args.decode_weights == "fp8"
+        p8 = args.prefill_dtype == "fp8"
         step_bytes = gemv_bytes_per_step(cfg) / (2 if fp8 else 1)
         bytes_per_launch = step_bytes / gemv_launches
         achieved = bytes_per_launch / gemv_avg / 1e9
@@ -327,13 +330,15 @@ def main():
             "metric": "inspected images/sec (1024x1024, Qwen2-VL-7B)" if args.model == "7b" else "images/sec (tiny)",
             "value": world * args.steps * args.batch / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not fp8 else "bf16 prefill / fp8-e4m3 decode weights",
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not (fp8 or p8) else
+            f"{'fp8-e4m3 (LLM projections)' if p8 else 'bf16'} prefill / {'fp8-e4m3' if fp8 else 'bf16'} decode weights",
             "data": "synthetic",
             "config": {"workload": (f"configs[1]: Qwen2-VL-7B Inspector bf16, single {args.image_size}x"
                                     f"{args.image_size} image per step per GPU, greedy decode {new} tok")
-                       if args.batch == 1 and not fp8 else
-                       (f"configs[4] slice (NOT the headline precision): Qwen2-VL-7B, bf16 prefill, fp8-e4m3 weights in "
-                        f"the decode GEMVs, single {args.image_size}x{args.image_size} image, greedy decode {new} tok")
+                       if args.batch == 1 and not (fp8 or p8) else
+                       (f"configs[4] (NOT the headline precision): Qwen2-VL-7B, {'fp8 MFMA' if p8 else 'bf16'} LLM prefill, "
+                        f"{'fp8-e4m3' if fp8 else 'bf16'} weights in the decode GEMVs, single {args.image_size}x"
+                        f"{args.image_size} image, greedy decode {new} tok")
                        if args.batch == 1 else
                        (f"batch inspection: {args.batch} x {args.image_size}x{args.image_size} images per step per GPU, "
                         f"per-image prefill + batched decode {new} tok (NOT the headline configuration)"),

@@ -237,15 +237,27 @@ class KVCache:
         return self.k[i], self.v[i]
 
 
+def fake_quant_rows_e4m3(x: torch.Tensor, round_bf16: bool = True) -> torch.Tensor:
+    """Per-row dynamic e4m3 quantise -> de-quantise (scale = amax/448, multiply by the reciprocal, RNE) - the
+    activation side of the fp8 configuration (product: vis_quant_rows_fp8).  The product quantises bf16 tensors."""
+    if round_bf16:
+        x = x.to(torch.bfloat16).float()
+    sc = (x.abs().amax(dim=-1, keepdim=True) / 448.0).clamp_min(1e-12)
+    return (x * (1.0 / sc)).to(torch.float8_e4m3fn).float() * sc
+
+
 def text_forward(cfg: RefConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, cos: torch.Tensor,
                  sin: torch.Tensor, cache: KVCache, taps: Optional[dict] = None,
-                 n_layers: Optional[int] = None) -> torch.Tensor:
-    """x [S, hidden] new-token embeddings; cos/sin [S, head_dim]; returns final-normed hidden [S, hidden]."""
+                 n_layers: Optional[int] = None, act_fp8: bool = False) -> torch.Tensor:
+    """x [S, hidden] new-token embeddings; cos/sin [S, head_dim]; returns final-normed hidden [S, hidden].
+    act_fp8: fake-quantise the input of every projection per row to e4m3 (fp8 prefill configuration; the weights
+    in ``sd`` are then expected to be the de-quantised e4m3 weights)."""
     Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
     S = x.shape[0]
+    fq = fake_quant_rows_e4m3 if act_fp8 else (lambda t: t)
     for i in range(cfg.layers if n_layers is None else n_layers):
         p = f"model.layers.{i}."
-        y = rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_eps)
+        y = fq(rms_norm(x, sd[p + "input_layernorm.weight"], cfg.rms_eps))
         q = (y @ sd[p + "self_attn.q_proj.weight"].t() + sd[p + "self_attn.q_proj.bias"]).reshape(S, Hq, D)
         k = (y @ sd[p + "self_attn.k_proj.weight"].t() + sd[p + "self_attn.k_proj.bias"]).reshape(S, Hkv, D)
         v = (y @ sd[p + "self_attn.v_proj.weight"].t() + sd[p + "self_attn.v_proj.bias"]).reshape(S, Hkv, D)
@@ -259,11 +271,11 @@ def text_forward(cfg: RefConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, c
         mask = torch.ones(S, T, dtype=torch.bool).triu(T - S + 1)
         sc = sc.masked_fill(mask, float("-inf"))
         att = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, dim=-1), vr).reshape(S, Hq * D)
-        x = x + att @ sd[p + "self_attn.o_proj.weight"].t()
-        y = rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_eps)
+        x = x + fq(att) @ sd[p + "self_attn.o_proj.weight"].t()
+        y = fq(rms_norm(x, sd[p + "post_attention_layernorm.weight"], cfg.rms_eps))
         g = y @ sd[p + "mlp.gate_proj.weight"].t()
         u = y @ sd[p + "mlp.up_proj.weight"].t()
-        x = x + (F.silu(g) * u) @ sd[p + "mlp.down_proj.weight"].t()
+        x = x + fq(F.silu(g) * u) @ sd[p + "mlp.down_proj.weight"].t()
         if taps is not None and i == 0:
             taps["layer0"] = x.clone()
     return rms_norm(x, sd["model.norm.weight"], cfg.rms_eps)
@@ -283,7 +295,7 @@ def embed_inputs(cfg: RefConfig, sd, input_ids: Sequence[int], image_embeds: Opt
 def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[int],
              pixel_values: Optional[torch.Tensor], grids, max_new_tokens: int,
              eos_ids: Sequence[int] = (), taps: Optional[dict] = None,
-             decode_sd: Optional[Dict[str, torch.Tensor]] = None):
+             decode_sd: Optional[Dict[str, torch.Tensor]] = None, prefill_fp8_sd: Optional[Dict[str, torch.Tensor]] = None):
     """Greedy decode.  Returns (tokens, per-step logits list [vocab] - entry t produced token t).
     ``decode_sd``: a second state dict used for the per-token steps only (the prompt still runs on ``sd``) - how the
     fp8-decode-weights configuration is checked: decode_sd holds the de-quantised e4m3 projections."""
@@ -295,7 +307,10 @@ def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[in
         taps["position_ids"] = pos3.clone()
         taps["cos"] = cos.clone()
     cache = KVCache(cfg.layers)
-    h = text_forward(cfg, sd, x, cos, sin, cache, taps)
+    if prefill_fp8_sd is not None:   # fp8 prefill configuration: de-quantised weights + fake-quantised activations
+        h = text_forward(cfg, prefill_fp8_sd, x, cos, sin, cache, taps, act_fp8=True)
+    else:
+        h = text_forward(cfg, sd, x, cos, sin, cache, taps)
     if taps is not None:
         taps["final_norm_last"] = h[-1].clone()
     logits = h[-1] @ sd["lm_head.weight"].t()

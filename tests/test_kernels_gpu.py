@@ -249,6 +249,66 @@ def test_gemm_splitk(hip, device, M, N, K, ks):
     assert torch.equal(out, hip.gemm_splitk(a, w, work, ks, bias=b, residual=r))     # fixed order: reproducible
 
 
+# ----------------------------------------------------------------------------- fp8 MFMA GEMM + activation quantiser
+@pytest.mark.parametrize("M,K,norm", [(37, 256, True), (300, 3584, True), (300, 3584, False), (64, 18944, False)])
+def test_quant_rows_fp8(hip, device, M, K, norm):
+    x = _randn((M, K), device, 170, 2.0)
+    nw = _randn((K,), device, 171) if norm else None
+    q, sc = hip.quant_rows_fp8(x, norm_w=nw, eps=1e-6)
+    xf = x.float()
+    if norm:
+        xf = ((xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)).to(torch.bfloat16).float() * nw.float()
+              ).to(torch.bfloat16).float()
+    ref_sc = (xf.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+    assert torch.allclose(sc, ref_sc, rtol=2e-2 if norm else 1e-6, atol=0)     # norm: rstd differs in the last bits
+    ref_q = (xf * (1.0 / sc)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)   # the kernel multiplies by 1/scale
+    mism = (q != ref_q).float().mean().item()
+    assert mism < (2e-2 if norm else 1e-6), f"{mism:.4f} of the bytes differ"        # exact without the norm
+    deq = q.view(torch.float8_e4m3fn).float() * sc[:, None]
+    assert (deq - xf).abs().max() <= xf.abs().amax() / 16 + 1e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 1024), (2249, 4608, 3584), (2249, 3584, 18944), (77, 100, 256)])
+def test_gemm_fp8(hip, device, M, N, K):
+    """Against the SAME quantised operands in fp32: the kernel adds only f32 accumulation-order effects."""
+    a = _randn((M, K), device, 172)
+    w = _randn((N, K), device, 173, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 174)
+    r = _randn((M, N), device, 175)
+    aq, sa = hip.quant_rows_fp8(a)
+    wq, sw = hip.quantize_fp8_rows(w)
+    out = hip.gemm_fp8(aq, sa, wq, sw, bias=b, residual=r)
+    ref = (aq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().t()) * sa[:, None] * sw[None, :] \
+        + b.float() + r.float()
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what=f"gemm fp8 {M}x{N}x{K}")
+    # and the quantised product stays close to the bf16 one (fp8 noise ~ 2^-4 / sqrt(K) per term)
+    full = a.float() @ w.float().t() + b.float() + r.float()
+    assert (out.float() - full).abs().max() < 0.25
+
+
+def test_gemm_fp8_swiglu_and_asymmetric_identity(hip, device):
+    from vision_inspection_system_amd.weights import interleave_gate_up
+    M, K, I = 200, 256, 704
+    a = _randn((M, K), device, 176)
+    wg = _randn((I, K), device, 177, 1.0 / math.sqrt(K))
+    wu = _randn((I, K), device, 178, 1.0 / math.sqrt(K))
+    aq, sa = hip.quant_rows_fp8(a)
+    wq, sw = hip.quantize_fp8_rows(interleave_gate_up(wg, wu))
+    out = hip.gemm_fp8(aq, sa, wq, sw, act=hip.ACT_SWIGLU)
+    d = (wq.view(torch.float8_e4m3fn).float() * sw[:, None]).view(I // 16, 2, 16, K)
+    af = aq.view(torch.float8_e4m3fn).float() * sa[:, None]
+    ref = torch.nn.functional.silu(af @ d[:, 0].reshape(I, K).t()) * (af @ d[:, 1].reshape(I, K).t())
+    _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="gemm fp8 swiglu")
+    # A = I (exact in e4m3) with an asymmetric W: catches row/col swaps in the C write
+    n = 256
+    eye = torch.eye(n, device=device).to(torch.bfloat16)
+    w2 = (torch.arange(n * n, device=device).reshape(n, n) % 15 - 7).to(torch.bfloat16)   # row amax 7 -> scale 1/64: exact in e4m3
+    eq, es = hip.quant_rows_fp8(eye)
+    w2q, w2s = hip.quantize_fp8_rows(w2)
+    o2 = hip.gemm_fp8(eq, es, w2q, w2s)
+    _assert_close(o2, w2.float().t(), atol=1e-2, rtol=1e-2, what="fp8 identity")
+
+
 # ----------------------------------------------------------------------------- K10 GEMV
 @pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1000, 704)])
 def test_gemv_plain(hip, device, N, K):

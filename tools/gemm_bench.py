@@ -24,6 +24,24 @@ ref = a.float() @ w.float().t()
 err = (out.float() - ref).abs().max().item()
 print(f"max abs err vs fp32 matmul: {err:.4f} (ref max {ref.abs().max().item():.2f})")
 assert err < 0.06 * max(1.0, ref.abs().max().item()), "GEMM mismatch"
+if os.environ.get("VIS_FP8"):
+    aq, sa = hip.quant_rows_fp8(a)
+    wq, sw = hip.quantize_fp8_rows(w)
+    o8 = torch.empty_like(out)
+    for _ in range(2):
+        hip.gemm_fp8(aq, sa, wq, sw, out=o8)
+    torch.cuda.synchronize()
+    s.record()
+    for _ in range(reps):
+        hip.gemm_fp8(aq, sa, wq, sw, out=o8)
+    e.record(); torch.cuda.synchronize()
+    t8 = s.elapsed_time(e) / reps * 1e-3
+    s.record()
+    for _ in range(reps):
+        hip.quant_rows_fp8(a, aq, sa)
+    e.record(); torch.cuda.synchronize()
+    tq = s.elapsed_time(e) / reps * 1e-3
+    print(f"fp8 MFMA: {t8*1e3:.3f} ms {2.0*M*N*K/t8/1e12:.1f} TFLOP/s  (quantise A: {tq*1e6:.1f} us)  max diff vs bf16 {(o8.float()-out.float()).abs().max().item():.3f}")
 if os.environ.get("VIS_SPLITK"):
     ks = int(os.environ["VIS_SPLITK"])
     work = torch.empty(ks * M * N, dtype=torch.float32, device=dev)

@@ -1,0 +1,331 @@
+// BASELINE configs[4]: fp8 (OCP e4m3) weights AND activations on the CDNA4 block-scaled MFMA
+// (v_mfma_scale_f32_16x16x128_f8f6f4 with unit E8M0 block scales: 2x the bf16 MFMA rate, MI355X_MICROARCH.md).
+//
+//   C[M, N(/2)] = act((A_q W_q^T) * sa[m] * sw[n] + bias) + R
+//   A_q [M][lda] e4m3 bytes with a per-ROW (per-token) f32 scale sa, W_q [N][ldw] e4m3 bytes with a per-output-row
+//   f32 scale sw (hip.quantize_fp8_rows), f32 accumulation, bf16 output; same epilogues as vis_gemm_bf16.
+//
+// Structure = the 256x256 bf16 kernel (gemm_bf16.hip) with the K-step doubled to 128 elements - which is again 128
+// BYTES per tile row, so the LDS-DMA staging, the source-side XOR swizzle and the two 64 KiB buffers are identical:
+//  * 512 threads = 8 waves (2 x 4), 128 x 64 outputs per wave (8 x 4 MFMA tiles, 128 accumulator VGPRs);
+//  * operand lane map (checked with exact integer data, tools/probes/mfma_f8_probe.hip): lane l holds
+//    X[row l & 15][k = 32 (l >> 4) + j], j = 0..31 - i.e. 16-byte chunks 2h and 2h+1 of its row (two ds_read_b128
+//    at the swizzled positions), 8 VGPRs per tile; C/D as for bf16;
+//  * a K-step is 32 MFMAs of K = 128 per wave.  Its operands are fat (96 VGPRs per K-step), so fragments are NOT
+//    double-buffered across K-steps; instead the step is split by m: [B, A0] -> 16 MFMAs while A1 is read ->
+//    one barrier (all reads of this buffer done, next stage landed) -> refill of this buffer -> 16 MFMAs.
+#include "common.hip.h"
+
+#define F8_B 256
+#define F8_BK 128                                  // K elements = bytes per tile row per K-step
+#define F8_STAGE_BYTES (2 * F8_B * F8_BK)          // 65536
+#define F8_LDS_BYTES (2 * F8_STAGE_BYTES)          // 131072
+
+enum { F8_ACT_NONE = 0, F8_ACT_QUICKGELU = 1, F8_ACT_GELU_ERF = 2, F8_ACT_SWIGLU = 3 };
+
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+struct GemmF8Args {
+  const uint8_t* A;
+  const uint8_t* W;
+  const float* sa;      // [M]
+  const float* sw;      // [N]
+  const bf16_t* bias;   // [N] or null
+  const bf16_t* R;      // [M, ldr] or null
+  bf16_t* C;
+  int M, N, K, lda, ldw, ldc, ldr, act, tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float f8_act(float x, int act) {
+  if (act == F8_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if (act == F8_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  return x;
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char lds8[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * F8_B, n0 = tn * F8_B;
+
+  uint32_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 512 + tid;
+    const int row = c >> 3;
+    const int ch = (c & 7) ^ (row & 7);
+    a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.lda + ch * 16;
+    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.ldw + ch * 16;
+  }
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
+  constexpr int A_BYTES = F8_B * F8_BK;  // 32 KiB
+
+  auto stage = [&](int buf, int kt) {
+    char* base = lds8 + buf * F8_STAGE_BYTES + wave_base;
+    const char* a_k = a_base + kt * F8_BK;
+    const char* w_k = w_base + kt * F8_BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_k + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_k + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8192), 16, 0,
+                                       0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = lane & 7;
+  const int rdlo = l15 * 128 + (((2 * h) ^ sw) << 4);
+  const int rdhi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
+  const int a_rd = wm * 128 * 128;           // + i * 2048
+  const int w_rd = A_BYTES + wn * 64 * 128;  // + j * 2048
+
+  auto frag = [&](const char* p0) -> i32x8 {
+    const u32x4 lo = *(const u32x4*)(p0 + rdlo), hi = *(const u32x4*)(p0 + rdhi);
+    return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+
+  const int nk = p.K / F8_BK;
+  stage(0, 0);
+  stage(1, min(1, nk - 1));
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = lds8 + buf * F8_STAGE_BYTES;
+    i32x8 wf[4], af[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = frag(base + w_rd + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = frag(base + a_rd + i * 2048);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                     0x7f7f7f7f);
+    i32x8 ag[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ag[i] = frag(base + a_rd + (4 + i) * 2048);
+    __builtin_amdgcn_s_setprio(0);
+    // mid: every read of this buffer has landed in registers; the next stage has landed; buffer is dead
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) stage(buf, kt + 2);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], ag[i], acc[4 + i][j], 0, 0, 0,
+                                                                         0x7f7f7f7f, 0, 0x7f7f7f7f);
+    __builtin_amdgcn_s_setprio(0);
+    buf ^= 1;
+  }
+
+  // ---- epilogue: lane holds D[n = nbase + 16 j + 4 h + r][m = mbase + 16 i + l15] (W was the A operand)
+  const bool swiglu = (p.act == F8_ACT_SWIGLU);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = m0 + wm * 128 + i * 16 + l15;
+    if (m >= p.M) continue;
+    const float sam = p.sa[m];
+    if (swiglu) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * h;  // gate rows; the matching up rows are n + 16
+        if (n >= p.N) continue;
+        const int oc = ((n0 + wn * 64) >> 1) + (j >> 1) * 16 + 4 * h;
+        const f32x4 sg = *(const f32x4*)(p.sw + n), su = *(const f32x4*)(p.sw + n + 16);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[i][j][r] * sam * sg[r], u = acc[i][j + 1][r] * sam * su[r];
+          v[r] = g / (1.0f + __expf(-g)) * u;
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + oc) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * h;
+        if (n >= p.N) continue;
+        const f32x4 s4 = *(const f32x4*)(p.sw + n);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sam * s4[r];
+        if (p.bias) {
+          const u32x2 b = *(const u32x2*)(p.bias + n);
+          v[0] += __uint_as_float(b[0] << 16);
+          v[1] += __uint_as_float(b[0] & 0xffff0000u);
+          v[2] += __uint_as_float(b[1] << 16);
+          v[3] += __uint_as_float(b[1] & 0xffff0000u);
+        }
+        if (p.act != F8_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f8_act(v[r], p.act);
+        }
+        if (p.R) {
+          const u32x2 rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
+          v[0] += __uint_as_float(rr[0] << 16);
+          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rr[1] << 16);
+          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, const void* sw, const void* bias,
+                            const void* R, void* C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
+                            hipStream_t stream) {
+  if (!Aq || !sa || !Wq || !sw || !C || M <= 0 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % F8_BK != 0 || N % 4 != 0 || lda % 16 != 0 || ldw % 16 != 0 || lda < K || ldw < K) return VIS_ERR_ARG;
+  if (ldc % 4 != 0 || (R && ldr % 4 != 0)) return VIS_ERR_ARG;
+  if (act < F8_ACT_NONE || act > F8_ACT_SWIGLU) return VIS_ERR_ARG;
+  if (act == F8_ACT_SWIGLU && (N % 32 != 0 || bias || R)) return VIS_ERR_ARG;
+  if (((uintptr_t)Aq | (uintptr_t)Wq | (uintptr_t)sw) & 15) return VIS_ERR_ARG;
+  if (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 7 || ((uintptr_t)sa & 3)) return VIS_ERR_ARG;
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute((const void*)gemm_fp8_256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               F8_LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr_ok) return VIS_ERR_LAUNCH;
+  GemmF8Args p;
+  p.A = (const uint8_t*)Aq; p.W = (const uint8_t*)Wq; p.sa = (const float*)sa; p.sw = (const float*)sw;
+  p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R; p.C = (bf16_t*)C;
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
+  p.tiles_m = (M + F8_B - 1) / F8_B;
+  p.tiles_n = (N + F8_B - 1) / F8_B;
+  vis_clear_error();
+  hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), F8_LDS_BYTES, stream, p);
+  return vis_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// vis_quant_rows_fp8: per-row (per-token) dynamic quantisation of bf16 activations to e4m3:
+//   scale[m] = max(|x[m][:]|) / 448 (>= 1e-12),  q[m][k] = e4m3_rne(x[m][k] / scale[m])
+// with an optional fused RMSNorm in front (norm_w != null: x <- bf16(bf16(x * rstd) * w), exactly the values
+// vis_rmsnorm_bf16 would have written).  One wave per row, the row lives in registers.
+#define QR_MAX_CHUNKS 8  // register-resident rows: K <= 64 * 8 * 8 = 4096 (the fused-norm case); longer rows stream
+
+__device__ __forceinline__ u32x2 qr_pack8(const float* f, float inv) {
+  // v_cvt_pk_fp8_f32: two floats -> two e4m3 bytes (RNE, saturating), into the low or high half of a dword
+  int w0 = 0, w1 = 0;
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, w0, false);
+  w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, w0, true);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, w1, false);
+  w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, w1, true);
+  return (u32x2){(uint32_t)w0, (uint32_t)w1};
+}
+
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ nw,
+                                                             uint8_t* __restrict__ q, float* __restrict__ scale,
+                                                             int rows, int K, int ldx, int ldq, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = K >> 3;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  uint8_t* qr = q + (size_t)row * ldq;
+  if (nch <= 64 * QR_MAX_CHUNKS) {  // the row lives in registers (uniform branch)
+    float v[QR_MAX_CHUNKS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+        unpack8(*(const u32x4*)(xr + c * 8), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+      }
+    }
+    if (nw) {
+      ss = wave_sum(ss);
+      const float rstd = rsqrtf(ss / (float)K + eps);
+#pragma unroll
+      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+          float w[8];
+          unpack8(*(const u32x4*)(nw + c * 8), w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] = bf2f(f2bf(bf2f(f2bf(v[i][e] * rstd)) * w[e]));
+        }
+      }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[i][e]));
+      }
+    }
+    amax = wave_max(amax);
+    const float sc = fmaxf(amax / 448.0f, 1e-12f);
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+#pragma unroll
+    for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) *(u32x2*)(qr + c * 8) = qr_pack8(v[i], inv);
+    }
+  } else {  // long rows (no norm): max pass, then a second pass over the (L2-resident) row
+    float amax = 0.f;
+    for (int c = lane; c < nch; c += 64) {
+      float f[8];
+      unpack8(*(const u32x4*)(xr + c * 8), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+    }
+    amax = wave_max(amax);
+    const float sc = fmaxf(amax / 448.0f, 1e-12f);
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    for (int c = lane; c < nch; c += 64) {
+      float f[8];
+      unpack8(*(const u32x4*)(xr + c * 8), f);
+      *(u32x2*)(qr + c * 8) = qr_pack8(f, inv);
+    }
+  }
+}
+
+extern "C" int vis_quant_rows_fp8(const void* x, const void* norm_w, void* q, void* scale, int rows, int K, int ldx,
+                                  int ldq, float eps, hipStream_t stream) {
+  if (!x || !q || !scale || rows <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % 8 != 0 || ldx % 8 != 0 || ldq % 8 != 0 || ldq < K) return VIS_ERR_ARG;
+  if (norm_w && K > 64 * 8 * QR_MAX_CHUNKS) return VIS_ERR_ARG;  // the fused norm needs the row in registers
+  if (((uintptr_t)x | (uintptr_t)norm_w) & 15 || ((uintptr_t)q & 7) || ((uintptr_t)scale & 3)) return VIS_ERR_ARG;
+  vis_clear_error();
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x,
+                     (const bf16_t*)norm_w, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
+  return vis_check_launch();
+}

@@ -112,7 +112,8 @@ class Qwen2VLEngine:
     """One model replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
 
     def __init__(self, cfg: Qwen2VLConfig, weights: DeviceWeights, device, max_ctx: int = 4096,
-                 decode_splits: int = 0, max_batch: int = 1, decode_weights: str = "bf16"):
+                 decode_splits: int = 0, max_batch: int = 1, decode_weights: str = "bf16",
+                 prefill_dtype: str = "bf16"):
         """decode_weights="fp8" (BASELINE configs[4] slice, also VIS_DECODE_WEIGHTS=fp8): the single-sequence decode
         step streams OCP-e4m3 copies of the LLM projections and the lm_head (per-output-row f32 scales,
         hip.quantize_fp8_rows at load time) through vis_gemv_fp8w; prefill and the batched decode keep bf16."""
@@ -166,10 +167,23 @@ class Qwen2VLEngine:
         if decode_weights not in ("bf16", "fp8"):
             raise ValueError("decode_weights must be 'bf16' or 'fp8'")
         self.q8: List[dict] = []
-        if decode_weights == "fp8":
+        self.prefill_dtype = prefill_dtype
+        if prefill_dtype not in ("bf16", "fp8"):
+            raise ValueError("prefill_dtype must be 'bf16' or 'fp8'")
+        if decode_weights == "fp8" or prefill_dtype == "fp8":
             for lw in weights.llm:
                 self.q8.append({n: hip.quantize_fp8_rows(getattr(lw, n)) for n in ("qkv_w", "o_w", "gateup_w", "down_w")})
             self.q8_lm_head = hip.quantize_fp8_rows(weights.lm_head)
+        if prefill_dtype == "fp8":     # fp8 MFMA needs K % 128 == 0: zero-pad the down projection's K if necessary
+            self.kpad = _round_up(cfg.intermediate, 128)
+            if self.kpad != cfg.intermediate:
+                for q in self.q8:
+                    wq, sc = q["down_w"]
+                    pad = torch.zeros((wq.shape[0], self.kpad), dtype=torch.uint8, device=wq.device)
+                    pad[:, :cfg.intermediate] = wq
+                    q["down_w_pad"] = (pad, sc)
+            if cfg.hidden % 128 or (cfg.heads * cfg.head_dim) % 128:
+                raise ValueError("fp8 prefill needs hidden and heads*head_dim to be multiples of 128")
         self.slot_prompt_len = [0] * Bm
         self._prefill_streams: List[torch.cuda.Stream] = []
         self._vit_side_streams: List[torch.cuda.Stream] = []
@@ -345,20 +359,23 @@ class Qwen2VLEngine:
         splitk_work = None
         if S >= 1024 and cfg.intermediate >= 8192 and 96 <= tiles4 <= 128 and H % 8 == 0:
             splitk_work = torch.empty(2 * S * H, dtype=torch.float32, device=dev)
-        for li, lw in enumerate(w.llm):
-            hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
-            hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
-            hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=0)
-            hip.attn_prefill(q, kcache[li], vt, att, work, True, scale)
-            hip.gemm(att, lw.o_w, residual=x, out=x)
-            hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
-            hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
-            if splitk_work is not None:      # long K, too few 256x256 tiles for the chip: two K-slices per tile
-                hip.gemm_splitk(act, lw.down_w, splitk_work, 2, residual=x, out=x)
-            else:
-                hip.gemm(act, lw.down_w, residual=x, out=x)
-            if taps is not None and li == 0:
-                taps["layer0"] = x.clone()
+        if self.prefill_dtype == "fp8":
+            self._llm_layers_fp8(x, qkv, q, vt, att, act, cos, sin, kcache, vcache, work, S, taps)
+        else:
+            for li, lw in enumerate(w.llm):
+                hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
+                hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
+                hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=0)
+                hip.attn_prefill(q, kcache[li], vt, att, work, True, scale)
+                hip.gemm(att, lw.o_w, residual=x, out=x)
+                hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
+                hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
+                if splitk_work is not None:      # long K, too few 256x256 tiles for the chip: two K-slices per tile
+                    hip.gemm_splitk(act, lw.down_w, splitk_work, 2, residual=x, out=x)
+                else:
+                    hip.gemm(act, lw.down_w, residual=x, out=x)
+                if taps is not None and li == 0:
+                    taps["layer0"] = x.clone()
         # first token: final norm fused into the lm_head GEMV of the last position only
         hip.gemv(x[S - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
         if taps is not None:
@@ -371,6 +388,30 @@ class Qwen2VLEngine:
         if slot == 0:
             self.prompt_len = S
             self._decoded = 0
+
+    def _llm_layers_fp8(self, x, qkv, q, vt, att, act, cos, sin, kcache, vcache, work, S, taps) -> None:
+        """The decoder layers of the prompt pass with every projection on the fp8 MFMA (configs[4])."""
+        cfg, w, dev = self.cfg, self.w, self.device
+        H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
+        scale = D ** -0.5
+        xq = torch.empty((S, H), dtype=torch.uint8, device=dev)
+        aq = torch.empty((S, Hq * D), dtype=torch.uint8, device=dev)
+        hq = torch.zeros((S, self.kpad), dtype=torch.uint8, device=dev)      # pad columns stay 0 (= +0.0 in e4m3)
+        sx = torch.empty(S, dtype=torch.float32, device=dev)
+        for li, lw in enumerate(w.llm):
+            q8 = self.q8[li]
+            hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+            hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=lw.qkv_b, out=qkv)
+            hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=0)
+            hip.attn_prefill(q, kcache[li], vt, att, work, True, scale)
+            hip.quant_rows_fp8(att, aq, sx)
+            hip.gemm_fp8(aq, sx, *q8["o_w"], residual=x, out=x)
+            hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln2_w, eps=cfg.rms_eps)
+            hip.gemm_fp8(xq, sx, *q8["gateup_w"], act=hip.ACT_SWIGLU, out=act)
+            hip.quant_rows_fp8(act, hq[:, :cfg.intermediate], sx)
+            hip.gemm_fp8(hq, sx, *q8.get("down_w_pad", q8["down_w"]), residual=x, out=x)
+            if taps is not None and li == 0:
+                taps["layer0"] = x.clone()
 
     def prefill_many(self, requests: Sequence[Tuple[Sequence[int], Sequence[torch.Tensor]]], temperature: float = 0.0,
                      seed: int = 0, max_new_tokens: Optional[int] = None,

@@ -23,6 +23,8 @@ _SIGS = {
     "vis_abi_version": "",
     "vis_gemm_bf16": "ppppp" + "iiiiiiii" + "p",
     "vis_gemm_bf16_splitk": "pppppp" + "iiiiiiiii" + "p",
+    "vis_gemm_fp8": "ppppppp" + "iiiiiiii" + "p",
+    "vis_quant_rows_fp8": "pppp" + "iiii" + "f" + "p",
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
@@ -140,6 +142,45 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, work: torch.Tensor, ksplit: in
                                      a.stride(0), w.stride(0), out.stride(0),
                                      residual.stride(0) if residual is not None else 0, act, ksplit, _stream())
     _check(rc, "vis_gemm_bf16_splitk")
+    return out
+
+
+def quant_rows_fp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
+                   norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6):
+    """bf16 [M, K] -> (e4m3 bytes [M, K] uint8, f32 row scales [M]) on the GPU; optional fused RMSNorm in front."""
+    _bf16(x, "quant_rows_fp8 x")
+    M, K = x.shape
+    if q is None:
+        q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
+    if scale is None:
+        scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    if q.dtype != torch.uint8 or q.shape != (M, K) or q.stride(1) != 1 or scale.numel() != M or x.stride(1) != 1:
+        raise HipLibraryError("quant_rows_fp8: bad shapes")
+    rc = load().vis_quant_rows_fp8(_ptr(x), _ptr(norm_w), _ptr(q), _ptr(scale), M, K, x.stride(0), q.stride(0), eps,
+                                   _stream())
+    _check(rc, "vis_quant_rows_fp8")
+    return q, scale
+
+
+def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor,
+             bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N(/2)] = act((aq @ wq.T) * sa[:, None] * sw[None, :] + bias) + residual on the fp8 MFMA."""
+    M, K = aq.shape
+    N = wq.shape[0]
+    if aq.dtype != torch.uint8 or wq.dtype != torch.uint8 or wq.shape[1] != K or aq.stride(1) != 1 or wq.stride(1) != 1:
+        raise HipLibraryError("gemm_fp8: uint8 (e4m3) operands [M,K] / [N,K] required")
+    if sa.dtype != torch.float32 or sw.dtype != torch.float32 or sa.numel() != M or sw.numel() != N:
+        raise HipLibraryError("gemm_fp8: bad scales")
+    n_out = N // 2 if act == ACT_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.bfloat16, device=aq.device)
+    if out.shape != (M, n_out) or out.stride(1) != 1:
+        raise HipLibraryError("gemm_fp8: bad output shape")
+    rc = load().vis_gemm_fp8(_ptr(aq), _ptr(sa), _ptr(wq), _ptr(sw), _ptr(bias), _ptr(residual), _ptr(out), M, N, K,
+                             aq.stride(0), wq.stride(0), out.stride(0),
+                             residual.stride(0) if residual is not None else 0, act, _stream())
+    _check(rc, "vis_gemm_fp8")
     return out
 
 
