@@ -160,9 +160,12 @@ int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* 
 
 /* BASELINE configs[4]: GEMM on the CDNA4 block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales).
  * C[M, N(/2)] = act((Aq Wq^T) * sa[m] * sw[n] + bias) + R with Aq [M][lda] / Wq [N][ldw] OCP e4m3 bytes, per-row f32
- * scales sa [M] (per token, vis_quant_rows_fp8) and sw [N] (per output channel); act as vis_gemm_bf16; K % 128 == 0. */
+ * scales sa [M] (per token, vis_quant_rows_fp8) and sw [N] (per output channel); act as vis_gemm_bf16; K % 128 == 0.
+ * work != NULL: split-K over `ksplit` (2..8) K-slices with f32 partials in work (ksplit*M*N floats) and a fixed-order
+ * finalisation (long-K problems with too few 256x256 tiles; N % 8 == 0, no SwiGLU); work == NULL: single pass. */
 int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, const void* sw, const void* bias, const void* R,
-                 void* C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act, vis_stream_t stream);
+                 void* C, void* work, int ksplit, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
+                 vis_stream_t stream);
 
 /* Per-row dynamic quantisation of bf16 activations to e4m3: scale[m] = amax(row)/448, q = rne(x/scale); with norm_w
  * != NULL the row is RMS-normalised first (same values vis_rmsnorm_bf16 writes; K <= 4096). */

@@ -281,6 +281,10 @@ def test_gemm_fp8(hip, device, M, N, K):
     ref = (aq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().t()) * sa[:, None] * sw[None, :] \
         + b.float() + r.float()
     _assert_close(out, ref, atol=3e-2, rtol=1e-2, what=f"gemm fp8 {M}x{N}x{K}")
+    if N % 8 == 0 and K >= 512:          # split-K form: same result up to the f32 summation order
+        work = torch.empty(2 * M * N, dtype=torch.float32, device=device)
+        o2 = hip.gemm_fp8(aq, sa, wq, sw, bias=b, residual=r, work=work, ksplit=2)
+        _assert_close(o2, ref, atol=3e-2, rtol=1e-2, what=f"gemm fp8 split-K {M}x{N}x{K}")
     # and the quantised product stays close to the bf16 one (fp8 noise ~ 2^-4 / sqrt(K) per term)
     full = a.float() @ w.float().t() + b.float() + r.float()
     assert (out.float() - full).abs().max() < 0.25

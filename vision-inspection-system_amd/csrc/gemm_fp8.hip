@@ -34,6 +34,8 @@ struct GemmF8Args {
   const bf16_t* R;      // [M, ldr] or null
   bf16_t* C;
   int M, N, K, lda, ldw, ldc, ldr, act, tiles_m, tiles_n;
+  float* part;   // split-K: f32 partial sums [ksplit][M][N] (unscaled), or null
+  int ksplit;
 };
 
 __device__ __forceinline__ float f8_act(float x, int act) {
@@ -64,8 +66,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
     a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.lda + ch * 16;
     w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.ldw + ch * 16;
   }
-  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
-  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  const int nk_all = p.K / F8_BK;
+  const int kt0 = p.part ? (int)((long long)nk_all * blockIdx.y / p.ksplit) : 0;
+  const int kt1 = p.part ? (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit) : nk_all;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda) + (size_t)kt0 * F8_BK;
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt0 * F8_BK;
   const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
   constexpr int A_BYTES = F8_B * F8_BK;  // 32 KiB
 
@@ -101,24 +106,26 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
     return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
   };
 
-  const int nk = p.K / F8_BK;
+  const int nk = kt1 - kt0;
   stage(0, 0);
   stage(1, min(1, nk - 1));
   asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   int buf = 0;
+  i32x8 af[4];   // A rows 0..63 of the wave's tile for the CURRENT K-step (read one half-step ahead)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) af[i] = frag(lds8 + a_rd + i * 2048);
   for (int kt = 0; kt < nk; ++kt) {
     const char* base = lds8 + buf * F8_STAGE_BYTES;
-    i32x8 wf[4], af[4];
+    i32x8 wf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) wf[j] = frag(base + w_rd + j * 2048);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = frag(base + a_rd + i * 2048);
     __builtin_amdgcn_s_setprio(1);
+    // phase A: column-major over the W fragments, so the first MFMAs start as soon as wf[0] has landed
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int i = 0; i < 4; ++i)
         acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
                                                                      0x7f7f7f7f);
     i32x8 ag[4];
@@ -131,16 +138,36 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
     __builtin_amdgcn_s_barrier();
     if (kt + 2 < nk) stage(buf, kt + 2);
     __builtin_amdgcn_s_setprio(1);
+    // phase B: rows 64..127; the next K-step's rows 0..63 are read underneath (af is free since phase A)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
         acc[4 + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], ag[i], acc[4 + i][j], 0, 0, 0,
                                                                          0x7f7f7f7f, 0, 0x7f7f7f7f);
+    if (kt + 1 < nk) {
+      const char* nb = lds8 + (buf ^ 1) * F8_STAGE_BYTES;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag(nb + a_rd + i * 2048);
+    }
     __builtin_amdgcn_s_setprio(0);
     buf ^= 1;
   }
 
+  if (p.part) {  // split-K: raw (unscaled) f32 partial sums; the finalize kernel applies scales and the epilogue
+    float* dst = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wm * 128 + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + 4 * h;
+        if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane holds D[n = nbase + 16 j + 4 h + r][m = mbase + 16 i + l15] (W was the A operand)
   const bool swiglu = (p.act == F8_ACT_SWIGLU);
 #pragma unroll
@@ -202,9 +229,50 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
   }
 }
 
+// split-K second half: C = act((sum_slices part) * sa[m] * sw[n] + bias) + R
+__global__ __launch_bounds__(256) void gemm_fp8_splitk_finalize_kernel(GemmF8Args p) {
+  const int chunks = p.N >> 3;
+  const long long total = (long long)p.M * chunks;
+  const size_t slice = (size_t)p.M * p.N;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int m = (int)(it / chunks), n = (int)(it - (long long)m * chunks) * 8;
+    const float* src = p.part + (size_t)m * p.N + n;
+    float v[8];
+    *(f32x4*)v = *(const f32x4*)src;
+    *(f32x4*)(v + 4) = *(const f32x4*)(src + 4);
+    for (int ks = 1; ks < p.ksplit; ++ks) {
+      const f32x4 a = *(const f32x4*)(src + ks * slice), b = *(const f32x4*)(src + ks * slice + 4);
+      v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+      v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+    }
+    const float sam = p.sa[m];
+    const f32x4 s0 = *(const f32x4*)(p.sw + n), s1 = *(const f32x4*)(p.sw + n + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] *= sam * s0[e]; v[4 + e] *= sam * s1[e]; }
+    if (p.bias) {
+      float f[8];
+      unpack8(*(const u32x4*)(p.bias + n), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+    if (p.act != F8_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f8_act(v[e], p.act);
+    }
+    if (p.R) {
+      float f[8];
+      unpack8(*(const u32x4*)(p.R + (size_t)m * p.ldr + n), f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += f[e];
+    }
+    *(u32x4*)(p.C + (size_t)m * p.ldc + n) = pack8(v);
+  }
+}
+
+// work != NULL with ksplit in 2..8: split-K (f32 partials in `work`, ksplit*M*N floats; needs N % 8 == 0, no SwiGLU)
 extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, const void* sw, const void* bias,
-                            const void* R, void* C, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
-                            hipStream_t stream) {
+                            const void* R, void* C, void* work, int ksplit, int M, int N, int K, int lda, int ldw,
+                            int ldc, int ldr, int act, hipStream_t stream) {
   if (!Aq || !sa || !Wq || !sw || !C || M <= 0 || N <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % F8_BK != 0 || N % 4 != 0 || lda % 16 != 0 || ldw % 16 != 0 || lda < K || ldw < K) return VIS_ERR_ARG;
   if (ldc % 4 != 0 || (R && ldr % 4 != 0)) return VIS_ERR_ARG;
@@ -223,8 +291,21 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
   p.tiles_m = (M + F8_B - 1) / F8_B;
   p.tiles_n = (N + F8_B - 1) / F8_B;
+  p.part = nullptr; p.ksplit = 1;
+  if (work) {
+    if (ksplit < 2 || ksplit > 8 || K / F8_BK < 2 * ksplit || N % 8 != 0 || ldc % 8 != 0 || (R && ldr % 8 != 0) ||
+        act == F8_ACT_SWIGLU || ((uintptr_t)work & 15) || (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 15))
+      return VIS_ERR_ARG;
+    p.part = (float*)work; p.ksplit = ksplit;
+  }
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), F8_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(p.tiles_m * p.tiles_n, p.ksplit), dim3(512), F8_LDS_BYTES, stream,
+                     p);
+  if (work) {
+    const long long total = (long long)M * (N / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gemm_fp8_splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  }
   return vis_check_launch();
 }
 

@@ -398,6 +398,9 @@ class Qwen2VLEngine:
         aq = torch.empty((S, Hq * D), dtype=torch.uint8, device=dev)
         hq = torch.zeros((S, self.kpad), dtype=torch.uint8, device=dev)      # pad columns stay 0 (= +0.0 in e4m3)
         sx = torch.empty(S, dtype=torch.float32, device=dev)
+        tiles4 = ((S + 255) // 256) * ((H + 255) // 256)
+        dwork = torch.empty(2 * S * H, dtype=torch.float32, device=dev) \
+            if (S >= 1024 and self.kpad >= 8192 and 96 <= tiles4 <= 128 and H % 8 == 0) else None
         for li, lw in enumerate(w.llm):
             q8 = self.q8[li]
             hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln1_w, eps=cfg.rms_eps)
@@ -409,7 +412,7 @@ class Qwen2VLEngine:
             hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln2_w, eps=cfg.rms_eps)
             hip.gemm_fp8(xq, sx, *q8["gateup_w"], act=hip.ACT_SWIGLU, out=act)
             hip.quant_rows_fp8(act, hq[:, :cfg.intermediate], sx)
-            hip.gemm_fp8(hq, sx, *q8.get("down_w_pad", q8["down_w"]), residual=x, out=x)
+            hip.gemm_fp8(hq, sx, *q8.get("down_w_pad", q8["down_w"]), residual=x, out=x, work=dwork, ksplit=2)
             if taps is not None and li == 0:
                 taps["layer0"] = x.clone()
 

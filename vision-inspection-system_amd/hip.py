@@ -23,7 +23,7 @@ _SIGS = {
     "vis_abi_version": "",
     "vis_gemm_bf16": "ppppp" + "iiiiiiii" + "p",
     "vis_gemm_bf16_splitk": "pppppp" + "iiiiiiiii" + "p",
-    "vis_gemm_fp8": "ppppppp" + "iiiiiiii" + "p",
+    "vis_gemm_fp8": "pppppppp" + "iiiiiiiii" + "p",
     "vis_quant_rows_fp8": "pppp" + "iiii" + "f" + "p",
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
@@ -164,8 +164,9 @@ def quant_rows_fp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scale: Opt
 
 def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor,
              bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
-             out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, N(/2)] = act((aq @ wq.T) * sa[:, None] * sw[None, :] + bias) + residual on the fp8 MFMA."""
+             out: Optional[torch.Tensor] = None, work: Optional[torch.Tensor] = None, ksplit: int = 0) -> torch.Tensor:
+    """out[M, N(/2)] = act((aq @ wq.T) * sa[:, None] * sw[None, :] + bias) + residual on the fp8 MFMA.
+    ``work`` (f32, >= ksplit*M*N) + ``ksplit`` select the split-K form."""
     M, K = aq.shape
     N = wq.shape[0]
     if aq.dtype != torch.uint8 or wq.dtype != torch.uint8 or wq.shape[1] != K or aq.stride(1) != 1 or wq.stride(1) != 1:
@@ -177,7 +178,10 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, wq: torch.Tensor, sw: torch.Ten
         out = torch.empty((M, n_out), dtype=torch.bfloat16, device=aq.device)
     if out.shape != (M, n_out) or out.stride(1) != 1:
         raise HipLibraryError("gemm_fp8: bad output shape")
-    rc = load().vis_gemm_fp8(_ptr(aq), _ptr(sa), _ptr(wq), _ptr(sw), _ptr(bias), _ptr(residual), _ptr(out), M, N, K,
+    if work is not None and (work.dtype != torch.float32 or work.numel() < ksplit * M * N):
+        raise HipLibraryError("gemm_fp8: split-K workspace too small")
+    rc = load().vis_gemm_fp8(_ptr(aq), _ptr(sa), _ptr(wq), _ptr(sw), _ptr(bias), _ptr(residual), _ptr(out),
+                             _ptr(work), ksplit if work is not None else 0, M, N, K,
                              aq.stride(0), wq.stride(0), out.stride(0),
                              residual.stride(0) if residual is not None else 0, act, _stream())
     _check(rc, "vis_gemm_fp8")
