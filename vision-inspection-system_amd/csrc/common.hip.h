@@ -70,15 +70,24 @@ __device__ __forceinline__ float hmax4(float x) {  // max over lanes l, l^16, l^
   return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// Intra-row (16 lanes) butterflies on the DPP path: quad_perm xor-1, xor-2, then row_half_mirror and row_mirror
+// (valid because the partial results are already symmetric) - four v_add_f32_dpp / v_max_f32_dpp instead of four
+// ds_bpermute round trips through the LDS crossbar (__shfl_xor).  The two cross-row steps are hsum4 / hmax4.
+#define VIS_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xf, 0xf, true))
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += VIS_DPP(v, 0xB1);   // quad_perm [1,0,3,2]
+  v += VIS_DPP(v, 0x4E);   // quad_perm [2,3,0,1]
+  v += VIS_DPP(v, 0x141);  // row_half_mirror
+  v += VIS_DPP(v, 0x140);  // row_mirror
   return hsum4(v);
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, VIS_DPP(v, 0xB1));
+  v = fmaxf(v, VIS_DPP(v, 0x4E));
+  v = fmaxf(v, VIS_DPP(v, 0x141));
+  v = fmaxf(v, VIS_DPP(v, 0x140));
   return hmax4(v);
 }
 
