@@ -192,6 +192,12 @@ int vis_decode_cross_attn(const void* q, const void* q_norm_w, const void* k, co
                           void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int key_tokens,
                           int nsplit, float scale, float eps, vis_stream_t stream);
 
+/* Row f4: pixel statistics of the image-quality pre-check (src/safety/image_quality.py:42-56,:118-127): exact integer
+ * sums over the RGB frame - stats[0] = sum gray, stats[1] = sum Laplacian, stats[2] = sum Laplacian^2 (int64[3]) with
+ * OpenCV's published 8-bit RGB2GRAY fixed-point rule and the ksize-1 Laplacian under BORDER_REFLECT_101.
+ * Parity with the reference's cv2 calls is UNPINNED (OpenCV is absent here; the reference holds no fixtures). */
+int vis_image_stats_u8(const void* img, int H, int W, void* stats, vis_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

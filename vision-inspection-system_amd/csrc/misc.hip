@@ -215,3 +215,57 @@ extern "C" int vis_add_rows_bf16(void* x, const void* table, const void* idx, in
                      (const int*)idx, n, D, ldx, n_table);
   return vis_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Row f4: the image-quality pre-check's pixel statistics (reference:
+// src/safety/image_quality.py:42-56,:118-127 - cv2.cvtColor(BGR2GRAY), cv2.Laplacian(gray, CV_64F).var(),
+// np.mean(gray)) as one HBM-bound pass over the decoded RGB frame.
+// PARITY UNPINNED: the reference computes these with OpenCV, which is not in this image and has no fixtures in the
+// reference; what is restated here is OpenCV's published 8-bit algorithm:
+//   gray = (4899 R + 9617 G + 1868 B + 8192) >> 14                  (RGB2GRAY fixed-point coefficients, shift 14)
+//   lap  = g[y-1][x] + g[y+1][x] + g[y][x-1] + g[y][x+1] - 4 g[y][x] (ksize = 1 aperture, BORDER_REFLECT_101)
+// Outputs are EXACT integer sums (int64 atomics: order-independent): stats[0] = sum gray, stats[1] = sum lap,
+// stats[2] = sum lap^2; the host forms mean and variance in float64.
+__device__ __forceinline__ int iq_gray(const uint8_t* __restrict__ img, int W, int y, int x) {
+  const uint8_t* p = img + ((size_t)y * W + x) * 3;
+  return (4899 * p[0] + 9617 * p[1] + 1868 * p[2] + 8192) >> 14;
+}
+
+__global__ __launch_bounds__(256) void image_stats_kernel(const uint8_t* __restrict__ img, int H, int W,
+                                                          long long* __restrict__ stats) {
+  long long sg = 0, sl = 0, sq = 0;
+  const long long total = (long long)H * W;
+  for (long long it = (long long)blockIdx.x * 256 + threadIdx.x; it < total; it += (long long)gridDim.x * 256) {
+    const int y = (int)(it / W), x = (int)(it - (long long)y * W);
+    const int yu = (y == 0) ? min(1, H - 1) : y - 1, yd = (y == H - 1) ? max(H - 2, 0) : y + 1;
+    const int xl = (x == 0) ? min(1, W - 1) : x - 1, xr = (x == W - 1) ? max(W - 2, 0) : x + 1;
+    const int c = iq_gray(img, W, y, x);
+    const int lap = iq_gray(img, W, yu, x) + iq_gray(img, W, yd, x) + iq_gray(img, W, y, xl) + iq_gray(img, W, y, xr) - 4 * c;
+    sg += c;
+    sl += lap;
+    sq += (long long)lap * lap;
+  }
+  __shared__ long long red[3][256];
+  red[0][threadIdx.x] = sg; red[1][threadIdx.x] = sl; red[2][threadIdx.x] = sq;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + s];
+      red[1][threadIdx.x] += red[1][threadIdx.x + s];
+      red[2][threadIdx.x] += red[2][threadIdx.x + s];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) atomicAdd((unsigned long long*)&stats[threadIdx.x], (unsigned long long)red[threadIdx.x][0]);
+}
+
+// stats: device int64[3], zeroed by this call before the kernel runs
+extern "C" int vis_image_stats_u8(const void* img, int H, int W, void* stats, hipStream_t stream) {
+  if (!img || !stats || H <= 0 || W <= 0 || ((uintptr_t)stats & 7)) return VIS_ERR_ARG;
+  vis_clear_error();
+  if (hipMemsetAsync(stats, 0, 3 * sizeof(long long), stream) != hipSuccess) return VIS_ERR_LAUNCH;
+  const long long total = (long long)H * W;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(image_stats_kernel, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)img, H, W, (long long*)stats);
+  return vis_check_launch();
+}

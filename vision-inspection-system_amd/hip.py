@@ -41,6 +41,7 @@ _SIGS = {
     "vis_patchify_tiles_u8": "pp" + "iiiiii" + "pp" + "p",
     "vis_add_rows_bf16": "ppp" + "iiii" + "p",
     "vis_decode_cross_attn": "pppppppp" + "iiiii" + "ff" + "p",
+    "vis_image_stats_u8": "p" + "ii" + "p" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
 }
@@ -501,6 +502,16 @@ def resize_rgb(frame: torch.Tensor, out_h: int, out_w: int, kind: str = "bicubic
                                   kx.shape[1], _ptr(ky), _ptr(by), ky.shape[1], _stream())
     _check(rc, "vis_resize_rgb_u8")
     return dst
+
+
+def image_stats(frame: torch.Tensor):
+    """uint8 device frame [H, W, 3] -> (sum gray, sum laplacian, sum laplacian^2) as Python ints (exact)."""
+    if frame.dtype != torch.uint8 or frame.dim() != 3 or frame.shape[2] != 3 or not frame.is_contiguous():
+        raise HipLibraryError("image_stats: contiguous uint8 [H, W, 3] frame required")
+    stats = torch.empty(3, dtype=torch.int64, device=frame.device)
+    rc = load().vis_image_stats_u8(_ptr(frame), frame.shape[0], frame.shape[1], _ptr(stats), _stream())
+    _check(rc, "vis_image_stats_u8")
+    return tuple(int(v) for v in stats.cpu().tolist())
 
 
 def patchify_tiles(frame: torch.Tensor, out: torch.Tensor, tiles_h: int, tiles_w: int, tile: int, mean, std) -> None:

@@ -1,0 +1,130 @@
+"""Row f4: the image-quality pre-check, the node right before the Inspector
+(reference: src/safety/image_quality.py:18-185, node src/orchestration/nodes.py:80-112).
+
+Same result dict, thresholds and scoring as the reference (sharpness = Laplacian variance, brightness = mean gray,
+resolution score; weighted 0.4 / 0.3 / 0.3; pass at >= 0.6; failures are reported, never raised).  The pixel
+statistics come from ONE pass over the decoded frame on the GPU (hip.image_stats: exact integer sums), the frame
+being the same decoded RGB image the Inspector request uploads.
+
+PARITY UNPINNED: the reference computes the statistics with OpenCV (cv2.imread / cvtColor /
+Laplacian), which this image does not contain, and ships no fixtures for this module.  The kernel restates OpenCV's
+published 8-bit algorithm (fixed-point RGB2GRAY, ksize-1 Laplacian, BORDER_REFLECT_101); tests check it against a
+numpy statement of that same algorithm, not against cv2.  The scoring arithmetic is plain Python and identical.
+"""
+from __future__ import annotations
+
+import logging
+from pathlib import Path
+from typing import Any, Dict, Tuple, Union
+
+import numpy as np
+from PIL import Image
+
+logger = logging.getLogger("vision_inspection_system_amd.image_quality")
+
+
+def gray_u8(rgb: np.ndarray) -> np.ndarray:
+    """OpenCV's 8-bit RGB->gray rule (numpy statement; tests and documentation)."""
+    r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+    return ((4899 * r + 9617 * g + 1868 * b + 8192) >> 14).astype(np.int64)
+
+
+def laplacian_reflect101(gray: np.ndarray) -> np.ndarray:
+    """ksize-1 Laplacian (4-neighbour) with BORDER_REFLECT_101 (numpy statement)."""
+    p = np.pad(gray, 1, mode="reflect")
+    return p[:-2, 1:-1] + p[2:, 1:-1] + p[1:-1, :-2] + p[1:-1, 2:] - 4 * gray
+
+
+class ImageQualityAssessment:
+    def __init__(self):
+        self.min_sharpness = 100.0
+        self.min_brightness = 30.0
+        self.max_brightness = 220.0
+        self.min_resolution = 100
+        self.min_pixels = 10000
+
+    # -- statistics -----------------------------------------------------------------
+    def _stats(self, rgb: np.ndarray) -> Tuple[float, float]:
+        """(laplacian variance, mean gray) from exact integer sums computed on the GPU."""
+        import torch
+        from . import hip
+        h, w, _ = rgb.shape
+        sg, sl, sq = hip.image_stats(torch.from_numpy(np.ascontiguousarray(rgb)).to("cuda"))
+        n = float(h * w)
+        mean_l = sl / n
+        return float(sq / n - mean_l * mean_l), float(sg / n)
+
+    # -- scores (reference arithmetic) -----------------------------------------------
+    def _sharpness_score(self, lap_var: float) -> float:
+        if lap_var < self.min_sharpness:
+            return lap_var / self.min_sharpness * 0.5
+        return min(1.0, 0.5 + (lap_var - self.min_sharpness) / 400.0)
+
+    def _brightness_score(self, mean_brightness: float) -> float:
+        if self.min_brightness <= mean_brightness <= self.max_brightness:
+            ideal = (self.min_brightness + self.max_brightness) / 2
+            return 1.0 - (abs(mean_brightness - ideal) / ((self.max_brightness - self.min_brightness) / 2)) * 0.3
+        if mean_brightness < self.min_brightness:
+            return max(0.0, mean_brightness / self.min_brightness * 0.6)
+        return max(0.0, 1.0 - ((mean_brightness - self.max_brightness) / (255 - self.max_brightness)) * 0.8)
+
+    def _resolution_score(self, width: int, height: int, total: int) -> float:
+        if min(width, height) < self.min_resolution:
+            return 0.3
+        if total < self.min_pixels:
+            return 0.5
+        return min(1.0, total / 2000000.0)
+
+    def assess_quality(self, image_path: Union[str, Path]) -> Dict[str, Any]:
+        try:
+            try:
+                img = Image.open(image_path)
+                img.load()
+            except Exception:
+                return self._failed(f"Failed to load image: {image_path}")
+            rgb = np.array(img.convert("RGB"), dtype=np.uint8)
+            height, width = rgb.shape[:2]
+            total = width * height
+            lap_var, mean_b = self._stats(rgb)
+            s, b, r = self._sharpness_score(lap_var), self._brightness_score(mean_b), self._resolution_score(width, height, total)
+            overall = 0.4 * s + 0.3 * b + 0.3 * r
+            result = {
+                "quality_score": round(overall, 3), "quality_passed": overall >= 0.6,
+                "sharpness": {"score": round(s, 3), "laplacian_variance": lap_var, "passed": s >= 0.6},
+                "brightness": {"score": round(b, 3), "mean_value": round(mean_b, 1), "passed": b >= 0.6},
+                "resolution": {"score": round(r, 3), "width": width, "height": height, "total_pixels": total,
+                               "passed": r >= 0.6},
+                "image_path": str(image_path),
+            }
+            logger.info(f"Image quality assessment: score={overall:.2f}, sharpness={s:.2f}, brightness={b:.2f}, "
+                        f"resolution={r:.2f}")
+            return result
+        except Exception as e:
+            logger.error(f"Image quality assessment failed: {e}", exc_info=True)
+            return self._failed(f"Assessment error: {str(e)}")
+
+    @staticmethod
+    def _failed(reason: str) -> Dict[str, Any]:
+        return {"quality_score": 0.0, "quality_passed": False, "sharpness": {"score": 0.0, "passed": False},
+                "brightness": {"score": 0.0, "passed": False}, "resolution": {"score": 0.0, "passed": False},
+                "error": reason}
+
+
+def assess_image_quality(image_path: Union[str, Path]) -> Dict[str, Any]:
+    return ImageQualityAssessment().assess_quality(image_path)
+
+
+def check_image_quality(state: Dict[str, Any]) -> Dict[str, Any]:
+    """The ``quality_check`` node (nodes.py:80-112): non-blocking; marks ``low_quality_image`` for the gates."""
+    state["current_step"] = "quality_check"
+    try:
+        paths = state["image_path"]
+        first = paths[0] if isinstance(paths, (list, tuple)) else paths
+        q = assess_image_quality(Path(first))
+        state["image_quality"] = q
+        if not q.get("quality_passed", False):
+            state["low_quality_image"] = True
+    except Exception as e:
+        logger.error(f"Image quality check failed: {e}", exc_info=True)
+        state["image_quality"] = {"quality_passed": False, "error": str(e)}
+    return state
