@@ -172,6 +172,19 @@ int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, const void* sw,
 int vis_quant_rows_fp8(const void* x, const void* norm_w, void* q, void* scale, int rows, int K, int ldx, int ldq,
                        float eps, vis_stream_t stream);
 
+/* BASELINE configs[4], batched decode: fp8 forms of vis_gemm_decode_bf16 / vis_skinny_finalize.
+ * vis_gemm_decode_fp8: xq [B][ldx] / Wq [N][ldw] OCP e4m3 bytes (K % 128 == 0) on the block-scaled fp8 MFMA, same
+ * persistent stream-K ring; partials (part != NULL) are RAW sums, the direct form (part == NULL) applies sx[b]*sw[n].
+ * vis_skinny_finalize_fp8: sums the partial slots, scales by sx[b]*sw[n], then bias / residual / SwiGLU / next
+ * RMSNorm as vis_skinny_finalize; yq != NULL additionally writes the row the NEXT projection consumes (yn if normed,
+ * else y) as e4m3 bytes with its per-row scale yq_scale[b] = amax/448 (the activation quantiser, fused). */
+int vis_gemm_decode_fp8_ksplit(int N, int K);
+int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* Wq, const void* sw, void* part, void* C, int B,
+                        int N, int K, int ldx, int ldw, int ldc, int ksplit, int out_f32, vis_stream_t stream);
+int vis_skinny_finalize_fp8(const void* part, int ksplit, const void* sx, const void* sw, const void* bias,
+                            const void* R, const void* norm_w, void* y, void* yn, void* yq, void* yq_scale, int B,
+                            int N, int ldr, int ldy, int ldyn, int ldyq, int swiglu, float eps, vis_stream_t stream);
+
 /* ---- Row f2: Llama-3.2-11B-Vision ("mllama") Auditor, reference src/agents/vlm_auditor.py:81-83,:152-158 ---- */
 
 /* Resized RGB frame -> patch rows of the tile canvas (zero padding applied to RAW pixels, then rescale/normalise;

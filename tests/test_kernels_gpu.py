@@ -313,6 +313,38 @@ def test_gemm_fp8_swiglu_and_asymmetric_identity(hip, device):
     _assert_close(o2, w2.float().t(), atol=1e-2, rtol=1e-2, what="fp8 identity")
 
 
+@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 768), (16, 4608, 3584), (8, 3584, 18944)])
+def test_decode_gemm_fp8_and_finalize(hip, device, B, N, K):
+    """fp8 batched-decode projection + fp8 finalisation against fp32 arithmetic on the same quantised operands."""
+    x = _randn((B, K), device, 180, 2.0)
+    w = _randn((N, K), device, 181, 1.0 / math.sqrt(K))
+    b = _randn((N,), device, 182)
+    r = _randn((B, N), device, 183)
+    nw = _randn((N,), device, 184)
+    xq, sx = hip.quant_rows_fp8(x)
+    wq, sw = hip.quantize_fp8_rows(w)
+    part = torch.full((16 * 16 * N,), float("nan"), dtype=torch.float32, device=device)
+    y = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+    yn = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+    yq = torch.zeros((B, N), dtype=torch.uint8, device=device)
+    ysc = torch.empty(B, dtype=torch.float32, device=device)
+    ks = hip.decode_gemm_fp8(xq, sx, wq, sw, part=part)
+    assert 1 <= ks <= 16
+    hip.skinny_finalize_fp8(part, ks, y, N, sx=sx, sw=sw, bias=b, residual=r, norm_w=nw, yn=yn, yq=yq, yq_scale=ysc)
+    prod = (xq.view(torch.float8_e4m3fn).float() @ wq.view(torch.float8_e4m3fn).float().t()) * sx[:, None] * sw[None, :]
+    ref = prod + b.float() + r.float()
+    _assert_close(y, ref, atol=4e-2, rtol=1e-2, what=f"decode gemm fp8 {B}x{N}x{K}")
+    ynf = yn.float()
+    ref_sc = (ynf.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+    assert torch.allclose(ysc, ref_sc, rtol=1e-6, atol=0)
+    ref_q = (ynf * (1.0 / ysc)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (yq != ref_q).float().mean().item() < 1e-6           # the fused quantiser equals the stand-alone one
+    # direct (scaled) outputs
+    out = torch.empty((B, N), dtype=torch.float32, device=device)
+    hip.decode_gemm_fp8(xq, sx, wq, sw, out=out)
+    _assert_close(out, prod, atol=3e-2, rtol=1e-2, what="decode gemm fp8 direct")
+
+
 # ----------------------------------------------------------------------------- K10 GEMV
 @pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1000, 704)])
 def test_gemv_plain(hip, device, N, K):

@@ -24,6 +24,14 @@ struct FinArgs {
   bf16_t* yn;            // [B][ldyn] or null
   int ksplit, N, ldr, ldy, ldyn, swiglu;
   float eps;
+  // fp8 form (BASELINE configs[4]): partials are raw sums of e4m3 products -> v *= sx[b] * sw[n] first;
+  // yq != null: the row handed to the NEXT projection (yn when normed, else y) is also written as e4m3 bytes
+  // with its own per-row scale (amax / 448) - the activation quantiser fused here because this workgroup owns the row
+  const float* sx;       // [B] or null
+  const float* sw;       // [N] or null
+  uint8_t* yq;           // [B][ldyq] or null
+  float* yq_scale;       // [B]
+  int ldyq;
 };
 
 template <int KS>
@@ -69,12 +77,24 @@ __global__ __launch_bounds__(FIN_THREADS) void skinny_finalize_kernel(FinArgs p)
     float v[4];
     if (p.swiglu) {
       const int g = ((o >> 4) << 5) + (o & 15);  // gate columns; the matching up columns are +16
-      const f32x4 ga = fin_sum_dyn(pb + g, stride, p.ksplit);
-      const f32x4 ua = fin_sum_dyn(pb + g + 16, stride, p.ksplit);
+      f32x4 ga = fin_sum_dyn(pb + g, stride, p.ksplit);
+      f32x4 ua = fin_sum_dyn(pb + g + 16, stride, p.ksplit);
+      if (p.sx) {
+        const float sxb = p.sx[b];
+        const f32x4 sg = *(const f32x4*)(p.sw + g), su = *(const f32x4*)(p.sw + g + 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ga[r] *= sxb * sg[r]; ua[r] *= sxb * su[r]; }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = ga[r] / (1.0f + __expf(-ga[r])) * ua[r];
     } else {
-      const f32x4 a = fin_sum_dyn(pb + o, stride, p.ksplit);
+      f32x4 a = fin_sum_dyn(pb + o, stride, p.ksplit);
+      if (p.sx) {
+        const float sxb = p.sx[b];
+        const f32x4 s4 = *(const f32x4*)(p.sw + o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] *= sxb * s4[r];
+      }
       v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
       if (p.bias) {
         const u32x2 bb = *(const u32x2*)(p.bias + o);
@@ -97,29 +117,84 @@ __global__ __launch_bounds__(FIN_THREADS) void skinny_finalize_kernel(FinArgs p)
       ss += r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3;
     }
   }
-  if (!p.yn) return;
   __shared__ float red[FIN_THREADS / 64];
-  ss = wave_sum(ss);
-  if ((tid & 63) == 0) red[tid >> 6] = ss;
-  __syncthreads();
-  float tot = 0.f;
+  if (p.yn) {
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
 #pragma unroll
-  for (int i = 0; i < FIN_THREADS / 64; ++i) tot += red[i];
-  const float rstd = rsqrtf(tot / (float)n_out + p.eps);
-  for (int o = tid * 4; o < n_out; o += FIN_THREADS * 4) {  // this thread re-reads its own (bf16) outputs
-    const u32x2 q = *(const u32x2*)(p.y + (size_t)b * p.ldy + o);
-    const u32x2 w = *(const u32x2*)(p.norm_w + o);
-    float f[4] = {__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16),
-                  __uint_as_float(q[1] & 0xffff0000u)};
-    const float g[4] = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
-                        __uint_as_float(w[1] & 0xffff0000u)};
+    for (int i = 0; i < FIN_THREADS / 64; ++i) tot += red[i];
+    const float rstd = rsqrtf(tot / (float)n_out + p.eps);
+    for (int o = tid * 4; o < n_out; o += FIN_THREADS * 4) {  // this thread re-reads its own (bf16) outputs
+      const u32x2 q = *(const u32x2*)(p.y + (size_t)b * p.ldy + o);
+      const u32x2 w = *(const u32x2*)(p.norm_w + o);
+      float f[4] = {__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16),
+                    __uint_as_float(q[1] & 0xffff0000u)};
+      const float g[4] = {__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xffff0000u), __uint_as_float(w[1] << 16),
+                          __uint_as_float(w[1] & 0xffff0000u)};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) f[r] = bf2f(f2bf(f[r] * rstd)) * g[r];
-    u32x2 t;
-    t[0] = pack2bf(f[0], f[1]);
-    t[1] = pack2bf(f[2], f[3]);
-    *(u32x2*)(p.yn + (size_t)b * p.ldyn + o) = t;
+      for (int r = 0; r < 4; ++r) f[r] = bf2f(f2bf(f[r] * rstd)) * g[r];
+      u32x2 t;
+      t[0] = pack2bf(f[0], f[1]);
+      t[1] = pack2bf(f[2], f[3]);
+      *(u32x2*)(p.yn + (size_t)b * p.ldyn + o) = t;
+    }
   }
+  if (!p.yq) return;
+  // ---- e4m3 copy of the row the next projection consumes (yn if normed, else y); own writes, re-read as bf16
+  const bf16_t* src = p.yn ? p.yn + (size_t)b * p.ldyn : p.y + (size_t)b * p.ldy;
+  float amax = 0.f;
+  for (int o = tid * 4; o < n_out; o += FIN_THREADS * 4) {
+    const u32x2 q = *(const u32x2*)(src + o);
+    amax = fmaxf(fmaxf(amax, fabsf(__uint_as_float(q[0] << 16))), fabsf(__uint_as_float(q[0] & 0xffff0000u)));
+    amax = fmaxf(fmaxf(amax, fabsf(__uint_as_float(q[1] << 16))), fabsf(__uint_as_float(q[1] & 0xffff0000u)));
+  }
+  amax = wave_max(amax);
+  __syncthreads();   // red[] may still be read by slower waves of the norm pass
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < FIN_THREADS / 64; ++i) am = fmaxf(am, red[i]);
+  const float sc = fmaxf(am / 448.0f, 1e-12f);
+  const float inv = 1.0f / sc;
+  if (tid == 0) p.yq_scale[b] = sc;
+  for (int o = tid * 4; o < n_out; o += FIN_THREADS * 4) {
+    const u32x2 q = *(const u32x2*)(src + o);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(q[0] << 16) * inv, __uint_as_float(q[0] & 0xffff0000u) * inv, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(q[1] << 16) * inv, __uint_as_float(q[1] & 0xffff0000u) * inv, w, true);
+    *(uint32_t*)(p.yq + (size_t)b * p.ldyq + o) = (uint32_t)w;
+  }
+}
+
+static int skinny_finalize_launch(FinArgs p, int B, hipStream_t stream) {
+  vis_clear_error();
+  hipLaunchKernelGGL(skinny_finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, stream, p);
+  return vis_check_launch();
+}
+
+// fp8 form: partials of vis_gemm_decode_fp8 (raw) scaled by sx[b] * sw[n]; optional e4m3 copy (yq, yq_scale) of the
+// row the next projection consumes (yn when norm_w is given, else y).  Everything else as vis_skinny_finalize.
+extern "C" int vis_skinny_finalize_fp8(const void* part, int ksplit, const void* sx, const void* sw, const void* bias,
+                                       const void* R, const void* norm_w, void* y, void* yn, void* yq, void* yq_scale,
+                                       int B, int N, int ldr, int ldy, int ldyn, int ldyq, int swiglu, float eps,
+                                       hipStream_t stream) {
+  if (!part || !y || B <= 0 || B > 16 || N <= 0 || N % 4 != 0 || ksplit < 1 || ksplit > FIN_MAXKS) return VIS_ERR_ARG;
+  if (swiglu && (N % 32 != 0 || bias || R)) return VIS_ERR_ARG;
+  if ((yn != nullptr) != (norm_w != nullptr)) return VIS_ERR_ARG;
+  if ((sx != nullptr) != (sw != nullptr) || (yq != nullptr) != (yq_scale != nullptr)) return VIS_ERR_ARG;
+  if (ldy % 4 != 0 || (R && ldr % 4 != 0) || (yn && ldyn % 4 != 0) || (yq && ldyq % 4 != 0)) return VIS_ERR_ARG;
+  if (((uintptr_t)part | (uintptr_t)sw) & 15 || ((uintptr_t)yq & 3) ||
+      (((uintptr_t)y | (uintptr_t)yn | (uintptr_t)bias | (uintptr_t)R | (uintptr_t)norm_w) & 7))
+    return VIS_ERR_ARG;
+  FinArgs p;
+  p.part = (const float*)part; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R; p.norm_w = (const bf16_t*)norm_w;
+  p.y = (bf16_t*)y; p.yn = (bf16_t*)yn;
+  p.ksplit = ksplit; p.N = N; p.ldr = ldr; p.ldy = ldy; p.ldyn = ldyn; p.swiglu = swiglu; p.eps = eps;
+  p.sx = (const float*)sx; p.sw = (const float*)sw; p.yq = (uint8_t*)yq; p.yq_scale = (float*)yq_scale; p.ldyq = ldyq;
+  return skinny_finalize_launch(p, B, stream);
 }
 
 extern "C" int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const void* R, const void* norm_w,
@@ -135,7 +210,6 @@ extern "C" int vis_skinny_finalize(const void* part, int ksplit, const void* bia
   p.part = (const float*)part; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R; p.norm_w = (const bf16_t*)norm_w;
   p.y = (bf16_t*)y; p.yn = (bf16_t*)yn;
   p.ksplit = ksplit; p.N = N; p.ldr = ldr; p.ldy = ldy; p.ldyn = ldyn; p.swiglu = swiglu; p.eps = eps;
-  vis_clear_error();
-  hipLaunchKernelGGL(skinny_finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, stream, p);
-  return vis_check_launch();
+  p.sx = nullptr; p.sw = nullptr; p.yq = nullptr; p.yq_scale = nullptr; p.ldyq = 0;
+  return skinny_finalize_launch(p, B, stream);
 }

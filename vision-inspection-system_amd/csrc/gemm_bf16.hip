@@ -551,8 +551,12 @@ struct DecGemmArgs {
   const bf16_t* W;  // [N][ldw]
   float* part;      // [nslots][16][N] or null
   void* C;          // direct output (part == null)
-  int M, N, lda, ldw, ldc;
+  int M, N, lda, ldw, ldc;   // lda / ldw in ELEMENTS (= bytes for fp8)
   int nk_all, total, spb, nslots, out_f32;
+  // fp8 form (template FP8): A / W are OCP e4m3 bytes, a K-step is 128 elements (again 128 bytes per tile row);
+  // the direct-output path applies the row scales sx[m] * sw[n]; partials stay raw (vis_skinny_finalize scales them)
+  const float* sx;
+  const float* sw;
 };
 
 __device__ __forceinline__ void gemm3_wait_stages(int younger) {
@@ -568,7 +572,9 @@ __device__ __forceinline__ void gemm3_wait_stages(int younger) {
 }
 static_assert(GEMM3_DEPTH == 7 && GEMM3_PER == 5, "gemm3_wait_stages encodes (DEPTH-2) x PER");
 
+template <bool FP8>
 __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs p) {
+  constexpr int EB = FP8 ? 1 : 2;  // bytes per element
   extern __shared__ __attribute__((aligned(16))) char lds3[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
   uint32_t a_off, w_off[4];
   {
     const int row = tid >> 3, ch = (tid & 7) ^ (row & 7);
-    a_off = (uint32_t)min(row, p.M - 1) * (uint32_t)(p.lda * 2) + ch * 16;
+    a_off = (uint32_t)min(row, p.M - 1) * (uint32_t)(p.lda * EB) + ch * 16;
   }
   int p_tile = s0 / p.nk_all, p_kt = s0 - p_tile * p.nk_all;  // producer cursor
   const char* a_ptr;
@@ -593,10 +599,10 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
     for (int i = 0; i < 4; ++i) {
       const int c = i * 256 + tid;
       const int row = c >> 3, ch = (c & 7) ^ (row & 7);
-      w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+      w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * EB) + ch * 16;
     }
-    a_ptr = (const char*)p.A + (size_t)kt * GEMM_BK * 2;
-    w_ptr = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt * GEMM_BK * 2;
+    a_ptr = (const char*)p.A + (size_t)kt * 128;
+    w_ptr = (const char*)p.W + (size_t)n0 * p.ldw * EB + (size_t)kt * 128;
   };
   enter_tile(p_tile, p_kt);
   const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
@@ -610,8 +616,8 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr + w_off[i]),
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096), 16, 0, 0);
-    a_ptr += GEMM_BK * 2;
-    w_ptr += GEMM_BK * 2;
+    a_ptr += 128;
+    w_ptr += 128;
     if (++p_kt == p.nk_all) {
       p_kt = 0;
       ++p_tile;
@@ -639,18 +645,34 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
       fill = (fill + 1 == GEMM3_DEPTH) ? 0 : fill + 1;
     }
     const char* base = lds3 + slot * GEMM3_STAGE_BYTES;
-    const bf16x8 a0 = *(const bf16x8*)(base + rd0);
-    const bf16x8 a1 = *(const bf16x8*)(base + rd1);
-    bf16x8 wf[2][2];
+    if constexpr (FP8) {
+      // lane holds row l15, k = 32 h .. 32 h + 31: 16-byte chunks 2h and 2h+1 at their swizzled positions
+      typedef int i32x8 __attribute__((ext_vector_type(8)));
+      const int qlo = l15 * 128 + (((2 * h) ^ sw) << 4), qhi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
+      auto frag8 = [&](const char* p0) -> i32x8 {
+        const u32x4 lo = *(const u32x4*)(p0 + qlo), hi = *(const u32x4*)(p0 + qhi);
+        return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+      };
+      const i32x8 xa = frag8(base);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      wf[j][0] = *(const bf16x8*)(base + w_rd + j * 2048 + rd0);
-      wf[j][1] = *(const bf16x8*)(base + w_rd + j * 2048 + rd1);
-    }
+      for (int j = 0; j < 2; ++j) {
+        const i32x8 wa = frag8(base + w_rd + j * 2048);
+        acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+      }
+    } else {
+      const bf16x8 a0 = *(const bf16x8*)(base + rd0);
+      const bf16x8 a1 = *(const bf16x8*)(base + rd1);
+      bf16x8 wf[2][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], a0, acc[j], 0, 0, 0);
-      acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], a1, acc[j], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
+        wf[j][0] = *(const bf16x8*)(base + w_rd + j * 2048 + rd0);
+        wf[j][1] = *(const bf16x8*)(base + w_rd + j * 2048 + rd1);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], a0, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], a1, acc[j], 0, 0, 0);
+      }
     }
     slot = (slot + 1 == GEMM3_DEPTH) ? 0 : slot + 1;
 
@@ -676,6 +698,12 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
           for (int j = 0; j < 2; ++j) {
             const int n = nb + j * 16;
             if (n >= p.N) continue;
+            if (FP8) {   // direct output of the fp8 form: apply the row scales here
+              const float sxm = p.sx[m];
+              const f32x4 s4 = *(const f32x4*)(p.sw + n);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[j][r] *= sxm * s4[r];
+            }
             if (p.out_f32) {
               *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = acc[j];
             } else {
@@ -695,8 +723,8 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
 }
 
 // geometry of the stream-K cut for (N, K): steps per workgroup and the number of partial slots a tile can need
-static void gemm3_geometry(int N, int K, bool direct, int* spb, int* nslots, int* nwg) {
-  const int tiles = (N + GEMM_BN - 1) / GEMM_BN, nk = K / GEMM_BK;
+static void gemm3_geometry(int N, int K, bool direct, int* spb, int* nslots, int* nwg, int kstep = GEMM_BK) {
+  const int tiles = (N + GEMM_BN - 1) / GEMM_BN, nk = K / kstep;
   const long total = (long)tiles * nk;
   int wg = GEMM3_MAX_WG;
   for (;;) {
@@ -741,7 +769,7 @@ extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, vo
     ksplit = 1;
   }
   static const bool attr3_ok = [] {
-    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                GEMM3_LDS_BYTES) == hipSuccess;
   }();
   if (!attr3_ok) return VIS_ERR_LAUNCH;
@@ -750,9 +778,9 @@ extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, vo
   p.M = B; p.N = N; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
   p.nk_all = K / GEMM_BK;
   p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
-  p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32;
+  p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32; p.sx = nullptr; p.sw = nullptr;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_decode_stream_kernel, dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(gemm_decode_stream_kernel<false>, dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   return vis_check_launch();
 }
 
@@ -761,6 +789,48 @@ extern "C" int vis_gemm_decode_ksplit(int N, int K) {
   if (N <= 0 || K < GEMM_BK) return 0;
   int spb, slots, nwg;
   gemm3_geometry(N, K, false, &spb, &slots, &nwg);
+  return slots;
+}
+
+// fp8 form of the batched decode projection (BASELINE configs[4]): xq [B][ldx] / Wq [N][ldw] OCP e4m3 bytes with row
+// scales sx [B] / sw [N].  Partials (part != NULL) are RAW sums - vis_skinny_finalize applies sx * sw; the direct
+// form (part == NULL) scales in the kernel.  K % 128 == 0.
+extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* Wq, const void* sw, void* part, void* C,
+                                   int B, int N, int K, int ldx, int ldw, int ldc, int ksplit, int out_f32,
+                                   hipStream_t stream) {
+  if (!xq || !Wq || (!part && !C) || B <= 0 || B > 16 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % 128 != 0 || N % 4 != 0 || ldx % 16 != 0 || ldw % 16 != 0 || ldx < K || ldw < K || (C && ldc % 4 != 0))
+    return VIS_ERR_ARG;
+  if (!part && (!sx || !sw)) return VIS_ERR_ARG;
+  if (((uintptr_t)xq | (uintptr_t)Wq | (uintptr_t)part | (uintptr_t)C | (uintptr_t)sw) & 15) return VIS_ERR_ARG;
+  int spb, need, nwg;
+  gemm3_geometry(N, K, part == nullptr, &spb, &need, &nwg, 128);
+  if (part) {
+    if (ksplit <= 0) ksplit = need;
+    if (ksplit < need || ksplit > GEMM3_MAX_SLOTS) return VIS_ERR_ARG;
+  } else {
+    ksplit = 1;
+  }
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM3_LDS_BYTES) == hipSuccess;
+  }();
+  if (!attr_ok) return VIS_ERR_LAUNCH;
+  DecGemmArgs p;
+  p.A = (const bf16_t*)xq; p.W = (const bf16_t*)Wq; p.part = (float*)part; p.C = C;
+  p.M = B; p.N = N; p.lda = ldx; p.ldw = ldw; p.ldc = ldc;
+  p.nk_all = K / 128;
+  p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
+  p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32; p.sx = (const float*)sx; p.sw = (const float*)sw;
+  vis_clear_error();
+  hipLaunchKernelGGL(gemm_decode_stream_kernel<true>, dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  return vis_check_launch();
+}
+
+extern "C" int vis_gemm_decode_fp8_ksplit(int N, int K) {
+  if (N <= 0 || K < 128) return 0;
+  int spb, slots, nwg;
+  gemm3_geometry(N, K, false, &spb, &slots, &nwg, 128);
   return slots;
 }
 

@@ -174,7 +174,15 @@ class Qwen2VLEngine:
             for lw in weights.llm:
                 self.q8.append({n: hip.quantize_fp8_rows(getattr(lw, n)) for n in ("qkv_w", "o_w", "gateup_w", "down_w")})
             self.q8_lm_head = hip.quantize_fp8_rows(weights.lm_head)
-        if prefill_dtype == "fp8":     # fp8 MFMA needs K % 128 == 0: zero-pad the down projection's K if necessary
+        self.fp8_batched = False
+        if decode_weights == "fp8" and Bm > 1 and cfg.hidden % 128 == 0:
+            self.fp8_batched = True
+            kp = _round_up(cfg.intermediate, 128)
+            self.b_xq = torch.zeros((Bm, cfg.hidden), dtype=torch.uint8, device=dev)
+            self.b_x2q = torch.zeros((Bm, cfg.hidden), dtype=torch.uint8, device=dev)
+            self.b_actq = torch.zeros((Bm, kp), dtype=torch.uint8, device=dev)       # pad columns stay 0
+            self.b_sx = torch.zeros((3, Bm), dtype=torch.float32, device=dev)
+        if prefill_dtype == "fp8" or self.fp8_batched:   # fp8 MFMA needs K % 128 == 0: zero-pad down's K if necessary
             self.kpad = _round_up(cfg.intermediate, 128)
             if self.kpad != cfg.intermediate:
                 for q in self.q8:
@@ -182,7 +190,7 @@ class Qwen2VLEngine:
                     pad = torch.zeros((wq.shape[0], self.kpad), dtype=torch.uint8, device=wq.device)
                     pad[:, :cfg.intermediate] = wq
                     q["down_w_pad"] = (pad, sc)
-            if cfg.hidden % 128 or (cfg.heads * cfg.head_dim) % 128:
+            if prefill_dtype == "fp8" and (cfg.hidden % 128 or (cfg.heads * cfg.head_dim) % 128):
                 raise ValueError("fp8 prefill needs hidden and heads*head_dim to be multiples of 128")
         self.slot_prompt_len = [0] * Bm
         self._prefill_streams: List[torch.cuda.Stream] = []
@@ -502,6 +510,8 @@ class Qwen2VLEngine:
     def _decode_step_batched(self, B: int) -> None:
         """Every projection = gemm_decode (weights streamed once for all B sequences, split-K f32 partials) +
         skinny_finalize (row-wise: sum, bias/residual/SwiGLU, and the RMSNorm of the NEXT projection)."""
+        if self.decode_weights == "fp8" and self.fp8_batched:
+            return self._decode_step_batched_fp8(B)
         cfg, w = self.cfg, self.w
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         scale, eps = D ** -0.5, cfg.rms_eps
@@ -524,6 +534,43 @@ class Qwen2VLEngine:
             next_norm = w.llm[li + 1].ln1_w if li + 1 < n_layers else w.final_norm_w
             hip.skinny_finalize(part, ks, x, cfg.hidden, residual=x2, norm_w=next_norm, yn=xn, eps=eps)
         hip.decode_gemm(xn, w.lm_head, out=self.logits_b[:B])
+        hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
+                   self.temperature, self.seed)
+
+    def _decode_step_batched_fp8(self, B: int) -> None:
+        """Batched decode on e4m3 weights AND activations (BASELINE configs[4]): qkv, gate/up, down and the lm_head run
+        on the fp8 stream-K projection; every finalisation also emits the next projection's input as e4m3 + row scale
+        (it owns the row, so the activation quantiser costs no extra launch).  The o projection stays bf16: its input
+        comes from the attention combine, which does not own whole rows."""
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        scale, eps = D ** -0.5, cfg.rms_eps
+        x, x2, qkv, att, act = self.b_x[:B], self.b_x2[:B], self.b_qkv[:B], self.b_attn[:B], self.b_act[:B]
+        xn, xn2, part = self.b_xn[:B], self.b_xn2[:B], self.b_part
+        xq, x2q, aq = self.b_xq[:B], self.b_x2q[:B], self.b_actq[:B]
+        sxq, sx2q, saq = self.b_sx[0, :B], self.b_sx[1, :B], self.b_sx[2, :B]
+        nq = qkv.shape[1]
+        hip.gather_rows(w.embed, self.cur_b[:B], x)
+        hip.quant_rows_fp8(x, xq, sxq, norm_w=w.llm[0].ln1_w, eps=eps)
+        n_layers = len(w.llm)
+        for li, lw in enumerate(w.llm):
+            q8 = self.q8[li]
+            ks = hip.decode_gemm_fp8(xq, sxq, *q8["qkv_w"], part=part)
+            hip.skinny_finalize_fp8(part, ks, qkv, nq, sx=sxq, sw=q8["qkv_w"][1], bias=lw.qkv_b, eps=eps)
+            hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+            ks = hip.decode_gemm(att, lw.o_w, part=part)
+            hip.skinny_finalize_fp8(part, ks, x2, cfg.hidden, residual=x, norm_w=lw.ln2_w, yn=xn2, yq=x2q,
+                                    yq_scale=sx2q, eps=eps)
+            ks = hip.decode_gemm_fp8(x2q, sx2q, *q8["gateup_w"], part=part)
+            hip.skinny_finalize_fp8(part, ks, act, 2 * cfg.intermediate, sx=sx2q, sw=q8["gateup_w"][1], swiglu=True,
+                                    yq=aq, yq_scale=saq, eps=eps)
+            dw = q8.get("down_w_pad", q8["down_w"])
+            ks = hip.decode_gemm_fp8(aq, saq, *dw, part=part)
+            next_norm = w.llm[li + 1].ln1_w if li + 1 < n_layers else w.final_norm_w
+            hip.skinny_finalize_fp8(part, ks, x, cfg.hidden, sx=saq, sw=dw[1], residual=x2, norm_w=next_norm, yn=xn,
+                                    yq=xq, yq_scale=sxq, eps=eps)
+        hip.decode_gemm_fp8(xq, sxq, *self.q8_lm_head, out=self.logits_b[:B])
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
 

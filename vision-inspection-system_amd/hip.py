@@ -35,6 +35,9 @@ _SIGS = {
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
     "vis_gemm_decode_ksplit": "ii",
     "vis_gemm_decode_bf16": "pppp" + "iiiiiiii" + "p",
+    "vis_gemm_decode_fp8_ksplit": "ii",
+    "vis_gemm_decode_fp8": "pppppp" + "iiiiiiii" + "p",
+    "vis_skinny_finalize_fp8": "p" + "i" + "ppppp" + "pppp" + "iiiiiii" + "f" + "p",
     "vis_skinny_finalize": "p" + "i" + "ppppp" + "iiiiii" + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_resize_rgb_u8": "ppp" + "iiii" + "ppi" + "ppi" + "p",
@@ -452,6 +455,51 @@ def decode_gemm(x: torch.Tensor, w: torch.Tensor, part: Optional[torch.Tensor] =
                                       out.stride(0), 1, 1 if out.dtype == torch.float32 else 0, _stream())
     _check(rc, "vis_gemm_decode_bf16")
     return ks
+
+
+def decode_gemm_fp8(xq: torch.Tensor, sx: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor,
+                    part: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, ksplit: int = 0) -> int:
+    """fp8 batched-decode projection: raw f32 partials (returns the slot count) or a direct scaled bf16 / f32 result."""
+    B, K = xq.shape
+    N = wq.shape[0]
+    if xq.dtype != torch.uint8 or wq.dtype != torch.uint8 or wq.shape[1] != K or xq.stride(1) != 1 or wq.stride(1) != 1 \
+            or (part is None) == (out is None):
+        raise HipLibraryError("decode_gemm_fp8: bad operands (give exactly one of part / out)")
+    lib = load()
+    if part is not None:
+        ks = ksplit or lib.vis_gemm_decode_fp8_ksplit(N, K)
+        if part.dtype != torch.float32 or part.numel() < ks * 16 * N:
+            raise HipLibraryError("decode_gemm_fp8: partial workspace too small")
+        rc = lib.vis_gemm_decode_fp8(_ptr(xq), _ptr(sx), _ptr(wq), _ptr(sw), _ptr(part), None, B, N, K, xq.stride(0),
+                                     wq.stride(0), 0, ks, 0, _stream())
+    else:
+        ks = 1
+        if out.shape != (B, N) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+            raise HipLibraryError("decode_gemm_fp8: bad output")
+        rc = lib.vis_gemm_decode_fp8(_ptr(xq), _ptr(sx), _ptr(wq), _ptr(sw), None, _ptr(out), B, N, K, xq.stride(0),
+                                     wq.stride(0), out.stride(0), 1, 1 if out.dtype == torch.float32 else 0, _stream())
+    _check(rc, "vis_gemm_decode_fp8")
+    return ks
+
+
+def skinny_finalize_fp8(part: torch.Tensor, ksplit: int, y: torch.Tensor, N: int, sx: Optional[torch.Tensor] = None,
+                        sw: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                        residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+                        yn: Optional[torch.Tensor] = None, yq: Optional[torch.Tensor] = None,
+                        yq_scale: Optional[torch.Tensor] = None, swiglu: bool = False, eps: float = 1e-6) -> None:
+    """Finalisation with fp8 partial scaling (sx, sw) and/or an e4m3 copy (yq, yq_scale) of the next projection's input."""
+    B = y.shape[0]
+    n_out = N // 2 if swiglu else N
+    if y.shape[1] != n_out or (yn is not None and yn.shape != y.shape):
+        raise HipLibraryError("skinny_finalize_fp8: bad output shapes")
+    if yq is not None and (yq.dtype != torch.uint8 or yq.shape[0] != B or yq.shape[1] < n_out or yq_scale is None):
+        raise HipLibraryError("skinny_finalize_fp8: bad yq")
+    rc = load().vis_skinny_finalize_fp8(_ptr(part), ksplit, _ptr(sx), _ptr(sw), _ptr(bias), _ptr(residual),
+                                        _ptr(norm_w), _ptr(y), _ptr(yn), _ptr(yq), _ptr(yq_scale), B, N,
+                                        residual.stride(0) if residual is not None else 0, y.stride(0),
+                                        yn.stride(0) if yn is not None else 0, yq.stride(0) if yq is not None else 0,
+                                        1 if swiglu else 0, eps, _stream())
+    _check(rc, "vis_skinny_finalize_fp8")
 
 
 def skinny_finalize(part: torch.Tensor, ksplit: int, y: torch.Tensor, N: int, bias: Optional[torch.Tensor] = None,
