@@ -125,7 +125,9 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
             cfg = Qwen2VLConfig.from_hf_dir(path)
             w = W.load_safetensors_dir(cfg, path, device)
             tok = HFTokenizer(path, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
-        lm = LoadedModel(Qwen2VLEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch), tok, cfg, model_id)
+        lm = LoadedModel(Qwen2VLEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch,
+                                       decode_weights=os.environ.get("VIS_DECODE_WEIGHTS", "bf16"),
+                                       prefill_dtype=os.environ.get("VIS_PREFILL_DTYPE", "bf16")), tok, cfg, model_id)
         _ENGINES[key] = lm
         return lm
 
