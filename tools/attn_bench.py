@@ -18,6 +18,10 @@ ld = (S + 63) // 64 * 64
 vt = torch.randn((Hkv, HD, ld), device=dev).to(torch.bfloat16)
 o = torch.empty((S, Hq * HD), dtype=torch.bfloat16, device=dev)
 work = hip.make_attn_work([(0, S)], causal, dev, heads=Hq if a.plan else 0)
+if os.environ.get("VIS_ATTN_FULLS") is not None and not causal:   # experiment: k full items per head, rest as 64-row items
+    nf = int(os.environ["VIS_ATTN_FULLS"])
+    items = [(q0, 128, 0, S) for q0 in range(0, nf * 128, 128)] + [(q0, min(64, S - q0), 0, S) for q0 in range(nf * 128, S, 64)]
+    work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
 print('items', work.shape[0], 'half', int((work[:, 1] <= 64).sum()))
 for _ in range(2):
     hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)

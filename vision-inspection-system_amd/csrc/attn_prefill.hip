@@ -18,7 +18,10 @@
 // Per workgroup: 256 threads = 4 waves; a wave owns 32 query rows (two 16-row
 // blocks) of a 65..128-row item, or 16 rows (one block) of a <= 64-row item, and
 // walks KV tiles of 64 keys that the whole workgroup stages through LDS
-// (double-buffered, register staged, one barrier per tile).
+// (double-buffered, one barrier per tile): head_dim 128 stages through registers (2 workgroups per CU);
+// head_dim 80 stages by LDS-DMA with the swizzles on the source address, recomputes its source offsets per tile
+// and runs the 16 leftover dims of QK^T on v_mfma_f32_16x16x16_bf16 - together that fits 168 VGPRs, i.e. THREE
+// workgroups per CU (PMC: the 2-per-CU kernel left both the MFMA and the VALU pipe < 40 % busy, waves waiting).
 //
 // MFMA formulation (v_mfma_f32_16x16x32_bf16, f32 accumulate, f32 softmax):
 //  * scores are computed TRANSPOSED,  S^T[key][q] = K * Q^T  (A = K rows from
@@ -54,13 +57,16 @@ struct AttnArgs {
 #define ATT_NEG (-1.0e30f)
 
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(AttnArgs p) {
   constexpr int DKS = (HD + 31) / 32;           // QK^T k-steps over d: 4 / 3
   constexpr int ND = HD / 16;                   // P*V output blocks over d: 8 / 5
   constexpr int KCH = HD / 8;                   // valid 16-B chunks per K row: 16 / 10
-  constexpr int KROW = (HD == 128) ? 256 : 224; // LDS bytes per K row (224: conflict-free b128 reads)
-  constexpr int K_BYTES = 64 * KROW;            // 16384 / 13312
-  constexpr int V_BYTES = HD * 128;             // 16384 / 10240
+  // head_dim 80: K / V^T tiles arrive by LDS-DMA (global_load_lds, lane-linear LDS image, the swizzle is applied to the
+  // SOURCE address) - no staging VGPRs, which is what lets three workgroups share a CU (<= 168 VGPRs).
+  constexpr bool DMA = (HD == 80);
+  constexpr int KROW = (HD == 128) ? 256 : 160;         // LDS bytes per K row (d = 80: dense rows)
+  constexpr int K_BYTES = DMA ? 12288 : 64 * KROW;      // DMA: 768 16-byte slots (3 per thread), 640 used
+  constexpr int V_BYTES = DMA ? 12288 : HD * 128;
   constexpr int BUF = K_BYTES + V_BYTES;
   constexpr int K_ITERS = (64 * KCH + 255) / 256;  // 4 / 3
   constexpr int V_ITERS = (HD * 8 + 255) / 256;    // 4 / 3
@@ -86,62 +92,98 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
 
   // ---- Q^T fragments (B operand), kept in registers
-  bf16x8 qf[2][DKS];
+  // head_dim 80 = two 32-wide k-steps + one 16-wide tail on v_mfma_f32_16x16x16_bf16 (lane: row l&15, k = 4(l>>4)+j):
+  // no zero-padded third 32-step (17 % fewer QK^T MFMA cycles, 4 fewer VGPRs, half the K-fragment bytes for it)
+  constexpr int DKF = HD / 32;                 // full 32-wide k-steps: 4 / 2
+  constexpr bool TAIL16 = (HD % 32) == 16;
+  typedef short bf16x4s __attribute__((ext_vector_type(4)));
+  bf16x8 qf[2][DKF];
+  bf16x4s qt[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = min(wq0 + qb * 16 + l15, p.Sq - 1);
     const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
 #pragma unroll
-    for (int ds = 0; ds < DKS; ++ds) {
-      const int d = ds * 32 + 8 * h;
-      u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
-      if (d < HD) raw = *(const u32x4*)(qp + d);
-      qf[qb][ds] = __builtin_bit_cast(bf16x8, raw);
-    }
+    for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ds * 32 + 8 * h));
+    qt[qb] = TAIL16 ? __builtin_bit_cast(bf16x4s, *(const u32x2*)(qp + DKF * 32 + 4 * h)) : (bf16x4s){0, 0, 0, 0};
   }
 
-  // zero the d-padding chunks of both K buffers once (head_dim 80 only)
-  if (HD != 128) {
-    for (int it = tid; it < 2 * 64 * 2; it += 256) {
-      const int b = it >> 7, row = (it >> 1) & 63, c = KCH + (it & 1);
-      *(u32x4*)(lds + b * BUF + row * KROW + c * 16) = (u32x4){0u, 0u, 0u, 0u};
-    }
-  }
 
   // per-thread staging slots, computed once (no div/mod inside the KV loop)
   int k_goff[K_ITERS], k_loff[K_ITERS], k_row[K_ITERS], v_goff[V_ITERS], v_loff[V_ITERS];
+  u32x4 kreg[DMA ? 1 : K_ITERS], vreg[DMA ? 1 : V_ITERS];
+  if constexpr (DMA) {
+    // LDS slot p = i * 256 + tid (16 bytes each, lane-linear per wave instruction).  K slot p holds chunk
+    // c ^ ((row >> 3) & 1) of row p / 10: rows r and r + 8 then land on different bank quads (dense 160-byte rows
+    // alone would collide two-way); V^T slot p holds chunk c ^ ((d >> 1) & 7) of row d = p / 8, as before.
+    // The source offsets are RECOMPUTED per tile (a dozen integer ops per DMA): kept as loop-invariant arrays they
+    // were spilled at 168 VGPRs, and every scratch reload forced an s_waitcnt vmcnt(0) between two DMAs.
 #pragma unroll
-  for (int i = 0; i < K_ITERS; ++i) {
-    const int it = min(tid + i * 256, 64 * KCH - 1);
-    const int row = it / KCH, c = it - row * KCH;
-    k_row[i] = row;
-    k_goff[i] = c * 8;
-    k_loff[i] = row * KROW + (((HD == 128) ? (c ^ (row & 15)) : c) << 4);
-  }
+    for (int i = 0; i < K_ITERS; ++i) { k_row[i] = 0; k_goff[i] = 0; k_loff[i] = 0; }
 #pragma unroll
-  for (int i = 0; i < V_ITERS; ++i) {
-    const int it = min(tid + i * 256, HD * 8 - 1);
-    const int d = it >> 3, c = it & 7;
-    v_goff[i] = d * p.vt_ld + c * 8;
-    v_loff[i] = K_BYTES + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
-  }
-  u32x4 kreg[K_ITERS], vreg[V_ITERS];
-  // loads are unconditional (a thread past the end re-loads the last chunk; the duplicate store is benign)
-  auto load_tile = [&](int kt) {
+    for (int i = 0; i < V_ITERS; ++i) { v_goff[i] = 0; v_loff[i] = 0; }
+  } else {
 #pragma unroll
     for (int i = 0; i < K_ITERS; ++i) {
-      const int key = min(kt + k_row[i], p.k_tokens - 1);
-      kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + k_goff[i]);
+      const int it = min(tid + i * 256, 64 * KCH - 1);
+      const int row = it / KCH, c = it - row * KCH;
+      k_row[i] = row;
+      k_goff[i] = c * 8;
+      k_loff[i] = row * KROW + ((c ^ (row & 15)) << 4);
     }
 #pragma unroll
-    for (int i = 0; i < V_ITERS; ++i) vreg[i] = *(const u32x4*)(Vh + v_goff[i] + kt);
+    for (int i = 0; i < V_ITERS; ++i) {
+      const int it = min(tid + i * 256, HD * 8 - 1);
+      const int d = it >> 3, c = it & 7;
+      v_goff[i] = d * p.vt_ld + c * 8;
+      v_loff[i] = K_BYTES + d * 128 + ((c ^ ((d >> 1) & 7)) << 4);
+    }
+  }
+  const int dma_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
+  // global -> LDS of one 64-key tile (DMA), or global -> registers (the head_dim 128 path stores them later)
+  auto load_tile = [&](int kt, int buf) {
+    if constexpr (DMA) {
+      char* base = lds + buf * BUF + dma_base;
+      int t = tid;
+      asm volatile("" : "+v"(t));   // opaque: the offsets below are recomputed here, not hoisted out of the loop
+      const char* kbase = (const char*)Kh;
+      const char* vbase = (const char*)(Vh + kt);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int ps = i * 256 + t;
+        const int r0 = (ps * 6554) >> 16;                 // ps / 10 for ps < 768
+        const int c = ps - r0 * 10, row = min(r0, 63);
+        const int key = min(kt + row, p.k_tokens - 1);
+        const uint32_t off = (uint32_t)key * (HD * 2) + ((c ^ ((row >> 3) & 1)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + off),
+                                         (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int ps = i * 256 + t;
+        const int d = min(ps >> 3, HD - 1), cv = ps & 7;
+        const uint32_t off = (uint32_t)d * (uint32_t)(p.vt_ld * 2) + ((cv ^ ((d >> 1) & 7)) << 4);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + off),
+                                         (__attribute__((address_space(3))) void*)(base + K_BYTES + i * 4096), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < K_ITERS; ++i) {
+        const int key = min(kt + k_row[i], p.k_tokens - 1);
+        kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + k_goff[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < V_ITERS; ++i) vreg[i] = *(const u32x4*)(Vh + v_goff[i] + kt);
+    }
   };
   auto store_tile = [&](int buf) {
-    char* base = lds + buf * BUF;
+    if constexpr (!DMA) {
+      char* base = lds + buf * BUF;
 #pragma unroll
-    for (int i = 0; i < K_ITERS; ++i) *(u32x4*)(base + k_loff[i]) = kreg[i];
+      for (int i = 0; i < K_ITERS; ++i) *(u32x4*)(base + k_loff[i]) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < V_ITERS; ++i) *(u32x4*)(base + v_loff[i]) = vreg[i];
+      for (int i = 0; i < V_ITERS; ++i) *(u32x4*)(base + v_loff[i]) = vreg[i];
+    }
   };
 
   // oacc[qb][ND] is the softmax denominator: P is multiplied by one extra "V column" of ones (a register
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
 
   if (nt > 0) {
-    load_tile(kt_begin);
+    load_tile(kt_begin, 0);
     store_tile(0);
   }
   __syncthreads();
@@ -167,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   for (int t = 0; t < nt; ++t) {
     const int kt = kt_begin + t * 64;
     const bool more = (t + 1 < nt);
-    if (more) load_tile(kt + 64);
+    if (more) load_tile(kt + 64, cur ^ 1);
 
     const bool active = !CAUSAL || (kt <= wq0 + wrows - 1);
     auto tile_body = [&](auto nq_tag) {
@@ -181,13 +223,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 #pragma unroll
         for (int qb = 0; qb < NQ; ++qb) sacc[kbk][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ds = 0; ds < DKS; ++ds) {
+      for (int ds = 0; ds < DKF; ++ds) {
         bf16x8 kf[4];
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk) {
           const int row = kbk * 16 + l15;
           const int c = ds * 4 + h;
-          const int pc = (HD == 128) ? (c ^ l15) : c;
+          const int pc = (HD == 128) ? (c ^ l15) : (c ^ ((l15 >> 3) & 1));
           kf[kbk] = *(const bf16x8*)(kb + row * KROW + pc * 16);
         }
 #pragma unroll
@@ -198,6 +240,20 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
       }
 
       const bool need_mask = (kt < k0) || (kt + 64 > k1) || (CAUSAL && (kt + 63 > wq0));
+      if constexpr (TAIL16) {   // dims 64..79: chunk 8 + (h >> 1), 8-byte half (h & 1)
+        bf16x4s kt4[4];
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk) {
+          const int row = kbk * 16 + l15;
+          const int pc = (DKF * 4 + (h >> 1)) ^ ((l15 >> 3) & 1);
+          kt4[kbk] = __builtin_bit_cast(bf16x4s, *(const u32x2*)(kb + row * KROW + pc * 16 + (h & 1) * 8));
+        }
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+          for (int qb = 0; qb < NQ; ++qb)
+            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt4[kbk], qt[qb], sacc[kbk][qb], 0, 0, 0);
+      }
       // ---- online softmax (query on the lane, keys in registers), log2 domain:
       //      p = exp2(s * scale_log2 - m), one FMA + one raw v_exp_f32 per score
       float alpha[NQ];
@@ -340,13 +396,17 @@ extern "C" int vis_attn_prefill(const void* Q, const void* K, const void* Vt, vo
   p.scale_log2 = scale * 1.4426950408889634f;
   if (n_work > 65535) return VIS_ERR_ARG;
   const dim3 grid(Hq, n_work), block(256);
+  // head_dim 80 is built for three workgroups per CU (768 slots, <= 168 VGPRs).  VIS_ATTN_OCC=2 caps residency at two
+  // per CU by asking for idle dynamic LDS (A/B runs only: three per CU measured faster on every shape tried).
+  static const int occ_forced = [] { const char* e = getenv("VIS_ATTN_OCC"); return e ? atoi(e) : 0; }();
+  const size_t pad_lds = (HD == 80 && occ_forced == 2) ? 28 * 1024 : 0;   // 48 KiB static + 28 KiB -> two per CU
   vis_clear_error();
   if (HD == 128) {
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, stream, p);
   } else {
-    if (causal) hipLaunchKernelGGL((attn_prefill_kernel<80, true>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((attn_prefill_kernel<80, false>), grid, block, 0, stream, p);
+    if (causal) hipLaunchKernelGGL((attn_prefill_kernel<80, true>), grid, block, pad_lds, stream, p);
+    else hipLaunchKernelGGL((attn_prefill_kernel<80, false>), grid, block, pad_lds, stream, p);
   }
   return vis_check_launch();
 }
