@@ -103,6 +103,6 @@ def test_attention_work_planner_partitions_rows():
         sizes = [it[1] > 64 for it in items]
         assert sizes == sorted(sizes, reverse=True)          # full items first
     vit = hip.plan_attn_items([(0, 4900)], 16)
-    assert sum(1 for it in vit if it[1] > 64) * 16 == hip.ATTN_SLOTS   # fulls fill exactly one round
+    assert hip.ATTN_SLOTS - 32 < len(vit) * 16 <= hip.ATTN_SLOTS - 16      # as fine as one round allows, one item of slack
     assert hip.plan_attn_items([(0, 4900)], 0) == [(q, min(128, 4900 - q), 0, 4900) for q in range(0, 4864, 128)] + \
         [(4864, 36, 0, 4900)]

@@ -253,7 +253,7 @@ def qkv_rope_split(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional
 
 
 # --------------------------------------------------------------------------- K6 / K7
-ATTN_SLOTS = 512          # resident attention workgroups on MI355X: 256 CUs x 2
+ATTN_SLOTS = 768          # resident head_dim-80 attention workgroups on MI355X: 256 CUs x 3 (head_dim 128: x 2)
 ATTN_HALF_COST = 0.6      # a 64-row item relative to a 128-row item (same K/V staging, half the MFMAs)
 
 
@@ -267,32 +267,37 @@ def _attn_makespan(n_full: int, n_half: int, slots: int = ATTN_SLOTS) -> float:
     return max(free)
 
 
-def plan_attn_items(segments, heads: int, block_q: int = 128):
+def plan_attn_items(segments, heads: int, block_q: int = 128, slots: int = ATTN_SLOTS):
     """Non-causal work items [(q0, qn, k0, k1)], full (<= block_q rows) items first, then 64-row halves.
-    Trailing full items are cut in two when that shortens the modelled schedule of items x heads workgroups
-    (the last, partial round of the 512 slots is filled with cheaper items)."""
+    Measured rule (MI355X, ViT 4900 x 16 heads): as long as everything stays ONE round of the resident slots, finer
+    items balance the CUs better (30 full + 17 half items per head: 0.214 ms; 39 full: 0.226 ms); one workgroup past
+    the round costs 20 % (28 + 21: 0.260 ms).  So trailing full items are cut in two while items x heads <= slots;
+    grids that need several rounds anyway use the modelled list schedule to fill the last round with halves."""
     full, half = [], []
     for (s, e) in segments:
         for q0 in range(s, e, block_q):
             qn = min(block_q, e - q0)
             (half if qn <= block_q // 2 else full).append((q0, qn, s, e))
-    if heads > 0 and len(full) * heads > ATTN_SLOTS:
-        keep = (len(full) * heads // ATTN_SLOTS) * ATTN_SLOTS // heads   # fulls that fill whole rounds
-        best = (_attn_makespan(len(full) * heads, len(half) * heads), len(full))
-        for k in (keep, keep - 1):
-            if 0 < k < len(full):
-                cut = len(full) - k
-                t = _attn_makespan(k * heads, (len(half) + 2 * cut) * heads)
+    if heads <= 0 or not full:
+        return full + half
+    k = len(full)
+    if (len(full) + len(half)) * heads <= slots:
+        while k > 0 and (k - 1 + len(half) + 2 * (len(full) - k + 1)) * heads <= slots - heads:   # one item of slack
+            k -= 1
+    elif len(full) * heads > slots:
+        keep = (len(full) * heads // slots) * slots // heads       # fulls that fill whole rounds
+        best = (_attn_makespan(len(full) * heads, len(half) * heads, slots), len(full))
+        for c in (keep, keep - 1):
+            if 0 < c < len(full):
+                t = _attn_makespan(c * heads, (len(half) + 2 * (len(full) - c)) * heads, slots)
                 if t < best[0] - 1e-9:
-                    best = (t, k)
+                    best = (t, c)
         k = best[1]
-        for (q0, qn, s, e) in full[k:]:
-            h1 = (qn + 1) // 2
-            h1 = min(block_q // 2, (h1 + 15) // 16 * 16)
-            half.append((q0, h1, s, e))
-            half.append((q0 + h1, qn - h1, s, e))
-        full = full[:k]
-    return full + half
+    for (q0, qn, s, e) in full[k:]:
+        h1 = min(block_q // 2, ((qn + 1) // 2 + 15) // 16 * 16)
+        half.append((q0, h1, s, e))
+        half.append((q0 + h1, qn - h1, s, e))
+    return full[:k] + half
 
 
 def make_attn_work(segments, causal: bool, device, block_q: int = 128, heads: int = 0) -> torch.Tensor:
