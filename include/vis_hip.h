@@ -167,10 +167,11 @@ int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, const void* sw,
                  void* C, void* work, int ksplit, int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act,
                  vis_stream_t stream);
 
-/* Per-row dynamic quantisation of bf16 activations to e4m3: scale[m] = amax(row)/448, q = rne(x/scale); with norm_w
- * != NULL the row is RMS-normalised first (same values vis_rmsnorm_bf16 writes; K <= 4096). */
-int vis_quant_rows_fp8(const void* x, const void* norm_w, void* q, void* scale, int rows, int K, int ldx, int ldq,
-                       float eps, vis_stream_t stream);
+/* Per-row dynamic quantisation of bf16 activations to e4m3: scale[m] = amax(row)/448, q = rne(x * (1/scale)); with
+ * norm_w != NULL the row is normalised first (K <= 4096): RMSNorm when norm_b == NULL, LayerNorm otherwise - the
+ * same bf16 values vis_rmsnorm_bf16 / vis_layernorm_bf16 write. */
+int vis_quant_rows_fp8(const void* x, const void* norm_w, const void* norm_b, void* q, void* scale, int rows, int K,
+                       int ldx, int ldq, float eps, vis_stream_t stream);
 
 /* BASELINE configs[4], batched decode: fp8 forms of vis_gemm_decode_bf16 / vis_skinny_finalize.
  * vis_gemm_decode_fp8: xq [B][ldx] / Wq [N][ldw] OCP e4m3 bytes (K % 128 == 0) on the block-scaled fp8 MFMA, same

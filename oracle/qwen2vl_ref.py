@@ -141,9 +141,11 @@ def vision_cos_sin(cfg: RefConfig, grids) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 def vision_forward(cfg: RefConfig, sd: Dict[str, torch.Tensor], pixel_values: torch.Tensor, grids,
-                   taps: Optional[dict] = None) -> torch.Tensor:
-    """pixel_values [N, 1176] -> merged image embeddings [N/4, hidden]."""
+                   taps: Optional[dict] = None, act_fp8: bool = False) -> torch.Tensor:
+    """pixel_values [N, 1176] -> merged image embeddings [N/4, hidden].  act_fp8: fake-quantise the input of the four
+    block projections per row to e4m3 (fp8 configuration; ``sd`` then holds the de-quantised e4m3 block weights)."""
     E, H, D = cfg.v_embed, cfg.v_heads, cfg.v_head_dim
+    fq = fake_quant_rows_e4m3 if act_fp8 else (lambda t: t)
     w_pe = sd["visual.patch_embed.proj.weight"].reshape(E, -1)
     x = pixel_values @ w_pe.t()
     if taps is not None:
@@ -156,7 +158,7 @@ def vision_forward(cfg: RefConfig, sd: Dict[str, torch.Tensor], pixel_values: to
             start += h * w
     for i in range(cfg.v_depth):
         p = f"visual.blocks.{i}."
-        y = F.layer_norm(x, (E,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
+        y = fq(F.layer_norm(x, (E,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6))
         qkv = y @ sd[p + "attn.qkv.weight"].t() + sd[p + "attn.qkv.bias"]
         qkv = qkv.reshape(-1, 3, H, D)
         q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]  # [N, H, D]
@@ -166,11 +168,11 @@ def vision_forward(cfg: RefConfig, sd: Dict[str, torch.Tensor], pixel_values: to
         for (s, e) in seg:
             sc = torch.einsum("qhd,khd->hqk", q[s:e], k[s:e]) * (D ** -0.5)
             att[s:e] = torch.einsum("hqk,khd->qhd", torch.softmax(sc, dim=-1), v[s:e])
-        x = x + att.reshape(-1, E) @ sd[p + "attn.proj.weight"].t() + sd[p + "attn.proj.bias"]
-        y = F.layer_norm(x, (E,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+        x = x + fq(att.reshape(-1, E)) @ sd[p + "attn.proj.weight"].t() + sd[p + "attn.proj.bias"]
+        y = fq(F.layer_norm(x, (E,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6))
         y = y @ sd[p + "mlp.fc1.weight"].t() + sd[p + "mlp.fc1.bias"]
         y = y * torch.sigmoid(1.702 * y)  # quick_gelu
-        x = x + y @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"]
+        x = x + fq(y) @ sd[p + "mlp.fc2.weight"].t() + sd[p + "mlp.fc2.bias"]
         if taps is not None and i == 0:
             taps["vit_block0"] = x.clone()
     y = F.layer_norm(x, (E,), sd["visual.merger.ln_q.weight"], sd["visual.merger.ln_q.bias"], 1e-6)
@@ -299,7 +301,12 @@ def generate(cfg: RefConfig, sd: Dict[str, torch.Tensor], input_ids: Sequence[in
     """Greedy decode.  Returns (tokens, per-step logits list [vocab] - entry t produced token t).
     ``decode_sd``: a second state dict used for the per-token steps only (the prompt still runs on ``sd``) - how the
     fp8-decode-weights configuration is checked: decode_sd holds the de-quantised e4m3 projections."""
-    img = vision_forward(cfg, sd, pixel_values, grids, taps) if pixel_values is not None else None
+    if pixel_values is None:
+        img = None
+    elif prefill_fp8_sd is not None:
+        img = vision_forward(cfg, prefill_fp8_sd, pixel_values, grids, taps, act_fp8=True)
+    else:
+        img = vision_forward(cfg, sd, pixel_values, grids, taps)
     x = embed_inputs(cfg, sd, input_ids, img)
     pos3, next_pos = rope_index(cfg, input_ids, grids or [])
     cos, sin = mrope_cos_sin(cfg, pos3)

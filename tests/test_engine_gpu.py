@@ -151,6 +151,10 @@ def _dequantised_sd(cfg, sd):
         dsd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(cfg.intermediate, cfg.hidden)
         dsd[p + "mlp.down_proj.weight"] = dq(sd[p + "mlp.down_proj.weight"])
     dsd["lm_head.weight"] = dq(sd["lm_head.weight"])
+    for i in range(cfg.v_depth):
+        p = f"visual.blocks.{i}."
+        for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+            dsd[p + n] = dq(sd[p + n])
     return dsd
 
 
@@ -202,7 +206,7 @@ def test_vit_two_stream_split_equals_single_stream(setup, device):
     assert (a - b).abs().max() < 1e-6 * max(1.0, float(a.abs().max())) or torch.equal(a, b)
 
 
-def test_fp8_prefill_matches_oracle_with_fake_quant(setup, device):
+def test_fp8_prefill_matches_oracle_with_fake_quant(setup, device, monkeypatch):
     """configs[4]: LLM projections of the prompt pass on the fp8 MFMA (e4m3 weights, per-token e4m3 activations).
     The oracle fake-quantises the same tensors (de-quantised weights, per-row activation quantise/de-quantise).
     A quantiser is discontinuous: the bf16-level differences between the GPU pipeline and the fp32 oracle move some
@@ -214,8 +218,10 @@ def test_fp8_prefill_matches_oracle_with_fake_quant(setup, device):
     from vision_inspection_system_amd.engine import Qwen2VLEngine
     from vision_inspection_system_amd.weights import pack_device_weights
     cfg, sd, eng16 = setup
+    monkeypatch.setenv("VIS_VIT_FP8", "1")      # exercise the (opt-in) fp8 ViT projections too
     eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, decode_splits=4,
                         prefill_dtype="fp8")
+    assert eng.vq8
     g = load_golden()
     dsd = _dequantised_sd(cfg, sd)
     psd = dict(dsd)
@@ -229,7 +235,7 @@ def test_fp8_prefill_matches_oracle_with_fake_quant(setup, device):
         eng.prefill(ids, [torch.from_numpy(f).to(device) for f in fr], taps=taps)
         got = taps["first_logits"].float().cpu()
         e8, e16 = (got - l8[0]).abs(), (got - l16[0]).abs()
-        assert e8.mean() < 0.05 and e8.max() < 0.35, (float(e8.mean()), float(e8.max()))
+        assert e8.mean() < 0.06 and e8.max() < 0.4, (float(e8.mean()), float(e8.max()))
         if not fr:
             assert e8.mean() < e16.mean()
         assert e16.max() > 1e-3                                 # really a different arithmetic from bf16

@@ -268,6 +268,18 @@ def test_quant_rows_fp8(hip, device, M, K, norm):
     assert (deq - xf).abs().max() <= xf.abs().amax() / 16 + 1e-6
 
 
+def test_quant_rows_fp8_fused_layernorm(hip, device):
+    M, K = 300, 1280
+    x = _randn((M, K), device, 185, 2.0)
+    nw, nb = _randn((K,), device, 186), _randn((K,), device, 187)
+    q, sc = hip.quant_rows_fp8(x, norm_w=nw, norm_b=nb, eps=1e-6)
+    ref = hip.layernorm(x, nw, nb, 1e-6).float()                      # the bf16 values the norm kernel writes
+    ref_sc = (ref.abs().amax(dim=1) / 448.0).clamp_min(1e-12)
+    assert torch.allclose(sc, ref_sc, rtol=1e-6, atol=0)
+    ref_q = (ref * (1.0 / sc)[:, None]).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (q != ref_q).float().mean().item() < 1e-6
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 1024), (2249, 4608, 3584), (2249, 3584, 18944), (77, 100, 256)])
 def test_gemm_fp8(hip, device, M, N, K):
     """Against the SAME quantised operands in fp32: the kernel adds only f32 accumulation-order effects."""

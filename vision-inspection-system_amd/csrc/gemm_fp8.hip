@@ -312,8 +312,8 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
 // ---------------------------------------------------------------------------
 // vis_quant_rows_fp8: per-row (per-token) dynamic quantisation of bf16 activations to e4m3:
 //   scale[m] = max(|x[m][:]|) / 448 (>= 1e-12),  q[m][k] = e4m3_rne(x[m][k] / scale[m])
-// with an optional fused RMSNorm in front (norm_w != null: x <- bf16(bf16(x * rstd) * w), exactly the values
-// vis_rmsnorm_bf16 would have written).  One wave per row, the row lives in registers.
+// with an optional fused norm in front, producing exactly the bf16 values vis_rmsnorm_bf16 / vis_layernorm_bf16 would
+// have written: norm_w only -> RMSNorm (x <- bf16(bf16(x * rstd) * w)); norm_w and norm_b -> LayerNorm.  One wave per row, the row lives in registers.
 #define QR_MAX_CHUNKS 8  // register-resident rows: K <= 64 * 8 * 8 = 4096 (the fused-norm case); longer rows stream
 
 __device__ __forceinline__ u32x2 qr_pack8(const float* f, float inv) {
@@ -327,8 +327,9 @@ __device__ __forceinline__ u32x2 qr_pack8(const float* f, float inv) {
 }
 
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ nw,
-                                                             uint8_t* __restrict__ q, float* __restrict__ scale,
-                                                             int rows, int K, int ldx, int ldq, float eps) {
+                                                             const bf16_t* __restrict__ nb, uint8_t* __restrict__ q,
+                                                             float* __restrict__ scale, int rows, int K, int ldx,
+                                                             int ldq, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -347,7 +348,39 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
         for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
       }
     }
-    if (nw) {
+    if (nw && nb) {   // LayerNorm (ViT): same arithmetic and single bf16 rounding as norm_rows_kernel<true>
+      float sm = 0.f;
+#pragma unroll
+      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sm += v[i][e];
+        }
+      }
+      const float mean = wave_sum(sm) / (float)K;
+      float d2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = v[i][e] - mean; d2 += d * d; }
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(d2) / (float)K + eps);
+#pragma unroll
+      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+        const int c = lane + i * 64;
+        if (c < nch) {
+          float w[8], b[8];
+          unpack8(*(const u32x4*)(nw + c * 8), w);
+          unpack8(*(const u32x4*)(nb + c * 8), b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[i][e] = bf2f(f2bf((v[i][e] - mean) * rstd * w[e] + b[e]));
+        }
+      }
+    } else if (nw) {  // RMSNorm (LLM)
       ss = wave_sum(ss);
       const float rstd = rsqrtf(ss / (float)K + eps);
 #pragma unroll
@@ -399,14 +432,16 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   }
 }
 
-extern "C" int vis_quant_rows_fp8(const void* x, const void* norm_w, void* q, void* scale, int rows, int K, int ldx,
-                                  int ldq, float eps, hipStream_t stream) {
+extern "C" int vis_quant_rows_fp8(const void* x, const void* norm_w, const void* norm_b, void* q, void* scale,
+                                  int rows, int K, int ldx, int ldq, float eps, hipStream_t stream) {
   if (!x || !q || !scale || rows <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % 8 != 0 || ldx % 8 != 0 || ldq % 8 != 0 || ldq < K) return VIS_ERR_ARG;
   if (norm_w && K > 64 * 8 * QR_MAX_CHUNKS) return VIS_ERR_ARG;  // the fused norm needs the row in registers
-  if (((uintptr_t)x | (uintptr_t)norm_w) & 15 || ((uintptr_t)q & 7) || ((uintptr_t)scale & 3)) return VIS_ERR_ARG;
+  if (norm_b && !norm_w) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)norm_w | (uintptr_t)norm_b) & 15 || ((uintptr_t)q & 7) || ((uintptr_t)scale & 3))
+    return VIS_ERR_ARG;
   vis_clear_error();
   hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x,
-                     (const bf16_t*)norm_w, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
+                     (const bf16_t*)norm_w, (const bf16_t*)norm_b, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
   return vis_check_launch();
 }

@@ -192,6 +192,23 @@ class Qwen2VLEngine:
                     q["down_w_pad"] = (pad, sc)
             if prefill_dtype == "fp8" and (cfg.hidden % 128 or (cfg.heads * cfg.head_dim) % 128):
                 raise ValueError("fp8 prefill needs hidden and heads*head_dim to be multiples of 128")
+        self.vq8: List[dict] = []
+        if prefill_dtype == "fp8" and cfg.v_mlp % 128 == 0 and os.environ.get("VIS_VIT_FP8", "0") == "1":
+            # OPT-IN (VIS_VIT_FP8=1): ViT block projections in e4m3 too.  Measured slower than bf16 on the 7B tower:
+            # the fp8 GEMM only has the 256x256 tile, and at M = 4900 / N = 1280..5120 that leaves 100-400 tiles for 256
+            # CUs (proj / fc2: 100 tiles) - it needs a 128x128 fp8 tile first.  K = v_embed is zero-padded to a
+            # multiple of 128 when necessary (tiny: 320).
+            self.vepad = _round_up(cfg.v_embed, 128)
+
+            def q8pad(wt):
+                wq, sc = hip.quantize_fp8_rows(wt)
+                if wq.shape[1] % 128:
+                    pad = torch.zeros((wq.shape[0], _round_up(wq.shape[1], 128)), dtype=torch.uint8, device=wq.device)
+                    pad[:, :wq.shape[1]] = wq
+                    wq = pad
+                return wq, sc
+            for b in weights.vit:
+                self.vq8.append({n: q8pad(getattr(b, n)) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w")})
         self.slot_prompt_len = [0] * Bm
         self._prefill_streams: List[torch.cuda.Stream] = []
         self._vit_side_streams: List[torch.cuda.Stream] = []
@@ -290,7 +307,23 @@ class Qwen2VLEngine:
         att = torch.empty((N, E), dtype=bf, device=dev)
         hmid = torch.empty((N, cfg.v_mlp), dtype=bf, device=dev)
         scale = D ** -0.5
-        if split_rows and len(frames) == 1 and N >= self.vit_split_min_rows and self.vit_streams == 2:
+        if self.vq8:
+            # fp8 configuration: the four block projections on the fp8 MFMA, LayerNorm fused into the activation quantiser
+            xq = torch.zeros((N, self.vepad), dtype=torch.uint8, device=dev)      # pad columns stay 0
+            hq = torch.empty((N, cfg.v_mlp), dtype=torch.uint8, device=dev)
+            sx = torch.empty(N, dtype=torch.float32, device=dev)
+            for b, q8 in zip(w.vit, self.vq8):
+                hip.quant_rows_fp8(x, xq, sx, norm_w=b.ln1_w, norm_b=b.ln1_b, eps=1e-6)
+                hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=b.qkv_b, out=qkv)
+                hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
+                hip.attn_prefill(q, k, vt, att, work, False, scale)
+                hip.quant_rows_fp8(att, xq, sx)
+                hip.gemm_fp8(xq, sx, *q8["proj_w"], bias=b.proj_b, residual=x, out=x)
+                hip.quant_rows_fp8(x, xq, sx, norm_w=b.ln2_w, norm_b=b.ln2_b, eps=1e-6)
+                hip.gemm_fp8(xq, sx, *q8["fc1_w"], bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid)
+                hip.quant_rows_fp8(hmid, hq, sx)
+                hip.gemm_fp8(hq, sx, *q8["fc2_w"], bias=b.fc2_b, residual=x, out=x)
+        elif split_rows and len(frames) == 1 and N >= self.vit_split_min_rows and self.vit_streams == 2:
             self._vit_blocks_two_streams(x, y, qkv, att, hmid, cos, sin, N, ld)
         else:
             for b in w.vit:

@@ -24,7 +24,7 @@ _SIGS = {
     "vis_gemm_bf16": "ppppp" + "iiiiiiii" + "p",
     "vis_gemm_bf16_splitk": "pppppp" + "iiiiiiiii" + "p",
     "vis_gemm_fp8": "pppppppp" + "iiiiiiiii" + "p",
-    "vis_quant_rows_fp8": "pppp" + "iiii" + "f" + "p",
+    "vis_quant_rows_fp8": "ppppp" + "iiii" + "f" + "p",
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
@@ -150,17 +150,19 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, work: torch.Tensor, ksplit: in
 
 
 def quant_rows_fp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
-                   norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6):
-    """bf16 [M, K] -> (e4m3 bytes [M, K] uint8, f32 row scales [M]) on the GPU; optional fused RMSNorm in front."""
+                   norm_w: Optional[torch.Tensor] = None, eps: float = 1e-6, norm_b: Optional[torch.Tensor] = None):
+    """bf16 [M, K] -> (e4m3 bytes [M, >= K] uint8, f32 row scales [M]) on the GPU; optional fused RMSNorm (norm_w) or
+    LayerNorm (norm_w + norm_b) in front."""
     _bf16(x, "quant_rows_fp8 x")
     M, K = x.shape
     if q is None:
         q = torch.empty((M, K), dtype=torch.uint8, device=x.device)
     if scale is None:
         scale = torch.empty(M, dtype=torch.float32, device=x.device)
-    if q.dtype != torch.uint8 or q.shape != (M, K) or q.stride(1) != 1 or scale.numel() != M or x.stride(1) != 1:
+    if q.dtype != torch.uint8 or q.shape[0] != M or q.shape[1] < K or q.stride(1) != 1 or scale.numel() != M \
+            or x.stride(1) != 1:
         raise HipLibraryError("quant_rows_fp8: bad shapes")
-    rc = load().vis_quant_rows_fp8(_ptr(x), _ptr(norm_w), _ptr(q), _ptr(scale), M, K, x.stride(0), q.stride(0), eps,
+    rc = load().vis_quant_rows_fp8(_ptr(x), _ptr(norm_w), _ptr(norm_b), _ptr(q), _ptr(scale), M, K, x.stride(0), q.stride(0), eps,
                                    _stream())
     _check(rc, "vis_quant_rows_fp8")
     return q, scale
