@@ -44,6 +44,146 @@ __device__ __forceinline__ float f8_act(float x, int act) {
   return x;
 }
 
+// 64 x 64 output block of one wave: lane holds D[n = nbase + 16 j + 4 h + r][m = mbase + 16 i + l15] (W was the A operand)
+__device__ __forceinline__ void f8_epilogue(const GemmF8Args& p, f32x4 (&acc)[4][4], int mbase, int nbase, int l15, int h) {
+  const bool swiglu = (p.act == F8_ACT_SWIGLU);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = mbase + i * 16 + l15;
+    if (m >= p.M) continue;
+    const float sam = p.sa[m];
+    if (swiglu) {
+#pragma unroll
+      for (int j = 0; j < 4; j += 2) {
+        const int n = nbase + j * 16 + 4 * h;  // gate rows; the matching up rows are n + 16
+        if (n >= p.N) continue;
+        const int oc = (nbase >> 1) + (j >> 1) * 16 + 4 * h;
+        const f32x4 sg = *(const f32x4*)(p.sw + n), su = *(const f32x4*)(p.sw + n + 16);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float g = acc[i][j][r] * sam * sg[r], u = acc[i][j + 1][r] * sam * su[r];
+          v[r] = g / (1.0f + __expf(-g)) * u;
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + oc) = o;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = nbase + j * 16 + 4 * h;
+        if (n >= p.N) continue;
+        const f32x4 s4 = *(const f32x4*)(p.sw + n);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sam * s4[r];
+        if (p.bias) {
+          const u32x2 b = *(const u32x2*)(p.bias + n);
+          v[0] += __uint_as_float(b[0] << 16);
+          v[1] += __uint_as_float(b[0] & 0xffff0000u);
+          v[2] += __uint_as_float(b[1] << 16);
+          v[3] += __uint_as_float(b[1] & 0xffff0000u);
+        }
+        if (p.act != F8_ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = f8_act(v[r], p.act);
+        }
+        if (p.R) {
+          const u32x2 rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
+          v[0] += __uint_as_float(rr[0] << 16);
+          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rr[1] << 16);
+          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+        }
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
+      }
+    }
+  }
+}
+
+// 128 x 128 x 128 tile, 4 waves (2 x 2) x 64 x 64, two workgroups per CU (2 x 32 KiB LDS): the small-grid / remainder
+// companion of the 256x256 kernel (ViT-sized problems, the ragged last columns of the gate/up projection).
+__global__ __launch_bounds__(256, 2) void gemm_fp8_128x128_kernel(GemmF8Args p) {
+  __shared__ __attribute__((aligned(16))) char lds[2 * 256 * F8_BK];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, h = lane >> 4;
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * 128, n0 = tn * 128;
+  uint32_t a_off[4], w_off[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 3;
+    const int ch = (c & 7) ^ (row & 7);
+    a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.lda + ch * 16;
+    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.ldw + ch * 16;
+  }
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
+  constexpr int A_BYTES = 128 * F8_BK;        // 16 KiB
+  constexpr int BUF_BYTES = 256 * F8_BK;      // 32 KiB
+  auto stage = [&](int buf) {
+    char* base = lds + buf * BUF_BYTES + wave_base;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_base + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_base + w_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 4096), 16, 0, 0);
+    a_base += F8_BK;
+    w_base += F8_BK;
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int sw = lane & 7;
+  const int rdlo = l15 * 128 + (((2 * h) ^ sw) << 4);
+  const int rdhi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
+  const int a_rd = wm * 64 * 128;
+  const int w_rd = A_BYTES + wn * 64 * 128;
+  auto frag = [&](const char* p0) -> i32x8 {
+    const u32x4 lo = *(const u32x4*)(p0 + rdlo), hi = *(const u32x4*)(p0 + rdhi);
+    return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+  const int nk = p.K / F8_BK;
+  stage(0);
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) stage(cur ^ 1);
+    const char* base = lds + cur * BUF_BYTES;
+    i32x8 af[4], wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = frag(base + w_rd + j * 2048);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = frag(base + a_rd + i * 2048);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                     0x7f7f7f7f);
+    __syncthreads();  // also drains the in-flight global_load_lds (vmcnt(0))
+    cur ^= 1;
+  }
+  f8_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
+}
+
 __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) {
   extern __shared__ __attribute__((aligned(16))) char lds8[];
   const int tid = threadIdx.x;
@@ -168,64 +308,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
     }
     return;
   }
-  // ---- epilogue: lane holds D[n = nbase + 16 j + 4 h + r][m = mbase + 16 i + l15] (W was the A operand)
-  const bool swiglu = (p.act == F8_ACT_SWIGLU);
+  // epilogue: two 64-row halves through the shared 4x4 epilogue
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int m = m0 + wm * 128 + i * 16 + l15;
-    if (m >= p.M) continue;
-    const float sam = p.sa[m];
-    if (swiglu) {
+  for (int hm = 0; hm < 2; ++hm) {
+    f32x4 sub[4][4];
 #pragma unroll
-      for (int j = 0; j < 4; j += 2) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * h;  // gate rows; the matching up rows are n + 16
-        if (n >= p.N) continue;
-        const int oc = ((n0 + wn * 64) >> 1) + (j >> 1) * 16 + 4 * h;
-        const f32x4 sg = *(const f32x4*)(p.sw + n), su = *(const f32x4*)(p.sw + n + 16);
-        float v[4];
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float g = acc[i][j][r] * sam * sg[r], u = acc[i][j + 1][r] * sam * su[r];
-          v[r] = g / (1.0f + __expf(-g)) * u;
-        }
-        u32x2 o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        *(u32x2*)(p.C + (size_t)m * p.ldc + oc) = o;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * h;
-        if (n >= p.N) continue;
-        const f32x4 s4 = *(const f32x4*)(p.sw + n);
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] * sam * s4[r];
-        if (p.bias) {
-          const u32x2 b = *(const u32x2*)(p.bias + n);
-          v[0] += __uint_as_float(b[0] << 16);
-          v[1] += __uint_as_float(b[0] & 0xffff0000u);
-          v[2] += __uint_as_float(b[1] << 16);
-          v[3] += __uint_as_float(b[1] & 0xffff0000u);
-        }
-        if (p.act != F8_ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = f8_act(v[r], p.act);
-        }
-        if (p.R) {
-          const u32x2 rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
-          v[0] += __uint_as_float(rr[0] << 16);
-          v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-          v[2] += __uint_as_float(rr[1] << 16);
-          v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-        }
-        u32x2 o;
-        o[0] = pack2bf(v[0], v[1]);
-        o[1] = pack2bf(v[2], v[3]);
-        *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
-      }
-    }
+      for (int j = 0; j < 4; ++j) sub[i][j] = acc[hm * 4 + i][j];
+    f8_epilogue(p, sub, m0 + wm * 128 + hm * 64, n0 + wn * 64, l15, h);
   }
 }
 
@@ -299,8 +390,36 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
     p.part = (float*)work; p.ksplit = ksplit;
   }
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(p.tiles_m * p.tiles_n, p.ksplit), dim3(512), F8_LDS_BYTES, stream,
-                     p);
+  // tile choice (same reasoning as gemm_dispatch for bf16; VIS_GEMM8_TILE=1|4 forces): 256x256 when its last round of
+  // 256 CUs is at least half full, whole rounds + a 128x128 remainder for wide problems, 128x128 (2 WG/CU) otherwise
+  static const int forced = [] { const char* e = getenv("VIS_GEMM8_TILE"); return e ? atoi(e) : 0; }();
+  const int t4 = p.tiles_m * p.tiles_n, last = t4 % 256;
+  auto launch128 = [&](GemmF8Args q) {
+    q.tiles_m = (q.M + 127) / 128;
+    q.tiles_n = (q.N + 127) / 128;
+    hipLaunchKernelGGL(gemm_fp8_128x128_kernel, dim3(q.tiles_m * q.tiles_n), dim3(256), 0, stream, q);
+  };
+  if (work || forced == 4 || (!forced && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128))) {
+    hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(t4, p.ksplit), dim3(512), F8_LDS_BYTES, stream, p);
+  } else if (!forced && M >= 1024 && t4 >= 768) {
+    const int cols4 = (t4 / 256) * 256 / p.tiles_m;  // whole rounds only
+    GemmF8Args q = p;
+    q.N = cols4 * F8_B;
+    q.tiles_n = cols4;
+    hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(q.tiles_m * q.tiles_n, 1), dim3(512), F8_LDS_BYTES, stream, q);
+    const int n_off = cols4 * F8_B;
+    const int c_off = (act == F8_ACT_SWIGLU) ? n_off / 2 : n_off;
+    GemmF8Args r = p;
+    r.W += (size_t)n_off * ldw;
+    r.sw += n_off;
+    if (r.bias) r.bias += n_off;
+    if (r.R) r.R += c_off;
+    r.C += c_off;
+    r.N = N - n_off;
+    launch128(r);
+  } else {
+    launch128(p);
+  }
   if (work) {
     const long long total = (long long)M * (N / 8);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
