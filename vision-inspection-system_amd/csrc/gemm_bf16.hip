@@ -57,8 +57,17 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 
 // Epilogue shared by both tile shapes.  The MFMAs were issued with W as the A operand, so a lane holds
 // D[n = nbase + 16 j + 4 h + r][m = mbase + 16 i + l15], r = 0..3: four consecutive output columns.
+__device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& p, f32x4 (&acc)[4][4], int mbase, int nbase, int l15,
+                                                int h, int ntiles);
+
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4][4], int mbase, int nbase, int l15,
                                               int h) {
+  gemm_epilogue_n(p, acc, mbase, nbase, l15, h, 4);
+}
+
+// ntiles (<= 4): number of valid 16-column tiles in acc (compile-time constant at every call site)
+__device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& p, f32x4 (&acc)[4][4], int mbase, int nbase, int l15,
+                                                int h, int ntiles) {
   const bool swiglu = (p.act == ACT_SWIGLU);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -68,7 +77,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
       for (int j = 0; j < 4; j += 2) {
         const int n = nbase + j * 16 + 4 * h;  // gate row index in the interleaved weight
-        if (n >= p.N) continue;
+        if (j >= ntiles || n >= p.N) continue;
         const int oc = (nbase >> 1) + (j >> 1) * 16 + 4 * h;
         float v[4];
 #pragma unroll
@@ -85,7 +94,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[4]
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int n = nbase + j * 16 + 4 * h;
-        if (n >= p.N) continue;
+        if (j >= ntiles || n >= p.N) continue;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
@@ -363,7 +372,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x128_kernel(GemmArgs p) {
 #define GEMM4_STAGE_BYTES (2 * GEMM4_B * GEMM_BK * 2)  // 65536
 #define GEMM4_LDS_BYTES (2 * GEMM4_STAGE_BYTES)        // 131072
 
-__global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
+// NT = 16-column MFMA tiles per wave: 4 -> 256 x 256 tile, 3 -> 256 x 192 (LLM qkv: 9 x 24 = 216 tiles = one round of
+// the chip instead of 1.27 rounds of 128 x 128 tiles), 2 -> 256 x 128.  Same pipeline; the W panel is NT x 64 rows.
+template <int NT>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256xN_kernel(GemmArgs p) {
+  constexpr int BN4 = 64 * NT;                    // tile columns
+  constexpr int WI = BN4 / 64;                    // W LDS-DMA instructions per thread per stage (= NT)
+  constexpr int NF = 8 + NT;                      // fragment reads per k-half
   extern __shared__ __attribute__((aligned(16))) char lds4[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -374,16 +389,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
   const int nwg = p.tiles_m * p.tiles_n;
   const int id = xcd_remap(blockIdx.x, nwg);
   const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
-  const int m0 = tm * GEMM4_B, n0 = tn * GEMM4_B;
+  const int m0 = tm * GEMM4_B, n0 = tn * BN4;
 
-  uint32_t a_off[4], w_off[4];
+  uint32_t a_off[4], w_off[WI];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = i * 512 + tid;
     const int row = c >> 3;
     const int ch = (c & 7) ^ (row & 7);
     a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
-    w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+    if (i < WI) w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
   }
   // split-K (p.part != null): grid.y slices of the K range, f32 partial tiles to part[slice][M][N]
   const int nk_all = p.K / GEMM_BK;
@@ -405,36 +420,36 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_k + a_off[i]),
                                        (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WI; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_k + w_off[i]),
                                        (__attribute__((address_space(3))) void*)(base + A_BYTES + i * 8192), 16, 0,
                                        0);
   };
 
-  f32x4 acc[8][4];
+  f32x4 acc[8][NT];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int sw = lane & 7;
   const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
   const int a_rd = wm * 128 * 128;            // + i * 2048
-  const int w_rd = A_BYTES + wn * 64 * 128;   // + j * 2048
+  const int w_rd = A_BYTES + wn * (16 * NT) * 128;   // + j * 2048
 
-  bf16x8 af0[8], wf0[4], af1[8], wf1[4];
-  auto read_frags = [&](bf16x8 (&af)[8], bf16x8 (&wf)[4], const char* base, int rd) {
+  bf16x8 af0[8], wf0[NT], af1[8], wf1[NT];
+  auto read_frags = [&](bf16x8 (&af)[8], bf16x8 (&wf)[NT], const char* base, int rd) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
+    for (int j = 0; j < NT; ++j) wf[j] = *(const bf16x8*)(base + w_rd + j * 2048 + rd);
 #pragma unroll
     for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(base + a_rd + i * 2048 + rd);
   };
-  auto mfma32 = [&](bf16x8 (&wf)[4], bf16x8 (&af)[8], int skip_first) {
+  auto mfma32 = [&](bf16x8 (&wf)[NT], bf16x8 (&af)[8], int skip_first) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NT; ++j)
         if ((i | j) >= skip_first)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
   };
@@ -442,7 +457,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
   const int nk = kt1 - kt0;
   stage(0, 0);
   stage(1, min(1, nk - 1));
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (NT == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if (NT == 3) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(af0, wf0, lds4, rd0);
   int buf = 0;
@@ -456,11 +473,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
     read_frags(af1, wf1, base, rd1);
     mfma32(wf0, af0, 1);
 #pragma unroll
-    for (int g = 0; g < 12; ++g) {
+    for (int g = 0; g < NF; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 19, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - 1 - NF, 0);
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     // mid
@@ -473,16 +490,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
     // phase B: MFMAs on F1 start at once; the stage issue and the F0 reads ride between them
     mfma32(wf1, af1, 0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < 4 + WI; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);  // one VMEM (LDS-DMA)
     }
 #pragma unroll
-    for (int g = 0; g < 12; ++g) {
+    for (int g = 0; g < NF; ++g) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 8 * NT - (4 + WI) - NF, 0);
     __builtin_amdgcn_sched_barrier(0);
     buf ^= 1;
   }
@@ -501,8 +518,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
       const int m = m0 + wm * 128 + i * 16 + l15;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + 4 * h;
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * (16 * NT) + j * 16 + 4 * h;
         if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
       }
     }
@@ -515,8 +532,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sub[i][j] = acc[hm * 4 + i][j];
-    gemm_epilogue(p, sub, m0 + wm * 128 + hm * 64, n0 + wn * 64, l15, h);
+      for (int j = 0; j < 4; ++j) sub[i][j] = (j < NT) ? acc[hm * 4 + i][j < NT ? j : 0] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_epilogue_n(p, sub, m0 + wm * 128 + hm * 64, n0 + wn * (16 * NT), l15, h, NT);
   }
 }
 
@@ -874,7 +891,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_finalize_kernel(GemmArgs p) {
 //  * 256x256 (1 WG/CU): best per-tile rate; used when its last round of 256 CUs is at least half full, and for
 //    wide problems (>= 3 rounds) with the ragged remainder columns handed to a second launch (LLM gate/up:
 //    9 x 148 tiles = 5.2 rounds -> 142 columns here + 6 columns below, instead of 6 rounds);
-//  * 256x128 3-stage (1 WG/CU): long-K problems whose grid is one full round (LLM o/down: 9 x 28 = 252 tiles);
+//  * 256x192 / 256x128 forms of the same pipelined kernel (NT = 3 / 2): problems whose grid is then one (nearly) full
+//    round - LLM qkv 9 x 24 = 216 tiles (0.095 -> 0.071 ms against 1.27 rounds of 128x128 tiles), LLM o 9 x 28 = 252,
+//    ViT fc2 20 x 10 = 200; the older 3-stage 256x128 kernel (VIS_GEMM_TILE=2) is 3-5 % slower and kept for A/B;
 //  * 128x128 (2 WG/CU): everything else.
 static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
   static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
@@ -890,9 +909,32 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
     cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only
     huge = cols4 > 0;
   }
+  // 256 x 192 / 256 x 128 forms of the pipelined kernel: one (nearly) full round of 256 workgroups
+  const int t3 = tm4 * ((N + 191) / 192), t2n = tm4 * tn1;
+  const bool nt3 = forced ? (forced == 6) : (!huge && p.act != ACT_SWIGLU && K >= 1024 && M >= 1024 && t3 >= 200 && t3 <= 256 &&
+                                             !(t2n >= 200 && t2n <= 256));
+  const bool nt2 = forced ? (forced == 5) : big;   // the pipelined 256x128 form beat the 3-stage kernel by 3-5 %
+  if (nt3 || nt2) {
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute((const void*)gemm_bf16_256xN_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM4_LDS_BYTES) == hipSuccess &&
+             hipFuncSetAttribute((const void*)gemm_bf16_256xN_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM4_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr_ok) return VIS_ERR_LAUNCH;
+    p.tiles_m = tm4;
+    if (nt3) {
+      p.tiles_n = (N + 191) / 192;
+      hipLaunchKernelGGL(gemm_bf16_256xN_kernel<3>, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, p);
+    } else {
+      p.tiles_n = tn1;
+      hipLaunchKernelGGL(gemm_bf16_256xN_kernel<2>, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, p);
+    }
+    return VIS_OK;
+  }
   if (huge) {
     static const bool attr4_ok = [] {
-      return hipFuncSetAttribute((const void*)gemm_bf16_256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      return hipFuncSetAttribute((const void*)gemm_bf16_256xN_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  GEMM4_LDS_BYTES) == hipSuccess;
     }();
     if (!attr4_ok) return VIS_ERR_LAUNCH;
@@ -900,7 +942,7 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
     if (cols4 < tn4) q.N = cols4 * GEMM4_B;
     q.tiles_m = tm4;
     q.tiles_n = cols4;
-    hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, q);
+    hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(q.tiles_m * q.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, q);
     if (cols4 == tn4) return VIS_OK;
     // remainder columns [n_off, N): same problem, shifted operands
     const int n_off = cols4 * GEMM4_B;
@@ -968,7 +1010,7 @@ extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bi
   if (ksplit < 2 || ksplit > 8 || K / GEMM_BK < 2 * ksplit) return VIS_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)R | (uintptr_t)work) & 15) return VIS_ERR_ARG;
   static const bool attr4_ok = [] {
-    return hipFuncSetAttribute((const void*)gemm_bf16_256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)gemm_bf16_256xN_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                GEMM4_LDS_BYTES) == hipSuccess;
   }();
   if (!attr4_ok) return VIS_ERR_LAUNCH;
@@ -979,7 +1021,7 @@ extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bi
   p.tiles_m = (M + GEMM4_B - 1) / GEMM4_B;
   p.tiles_n = (N + GEMM4_B - 1) / GEMM4_B;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_bf16_256x256_kernel, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM4_LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM4_LDS_BYTES, stream, p);
   const long long total = (long long)M * (N / 8);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(gemm_splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, p);
