@@ -52,6 +52,41 @@ def test_gemm_plain(hip, device, M, N, K):
     _assert_close(out, ref, atol=2e-2, rtol=1e-2, what=f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,K,kind", [
+    (2249, 4608, 3584, "bias"),        # LLM qkv       -> 256x192 tiles (one round)
+    (2249, 3584, 3584, "residual"),    # LLM o         -> 256x128 pipelined tiles
+    (2249, 37888, 3584, "swiglu"),     # LLM gate/up   -> 256x256 whole rounds + 128x128 remainder columns
+    (4900, 5120, 1280, "quickgelu"),   # ViT fc1       -> 256x256
+    (4900, 1280, 5120, "residual"),    # ViT fc2       -> 256x128
+    (4900, 3840, 1280, "bias"),        # ViT qkv       -> 128x128
+    (2300, 768, 1024, "bias"),         # ragged M and N tails on the 256-row kernels
+])
+def test_gemm_production_shapes(hip, device, M, N, K, kind):
+    """The shapes the 7B prefill actually runs, so that every tile kernel and dispatch branch is parity-checked."""
+    from vision_inspection_system_amd.weights import interleave_gate_up
+    a = _randn((M, K), device, 11)
+    w = _randn((N, K), device, 12, 1.0 / math.sqrt(K))
+    af, wf = a.float(), w.float()
+    if kind == "swiglu":
+        I = N // 2
+        out = hip.gemm(a, interleave_gate_up(w[:I].contiguous(), w[I:].contiguous()), act=hip.ACT_SWIGLU)
+        ref = torch.nn.functional.silu(af @ wf[:I].t()) * (af @ wf[I:].t())
+    elif kind == "residual":
+        r = _randn((M, N), device, 13)
+        out = hip.gemm(a, w, residual=r)
+        ref = af @ wf.t() + r.float()
+    elif kind == "quickgelu":
+        b = _randn((N,), device, 14)
+        out = hip.gemm(a, w, bias=b, act=hip.ACT_QUICKGELU)
+        y = af @ wf.t() + b.float()
+        ref = y * torch.sigmoid(1.702 * y)
+    else:
+        b = _randn((N,), device, 14)
+        out = hip.gemm(a, w, bias=b)
+        ref = af @ wf.t() + b.float()
+    _assert_close(out, ref, atol=3e-2, rtol=1e-2, what=f"gemm {M}x{N}x{K} {kind}")
+
+
 def test_gemm_asymmetric_layout(hip, device):
     # A = I, asymmetric W: catches a transposed accumulator map
     K = 128
