@@ -315,7 +315,8 @@ def test_quant_rows_fp8_fused_layernorm(hip, device):
     assert (q != ref_q).float().mean().item() < 1e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 1024), (2249, 4608, 3584), (2249, 3584, 18944), (77, 100, 256)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 520, 1024), (2249, 4608, 3584), (2249, 3584, 18944), (77, 100, 256),
+                                   (2249, 37888, 3584), (4900, 1280, 5120), (4900, 3840, 1280)])
 def test_gemm_fp8(hip, device, M, N, K):
     """Against the SAME quantised operands in fp32: the kernel adds only f32 accumulation-order effects."""
     a = _randn((M, K), device, 172)
