@@ -121,3 +121,20 @@ def test_mllama_backend_through_the_client_and_auditor(local_cfg, images):
     insp = VLMInspectorAgent().analyze(images[0], ctx)
     aud = VLMAuditorAgent().verify(images[0], ctx, insp)
     assert isinstance(aud, VLMAnalysisResult)
+
+
+def test_batch_inspection_with_mllama_auditor(local_cfg, images):
+    """BASELINE configs[2] plumbing: Inspector on the Qwen2-VL engine (batched decode), Auditor on the mllama engine,
+    consensus + gates + aggregation, through run_batch_inspection."""
+    from vision_inspection_system_amd import config as C
+    from vision_inspection_system_amd.batch import run_batch_inspection
+    from vision_inspection_system_amd import nodes
+    nodes._sleep = lambda s: None                      # no back-off sleeps in tests
+    cfg = C.get_config()
+    cfg.vlm_auditor_model = "synthetic:mllama-tiny"
+    out = run_batch_inspection(images, "high", "aerospace")
+    assert list(v["image_path"] for v in out["image_results"].values()) == images
+    assert out["session_results"]["total_images"] == 3
+    for v in out["image_results"].values():
+        assert v["completed"] is True and v["auditor_result"] is not None and v["consensus"] is not None
+        assert v["safety_verdict"]["verdict"] in ("SAFE", "UNSAFE", "REQUIRES_HUMAN_REVIEW")
