@@ -113,6 +113,60 @@ __device__ __forceinline__ void gv_finish(const GemvArgs& p, bool swiglu, int pa
   }
 }
 
+// x -> rmsnorm(x) * w -> LDS (bf16, HF rounding order).  x and w are loaded ONCE (both loads issued before the
+// reduction) and normalised from registers: hidden sizes <= 4096 give at most two 16-byte chunks per thread; the
+// re-reading loop of the first version put a second L2 round trip into every norm-fused GEMV's prologue.
+__device__ __forceinline__ void gv_stage_x_rmsnorm(const bf16_t* __restrict__ x, const bf16_t* __restrict__ nw, bf16_t* xs,
+                                                   int nch, int K, float eps, int tid, int lane, int wave) {
+  __shared__ float red[4];
+  if (nch <= 512) {
+    const int c0 = tid, c1 = tid + 256;
+    const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+    const u32x4 r0 = (c0 < nch) ? *(const u32x4*)(x + c0 * 8) : z, r1 = (c1 < nch) ? *(const u32x4*)(x + c1 * 8) : z;
+    const u32x4 g0 = (c0 < nch) ? *(const u32x4*)(nw + c0 * 8) : z, g1 = (c1 < nch) ? *(const u32x4*)(nw + c1 * 8) : z;
+    float f0[8], f1[8], w0[8], w1[8], o[8];
+    unpack8(r0, f0); unpack8(r1, f1);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += f0[e] * f0[e] + f1[e] * f1[e];
+    ss = wave_sum(ss);
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+    unpack8(g0, w0); unpack8(g1, w1);
+    if (c0 < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f0[e] * rstd)) * w0[e];
+      *(u32x4*)(xs + c0 * 8) = pack8(o);
+    }
+    if (c1 < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f1[e] * rstd)) * w1[e];
+      *(u32x4*)(xs + c1 * 8) = pack8(o);
+    }
+    return;
+  }
+  float ss = 0.f;
+  for (int c = tid; c < nch; c += 256) {
+    float f[8];
+    unpack8(*(const u32x4*)(x + c * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) red[wave] = ss;
+  __syncthreads();
+  const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)K + eps);
+  for (int c = tid; c < nch; c += 256) {
+    float f[8], w[8], o[8];
+    unpack8(*(const u32x4*)(x + c * 8), f);
+    unpack8(*(const u32x4*)(nw + c * 8), w);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f[e] * rstd)) * w[e];
+    *(u32x4*)(xs + c * 8) = pack8(o);
+  }
+}
+
 // x -> LDS for long inputs (K > 8192), all global loads of a thread issued before the first LDS store (K = 18944:
 // 10 chunks per thread; a plain load/store loop serialises ~10 L2 round trips in front of the weight stream).  Unconditional clamped
 // loads (a predicated load makes hipcc drain vmcnt per branch); chunks past the end are simply not stored.
@@ -148,28 +202,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
 
   // ---- stage x (optionally RMS-normalised) into LDS
   if (p.norm_w) {
-    float ss = 0.f;
-    for (int c = tid; c < nch; c += 256) {
-      float f[8];
-      unpack8(*(const u32x4*)(p.x + c * 8), f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-    }
-    ss = wave_sum(ss);
-    __shared__ float red[4];
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
-    for (int c = tid; c < nch; c += 256) {
-      float f[8], w[8], o[8];
-      unpack8(*(const u32x4*)(p.x + c * 8), f);
-      unpack8(*(const u32x4*)(p.norm_w + c * 8), w);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f[e] * rstd)) * w[e];
-      *(u32x4*)(xs + c * 8) = pack8(o);
-    }
+    gv_stage_x_rmsnorm(p.x, p.norm_w, xs, nch, p.K, p.eps, tid, lane, wave);
   } else if (nch > 1024) {
     gv_stage_x(p.x, xs, nch, tid);
+  } else if (nch <= 512) {   // both loads in flight before the first store (one L2 round trip, not two)
+    const u32x4 r0 = *(const u32x4*)(p.x + min(tid, nch - 1) * 8), r1 = *(const u32x4*)(p.x + min(tid + 256, nch - 1) * 8);
+    if (tid < nch) *(u32x4*)(xs + tid * 8) = r0;
+    if (tid + 256 < nch) *(u32x4*)(xs + (tid + 256) * 8) = r1;
   } else {
     for (int c = tid; c < nch; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(p.x + c * 8);
   }
@@ -356,28 +395,13 @@ __global__ __launch_bounds__(256) void gemv_fp8w_kernel(GemvF8Args p) {
   if (n_tasks > 0) gf_load(A, p, swiglu, q_begin, 0, lane, nch);  // in flight while x is staged
 
   if (p.norm_w) {
-    float ss = 0.f;
-    for (int c = tid; c < nch8; c += 256) {
-      float f[8];
-      unpack8(*(const u32x4*)(p.x + c * 8), f);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ss += f[e] * f[e];
-    }
-    ss = wave_sum(ss);
-    __shared__ float red[4];
-    if (lane == 0) red[wave] = ss;
-    __syncthreads();
-    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)p.K + p.eps);
-    for (int c = tid; c < nch8; c += 256) {
-      float f[8], w[8], o[8];
-      unpack8(*(const u32x4*)(p.x + c * 8), f);
-      unpack8(*(const u32x4*)(p.norm_w + c * 8), w);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(f[e] * rstd)) * w[e];
-      *(u32x4*)(xs + c * 8) = pack8(o);
-    }
+    gv_stage_x_rmsnorm(p.x, p.norm_w, xs, nch8, p.K, p.eps, tid, lane, wave);
   } else if (nch8 > 1024) {
     gv_stage_x(p.x, xs, nch8, tid);
+  } else if (nch8 <= 512) {   // both loads in flight before the first store (one L2 round trip, not two)
+    const u32x4 r0 = *(const u32x4*)(p.x + min(tid, nch8 - 1) * 8), r1 = *(const u32x4*)(p.x + min(tid + 256, nch8 - 1) * 8);
+    if (tid < nch8) *(u32x4*)(xs + tid * 8) = r0;
+    if (tid + 256 < nch8) *(u32x4*)(xs + (tid + 256) * 8) = r1;
   } else {
     for (int c = tid; c < nch8; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(p.x + c * 8);
   }
