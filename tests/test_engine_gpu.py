@@ -206,6 +206,25 @@ def test_vit_two_stream_split_equals_single_stream(setup, device):
     assert (a - b).abs().max() < 1e-6 * max(1.0, float(a.abs().max())) or torch.equal(a, b)
 
 
+def test_vit_features_do_not_depend_on_batch_position(setup, device):
+    """An image's features are bit-identical alone, second in a request, or batched behind other images: every image
+    starts on a 64-row boundary, so the attention kernel's absolute 64-key tiles group its keys the same way."""
+    cfg, sd, eng = setup
+    rng = np.random.default_rng(5)
+    fa = torch.from_numpy(rng.integers(0, 256, (28 * 5, 28 * 7, 3), dtype=np.uint8)).to(device)    # 140 patches
+    fb = torch.from_numpy(rng.integers(0, 256, (28 * 3, 28 * 3, 3), dtype=np.uint8)).to(device)    # 36 patches
+    na, nb = (10 * 14) // 4, (6 * 6) // 4
+    a = eng.vision_forward([fa])
+    b = eng.vision_forward([fb])
+    assert a.shape[0] == na and b.shape[0] == nb
+    mixed = eng.vision_forward([fb, fa, fb, fa])
+    assert mixed.shape[0] == 2 * (na + nb)
+    o = 0
+    for ref in (b, a, b, a):
+        assert torch.equal(mixed[o:o + ref.shape[0]], ref)
+        o += ref.shape[0]
+
+
 def test_fp8_prefill_matches_oracle_with_fake_quant(setup, device, monkeypatch):
     """configs[4]: LLM projections of the prompt pass on the fp8 MFMA (e4m3 weights, per-token e4m3 activations).
     The oracle fake-quantises the same tensors (de-quantised weights, per-row activation quantise/de-quantise).

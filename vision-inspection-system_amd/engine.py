@@ -277,26 +277,38 @@ class Qwen2VLEngine:
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
         grids = [(1, f.shape[0] // cfg.patch, f.shape[1] // cfg.patch) for f in frames]
         counts = [g[1] * g[2] for g in grids]
-        N = sum(counts)
+        # Every image starts on a 64-row boundary: the attention kernel walks keys in absolute 64-row tiles, so an
+        # image's online-softmax grouping (and with it the bf16 rounding of its features) would otherwise depend on
+        # what precedes it in the batch.  With aligned starts an image's features are bit-identical whether it runs
+        # alone, second in a request, or batched with other requests' images (tests/test_engine_gpu.py).  The pad
+        # rows (<= 60 per image) are zero patches that nothing attends to; they are dropped from the result.
+        starts, s0 = [], 0
+        for c in counts:
+            starts.append(s0)
+            s0 += _round_up(c, 64)
+        N = starts[-1] + counts[-1]
+        padded = N != sum(counts)
         E, Hh, D = cfg.v_embed, cfg.v_heads, cfg.v_head_dim
         kp = w.patch_w.shape[1]
-        patches = torch.empty((N, kp), dtype=bf, device=dev)
-        row0 = 0
-        for f, c in zip(frames, counts):
-            hip.patchify(f, patches, row0, CLIP_MEAN, CLIP_STD)
-            row0 += c
+        patches = (torch.zeros if padded else torch.empty)((N, kp), dtype=bf, device=dev)
+        for f, r0 in zip(frames, starts):
+            hip.patchify(f, patches, r0, CLIP_MEAN, CLIP_STD)
         x = hip.gemm(patches, w.patch_w)
         key = tuple(grids)
         if key not in self._vis_rope_cache:
             c, s = vision_cos_sin(cfg, grids)
+            if padded:
+                cp, sp = np.zeros((N, c.shape[1]), c.dtype), np.zeros((N, s.shape[1]), s.dtype)
+                o = 0
+                for r0, n in zip(starts, counts):
+                    cp[r0:r0 + n], sp[r0:r0 + n] = c[o:o + n], s[o:o + n]
+                    o += n
+                c, s = cp, sp
             self._vis_rope_cache[key] = (torch.from_numpy(c).to(dev), torch.from_numpy(s).to(dev))
             if len(self._vis_rope_cache) > 16:
                 self._vis_rope_cache.pop(next(iter(self._vis_rope_cache)))
         cos, sin = self._vis_rope_cache[key]
-        segs, s0 = [], 0
-        for c in counts:
-            segs.append((s0, s0 + c))
-            s0 += c
+        segs = [(r0, r0 + c) for r0, c in zip(starts, counts)]
         work = hip.make_attn_work(segs, False, dev, heads=Hh)
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
@@ -304,7 +316,7 @@ class Qwen2VLEngine:
         q = torch.empty((Hh, N, D), dtype=bf, device=dev)
         k = torch.empty((Hh, N, D), dtype=bf, device=dev)
         vt = torch.empty((Hh, D, ld), dtype=bf, device=dev)
-        att = torch.empty((N, E), dtype=bf, device=dev)
+        att = (torch.zeros if padded else torch.empty)((N, E), dtype=bf, device=dev)     # pad rows are never written
         hmid = torch.empty((N, cfg.v_mlp), dtype=bf, device=dev)
         scale = D ** -0.5
         if self.vq8:
@@ -338,7 +350,10 @@ class Qwen2VLEngine:
         hip.layernorm(x, w.merger_ln_w, w.merger_ln_b, 1e-6, out=y)
         m = cfg.merge ** 2
         z = hip.gemm(y.view(N // m, E * m), w.merger_fc0_w, bias=w.merger_fc0_b, act=hip.ACT_GELU_ERF)
-        return hip.gemm(z, w.merger_fc2_w, bias=w.merger_fc2_b)
+        out = hip.gemm(z, w.merger_fc2_w, bias=w.merger_fc2_b)
+        if padded:
+            out = torch.cat([out[r0 // m:(r0 + c) // m] for r0, c in zip(starts, counts)])
+        return out
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (),
