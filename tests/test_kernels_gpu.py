@@ -60,6 +60,8 @@ def test_gemm_plain(hip, device, M, N, K):
     (4900, 1280, 5120, "residual"),    # ViT fc2       -> 256x128
     (4900, 3840, 1280, "bias"),        # ViT qkv       -> 128x128
     (2300, 768, 1024, "bias"),         # ragged M and N tails on the 256-row kernels
+    (2049, 12296, 1088, "bias"),       # ping-pong 256x256: odd K-tile count (17), ragged M and N edges
+    (4096, 6144, 1024, "residual"),    # ping-pong 256x256: exactly full tiles, even K-tile count
 ])
 def test_gemm_production_shapes(hip, device, M, N, K, kind):
     """The shapes the 7B prefill actually runs, so that every tile kernel and dispatch branch is parity-checked."""
@@ -85,6 +87,26 @@ def test_gemm_production_shapes(hip, device, M, N, K, kind):
         out = hip.gemm(a, w, bias=b)
         ref = af @ wf.t() + b.float()
     _assert_close(out, ref, atol=3e-2, rtol=1e-2, what=f"gemm {M}x{N}x{K} {kind}")
+
+
+@pytest.mark.parametrize("K", [1024, 1088, 1152, 2048 + 64])
+def test_gemm_pingpong_exact_integers(hip, device, K):
+    """Small-integer operands: every product and partial sum is exact in f32 and the result is exact in bf16, so a
+    single stale or early LDS half-tile (a staging race in the ping-pong schedule) shows as a wrong integer.  Run
+    several times: a race would come and go."""
+    M, N = 2048 + 40, 12288 + 24          # 9 x 49 tiles of 256 x 256 -> the ping-pong kernel, ragged edges
+    g = torch.Generator(device="cpu").manual_seed(K)
+    a = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16).to(device)
+    w = torch.randint(-1, 2, (N, K), generator=g).to(torch.bfloat16).to(device)
+    # keep |sum| < 256 so that the bf16 output is exact: zero out all but 120 columns of k per row of w
+    keep = torch.zeros(K, dtype=torch.bool)
+    keep[torch.randperm(K, generator=g)[:120]] = True
+    w = w * keep.to(device).to(torch.bfloat16)
+    ref = (a.float() @ w.float().t())
+    assert float(ref.abs().max()) <= 256
+    for _ in range(5):
+        out = hip.gemm(a, w)
+        assert torch.equal(out.float(), ref)
 
 
 def test_gemm_asymmetric_layout(hip, device):

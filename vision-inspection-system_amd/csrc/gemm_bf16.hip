@@ -538,6 +538,208 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256xN_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------
+// 256 x 256 x 64 "ping-pong" tile: the two waves that share a SIMD (wave w and w + 4: row groups wr = 0 / 1) run
+// half a phase apart, so one of them is always inside an MFMA cluster while the other issues its LDS reads and
+// LDS-DMA stages.  A K-tile is four phases; a phase = {fragment reads + one half-tile stage | s_barrier |
+// 16 MFMAs (one 64 x 32 quadrant of the wave's 128 x 64 output over the whole K-tile) | s_barrier}, and group
+// wr = 1 enters the loop through one extra s_barrier (group 0 pays it back after the loop), which is what puts
+// its read section beside group 0's MFMA section and vice versa.
+//
+// LDS: two K-tile buffers (E: even tiles, O: odd) of four 16 KiB half-tiles.  A half-tile is not a contiguous
+// half of the tile but the rows every wave reads in the SAME phase: A-h(qa) = rows {wr*128 + qa*64 + r},
+// B-h(qb) = columns {wc*64 + qb*32 + c}.  Reads per K-tile: phase 1 B-h0 (4 x ds_read_b128) + A-h0 (8),
+// phase 2 B-h1 (4), phase 3 A-h1 (8), phase 4 none (quadrants (0,0) (0,1) (1,1) (1,0); B-h0 stays in registers).
+// So a half-tile is dead early and is refilled for the tile two ahead while its buffer is still being read:
+//   phase:   1        2        3        4        5        6        7        8
+//   reads:   E.B0,A0  E.B1     E.A1     -        O.B0,A0  O.B1     O.A1     -
+//   stage:   O.A1     E.B0     E.A0     E.B1     E.A1     O.B0     O.A0     O.B1      (E: tile t+2, O: t+1 / t+3)
+//   wait:                               vmcnt(6)                            vmcnt(6)
+// vmcnt(6) = the three youngest half-tiles stay in flight across every barrier; the wait in phase 4 (8) retires
+// the odd (even) buffer, which is read from the NEXT phase on (both groups have then passed a barrier after
+// their wait).  WAR: a half-tile is restaged >= 2 phases after the phase that read it, except B-h0, restaged one
+// phase after - its 4 reads are issued first and retired by lgkmcnt(8) BEFORE the reading phase's first barrier.
+// sched_barrier(0) at every s_barrier keeps hipcc from moving reads / MFMAs across them (the placement above IS
+// the synchronisation).  Same accumulator layout and epilogue as gemm_bf16_256xN_kernel<4>.
+#define GEMM5_HALF_BYTES 16384
+#define GEMM5_BUF_BYTES 65536
+#define GEMM5_LDS_BYTES 131072
+// half-tile slots inside a buffer
+#define G5_B0 0
+#define G5_A0 1
+#define G5_B1 2
+#define G5_A1 3
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds5[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * 256, n0 = tn * 256;
+
+  // staging: half-tile row hr = c >> 3 (c = i*512 + tid), 16-byte chunk (c & 7) ^ (hr & 7)
+  uint32_t a_off[2][2], w_off[2][2];   // [half][instruction]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid;
+    const int hr = c >> 3;
+    const int ch = (c & 7) ^ (hr & 7);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int arow = (hr >> 6) * 128 + q * 64 + (hr & 63);
+      const int wrow = (hr >> 5) * 64 + q * 32 + (hr & 31);
+      a_off[q][i] = (uint32_t)(min(m0 + arow, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
+      w_off[q][i] = (uint32_t)(min(n0 + wrow, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+    }
+  }
+  const int nk_all = p.K / GEMM_BK;
+  const int kt0 = p.part ? (int)((long long)nk_all * blockIdx.y / p.ksplit) : 0;
+  const int kt1 = p.part ? (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit) : nk_all;
+  const int nk = kt1 - kt0;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda) + (size_t)kt0 * GEMM_BK * 2;
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt0 * GEMM_BK * 2;
+  char* const wave_lds = lds5 + wave * 1024;
+
+  // one half-tile (slot of buffer buf) of K-tile kt; kt is clamped, a redundant stage refills a dead half-tile
+  auto stage = [&](int buf, int slot, int kt) {
+    kt = min(kt, nk - 1);
+    const bool is_a = slot & 1;
+    const int q = slot >> 1;
+    const char* src = (is_a ? a_base : w_base) + kt * (GEMM_BK * 2);
+    char* dst = wave_lds + buf * GEMM5_BUF_BYTES + slot * GEMM5_HALF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const __attribute__((address_space(1))) void* g =
+          (const __attribute__((address_space(1))) void*)(src + (is_a ? a_off[q][i] : w_off[q][i]));
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + i * 8192);
+      __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads: half-tile row l15 (+ 16 per fragment), k-half kh -> chunk (4 kh + h) ^ (row & 7)
+  const int sw = l15 & 7;
+  const int rd_k0 = l15 * 128 + (((0 + h) ^ sw) << 4);
+  const int rd_k1 = l15 * 128 + (((4 + h) ^ sw) << 4);
+  const int a_rd = wr * (64 * 128);   // + ii * 2048
+  const int b_rd = wc * (32 * 128);   // + jj * 2048
+  bf16x8 af[4][2], bq0[2][2], bq1[2][2];
+  auto read_a = [&](int buf, int qa) {
+    const char* base = lds5 + buf * GEMM5_BUF_BYTES + (qa ? G5_A1 : G5_A0) * GEMM5_HALF_BYTES + a_rd;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      af[ii][0] = *(const bf16x8*)(base + ii * 2048 + rd_k0);
+      af[ii][1] = *(const bf16x8*)(base + ii * 2048 + rd_k1);
+    }
+  };
+  auto read_b = [&](bf16x8 (&bq)[2][2], int buf, int qb) {
+    const char* base = lds5 + buf * GEMM5_BUF_BYTES + (qb ? G5_B1 : G5_B0) * GEMM5_HALF_BYTES + b_rd;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      bq[jj][0] = *(const bf16x8*)(base + jj * 2048 + rd_k0);
+      bq[jj][1] = *(const bf16x8*)(base + jj * 2048 + rd_k1);
+    }
+  };
+#define G5_BAR()                                  \
+  do {                                            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    asm volatile("s_barrier" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+#define G5_MFMA(QA, QB, BQ)                                                                                   \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                          \
+      acc[(QA) * 4 + ii][(QB) * 2 + jj] =                                                                     \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[jj][kh], af[ii][kh], acc[(QA) * 4 + ii][(QB) * 2 + jj], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
+  } while (0)
+  // four phases of K-tile kt in buffer B (0 = E, 1 = O); S1..S4 = (buffer, slot, tile) staged in each phase
+#define G5_TILE(B, KT, S1B, S1S, S1T, S2B, S2S, S2T, S3B, S3S, S3T, S4B, S4S, S4T)  \
+  do {                                                                              \
+    read_b(bq0, B, 0);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    read_a(B, 0);                                                                   \
+    stage(S1B, S1S, S1T);                                                           \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                              \
+    G5_BAR();                                                                       \
+    G5_MFMA(0, 0, bq0);                                                             \
+    G5_BAR();                                                                       \
+    read_b(bq1, B, 1);                                                              \
+    stage(S2B, S2S, S2T);                                                           \
+    G5_BAR();                                                                       \
+    G5_MFMA(0, 1, bq1);                                                             \
+    G5_BAR();                                                                       \
+    read_a(B, 1);                                                                   \
+    stage(S3B, S3S, S3T);                                                           \
+    G5_BAR();                                                                       \
+    G5_MFMA(1, 1, bq1);                                                             \
+    G5_BAR();                                                                       \
+    stage(S4B, S4S, S4T);                                                           \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                \
+    G5_BAR();                                                                       \
+    G5_MFMA(1, 0, bq0);                                                             \
+    G5_BAR();                                                                       \
+  } while (0)
+
+  // prologue: tile 0 complete (E), tile 1 less its A-h1 (O): 7 half-tiles; vmcnt(6) = E has landed
+  stage(0, G5_B0, 0); stage(0, G5_A0, 0); stage(0, G5_B1, 0); stage(0, G5_A1, 0);
+  stage(1, G5_B0, 1); stage(1, G5_A0, 1); stage(1, G5_B1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  G5_BAR();
+  if (wr == 1) G5_BAR();   // stagger: group 1 runs one barrier behind group 0
+
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    G5_TILE(0, t, 1, G5_A1, t + 1, 0, G5_B0, t + 2, 0, G5_A0, t + 2, 0, G5_B1, t + 2);
+    G5_TILE(1, t + 1, 0, G5_A1, t + 2, 1, G5_B0, t + 3, 1, G5_A0, t + 3, 1, G5_B1, t + 3);
+  }
+  if (t < nk) G5_TILE(0, t, 1, G5_A1, t + 1, 0, G5_B0, t + 2, 0, G5_A0, t + 2, 0, G5_B1, t + 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // redundant trailing stages
+  if (wr == 0) G5_BAR();   // pay the stagger back: every wave has now executed the same number of barriers
+#undef G5_TILE
+#undef G5_MFMA
+#undef G5_BAR
+
+  if (p.part) {  // split-K: raw f32 partial sums
+    float* dst = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + 4 * h;
+        if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+    f32x4 sub[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sub[i][j] = acc[hm * 4 + i][j];
+    gemm_epilogue_n(p, sub, m0 + wr * 128 + hm * 64, n0 + wc * 64, l15, h, 4);
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Batched decode projection (M = in-flight sequences <= 16): a pure weight-streaming problem, so the kernel is
 // built around BYTES IN FLIGHT, not around the MFMA.
 //  * The (128-column tile, 64-wide K-step) pairs of the whole projection form ONE sequence of
@@ -903,7 +1105,9 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
   const int tm4 = (M + GEMM4_B - 1) / GEMM4_B, tn4 = (N + GEMM4_B - 1) / GEMM4_B;
   const int t4 = tm4 * tn4, last = t4 % 256;
   const bool big = forced ? (forced == 2) : (K >= 2048 && t2 >= 200 && t2 <= 256);
-  bool huge = forced ? (forced == 4) : (!big && K >= 1024 && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128));
+  static const int pp_env = [] { const char* e = getenv("VIS_GEMM_PP"); return e ? atoi(e) : 1; }();   // 0: the 2-phase kernel (A/B)
+  const bool use_pp = (pp_env != 0 && forced != 4) || forced == 7;
+  bool huge = forced ? (forced == 4 || forced == 7) : (!big && K >= 1024 && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128));
   int cols4 = tn4;  // 256-wide tile columns given to the 256x256 kernel
   if (!forced && !big && !huge && K >= 1024 && M >= 1024 && t4 >= 768) {
     cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only
@@ -942,7 +1146,16 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
     if (cols4 < tn4) q.N = cols4 * GEMM4_B;
     q.tiles_m = tm4;
     q.tiles_n = cols4;
-    hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(q.tiles_m * q.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, q);
+    if (use_pp) {
+      static const bool attr5_ok = [] {
+        return hipFuncSetAttribute((const void*)gemm_bf16_256x256_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   GEMM5_LDS_BYTES) == hipSuccess;
+      }();
+      if (!attr5_ok) return VIS_ERR_LAUNCH;
+      hipLaunchKernelGGL(gemm_bf16_256x256_pp_kernel, dim3(q.tiles_m * q.tiles_n), dim3(512), GEMM5_LDS_BYTES, stream, q);
+    } else {
+      hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(q.tiles_m * q.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, q);
+    }
     if (cols4 == tn4) return VIS_OK;
     // remainder columns [n_off, N): same problem, shifted operands
     const int n_off = cols4 * GEMM4_B;
@@ -1021,7 +1234,17 @@ extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bi
   p.tiles_m = (M + GEMM4_B - 1) / GEMM4_B;
   p.tiles_n = (N + GEMM4_B - 1) / GEMM4_B;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM4_LDS_BYTES, stream, p);
+  static const int pp_env = [] { const char* e = getenv("VIS_GEMM_PP"); return e ? atoi(e) : 1; }();
+  if (pp_env) {
+    static const bool attr5_ok = [] {
+      return hipFuncSetAttribute((const void*)gemm_bf16_256x256_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM5_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr5_ok) return VIS_ERR_LAUNCH;
+    hipLaunchKernelGGL(gemm_bf16_256x256_pp_kernel, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM5_LDS_BYTES, stream, p);
+  } else {
+    hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM4_LDS_BYTES, stream, p);
+  }
   const long long total = (long long)M * (N / 8);
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
   hipLaunchKernelGGL(gemm_splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, p);
