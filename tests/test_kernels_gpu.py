@@ -360,6 +360,28 @@ def test_gemm_fp8(hip, device, M, N, K):
     assert (out.float() - full).abs().max() < 0.25
 
 
+@pytest.mark.parametrize("K", [1024, 1152, 2176])
+def test_gemm_fp8_pingpong_exact_integers(hip, device, K):
+    """Integer-valued e4m3 operands with unit scales: the fp8 ping-pong tile kernel must reproduce the integer product
+    exactly, run after run (8, 9 and 17 K-tiles: even and odd; ragged M and N edges)."""
+    M, N = 2048 + 40, 12288 + 24
+    g = torch.Generator(device="cpu").manual_seed(K)
+    a = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float()
+    keep = torch.zeros(K)
+    keep[torch.randperm(K, generator=g)[:120]] = 1.0
+    w = w * keep
+    aq = a.to(torch.float8_e4m3fn).view(torch.uint8).to(device)
+    wq = w.to(torch.float8_e4m3fn).view(torch.uint8).to(device)
+    sa = torch.ones(M, dtype=torch.float32, device=device)
+    sw = torch.ones(N, dtype=torch.float32, device=device)
+    ref = (a @ w.t()).to(device)
+    assert float(ref.abs().max()) <= 256
+    for _ in range(5):
+        out = hip.gemm_fp8(aq, sa, wq, sw)
+        assert torch.equal(out.float(), ref)
+
+
 def test_gemm_fp8_swiglu_and_asymmetric_identity(hip, device):
     from vision_inspection_system_amd.weights import interleave_gate_up
     M, K, I = 200, 256, 704

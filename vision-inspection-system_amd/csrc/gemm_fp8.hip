@@ -320,6 +320,183 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
   }
 }
 
+// The ping-pong schedule of gemm_bf16_256x256_pp_kernel (gemm_bf16.hip: half-tile layout, stage / read / wait table and
+// the hazard argument are written out there) on the fp8 MFMA: the tile row is again 128 bytes per K-step (128 e4m3
+// elements), a fragment is two 16-byte chunks (2h, 2h+1) per lane, a phase is 8 MFMAs of K = 128 - the same LDS
+// traffic, the same LDS-DMA count and the same MFMA time per phase as the bf16 kernel.
+#define F8P_HALF_BYTES 16384
+#define F8P_BUF_BYTES 65536
+#define F8P_B0 0
+#define F8P_A0 1
+#define F8P_B1 2
+#define F8P_A1 3
+
+__global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_pp_kernel(GemmF8Args p) {
+  extern __shared__ __attribute__((aligned(16))) char lds9[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * F8_B, n0 = tn * F8_B;
+
+  uint32_t a_off[2][2], w_off[2][2];   // [half][instruction]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid;
+    const int hr = c >> 3;
+    const int ch = (c & 7) ^ (hr & 7);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int arow = (hr >> 6) * 128 + q * 64 + (hr & 63);
+      const int wrow = (hr >> 5) * 64 + q * 32 + (hr & 31);
+      a_off[q][i] = (uint32_t)(min(m0 + arow, p.M - 1) - m0) * (uint32_t)p.lda + ch * 16;
+      w_off[q][i] = (uint32_t)(min(n0 + wrow, p.N - 1) - n0) * (uint32_t)p.ldw + ch * 16;
+    }
+  }
+  const int nk_all = p.K / F8_BK;
+  const int kt0 = p.part ? (int)((long long)nk_all * blockIdx.y / p.ksplit) : 0;
+  const int kt1 = p.part ? (int)((long long)nk_all * (blockIdx.y + 1) / p.ksplit) : nk_all;
+  const int nk = kt1 - kt0;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda) + (size_t)kt0 * F8_BK;
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw) + (size_t)kt0 * F8_BK;
+  char* const wave_lds = lds9 + wave * 1024;
+
+  auto stage = [&](int buf, int slot, int kt) {
+    kt = min(kt, nk - 1);
+    const bool is_a = slot & 1;
+    const int q = slot >> 1;
+    const char* src = (is_a ? a_base : w_base) + kt * F8_BK;
+    char* dst = wave_lds + buf * F8P_BUF_BYTES + slot * F8P_HALF_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + (is_a ? a_off[q][i] : w_off[q][i])),
+          (__attribute__((address_space(3))) void*)(dst + i * 8192), 16, 0, 0);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = l15 & 7;
+  const int rd_lo = l15 * 128 + (((2 * h) ^ sw) << 4);
+  const int rd_hi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
+  const int a_rd = wr * (64 * 128);   // + ii * 2048
+  const int b_rd = wc * (32 * 128);   // + jj * 2048
+  u32x4 af[4][2], bq0[2][2], bq1[2][2];   // [fragment][lo / hi chunk]
+  auto read_a = [&](int buf, int qa) {
+    const char* base = lds9 + buf * F8P_BUF_BYTES + (qa ? F8P_A1 : F8P_A0) * F8P_HALF_BYTES + a_rd;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      af[ii][0] = *(const u32x4*)(base + ii * 2048 + rd_lo);
+      af[ii][1] = *(const u32x4*)(base + ii * 2048 + rd_hi);
+    }
+  };
+  auto read_b = [&](u32x4 (&bq)[2][2], int buf, int qb) {
+    const char* base = lds9 + buf * F8P_BUF_BYTES + (qb ? F8P_B1 : F8P_B0) * F8P_HALF_BYTES + b_rd;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      bq[jj][0] = *(const u32x4*)(base + jj * 2048 + rd_lo);
+      bq[jj][1] = *(const u32x4*)(base + jj * 2048 + rd_hi);
+    }
+  };
+  auto cat = [](const u32x4& lo, const u32x4& hi) -> i32x8 {
+    return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  };
+#define F8P_BAR()                                 \
+  do {                                            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    asm volatile("s_barrier" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+#define F8P_MFMA(QA, QB, BQ)                                                                                  \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                          \
+      acc[(QA) * 4 + ii][(QB) * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(                   \
+          cat(BQ[jj][0], BQ[jj][1]), cat(af[ii][0], af[ii][1]), acc[(QA) * 4 + ii][(QB) * 2 + jj], 0, 0, 0,   \
+          0x7f7f7f7f, 0, 0x7f7f7f7f);                                                                         \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
+  } while (0)
+#define F8P_TILE(B, S1B, S1S, S1T, S2B, S2S, S2T, S3B, S3S, S3T, S4B, S4S, S4T)     \
+  do {                                                                              \
+    read_b(bq0, B, 0);                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                              \
+    read_a(B, 0);                                                                   \
+    stage(S1B, S1S, S1T);                                                           \
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");                              \
+    F8P_BAR();                                                                      \
+    F8P_MFMA(0, 0, bq0);                                                            \
+    F8P_BAR();                                                                      \
+    read_b(bq1, B, 1);                                                              \
+    stage(S2B, S2S, S2T);                                                           \
+    F8P_BAR();                                                                      \
+    F8P_MFMA(0, 1, bq1);                                                            \
+    F8P_BAR();                                                                      \
+    read_a(B, 1);                                                                   \
+    stage(S3B, S3S, S3T);                                                           \
+    F8P_BAR();                                                                      \
+    F8P_MFMA(1, 1, bq1);                                                            \
+    F8P_BAR();                                                                      \
+    stage(S4B, S4S, S4T);                                                           \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                \
+    F8P_BAR();                                                                      \
+    F8P_MFMA(1, 0, bq0);                                                            \
+    F8P_BAR();                                                                      \
+  } while (0)
+
+  stage(0, F8P_B0, 0); stage(0, F8P_A0, 0); stage(0, F8P_B1, 0); stage(0, F8P_A1, 0);
+  stage(1, F8P_B0, 1); stage(1, F8P_A0, 1); stage(1, F8P_B1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  F8P_BAR();
+  if (wr == 1) F8P_BAR();   // stagger: group 1 runs one barrier behind group 0
+
+  int t = 0;
+  for (; t + 1 < nk; t += 2) {
+    F8P_TILE(0, 1, F8P_A1, t + 1, 0, F8P_B0, t + 2, 0, F8P_A0, t + 2, 0, F8P_B1, t + 2);
+    F8P_TILE(1, 0, F8P_A1, t + 2, 1, F8P_B0, t + 3, 1, F8P_A0, t + 3, 1, F8P_B1, t + 3);
+  }
+  if (t < nk) F8P_TILE(0, 1, F8P_A1, t + 1, 0, F8P_B0, t + 2, 0, F8P_A0, t + 2, 0, F8P_B1, t + 2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // redundant trailing stages
+  if (wr == 0) F8P_BAR();   // every wave has now executed the same number of barriers
+#undef F8P_TILE
+#undef F8P_MFMA
+#undef F8P_BAR
+
+  if (p.part) {
+    float* dst = p.part + (size_t)blockIdx.y * p.M * p.N;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + wr * 128 + i * 16 + l15;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wc * 64 + j * 16 + 4 * h;
+        if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int hm = 0; hm < 2; ++hm) {
+    f32x4 sub[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sub[i][j] = acc[hm * 4 + i][j];
+    f8_epilogue(p, sub, m0 + wr * 128 + hm * 64, n0 + wc * 64, l15, h);
+  }
+}
+
 // split-K second half: C = act((sum_slices part) * sa[m] * sw[n] + bias) + R
 __global__ __launch_bounds__(256) void gemm_fp8_splitk_finalize_kernel(GemmF8Args p) {
   const int chunks = p.N >> 3;
@@ -373,8 +550,12 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
   if (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 7 || ((uintptr_t)sa & 3)) return VIS_ERR_ARG;
   static const bool attr_ok = [] {
     return hipFuncSetAttribute((const void*)gemm_fp8_256x256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               F8_LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemm_fp8_256x256_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                F8_LDS_BYTES) == hipSuccess;
   }();
+  static const int pp_env = [] { const char* e = getenv("VIS_GEMM_PP"); return e ? atoi(e) : 1; }();   // 0: 2-phase kernel (A/B)
+  auto* const k256 = pp_env ? gemm_fp8_256x256_pp_kernel : gemm_fp8_256x256_kernel;
   if (!attr_ok) return VIS_ERR_LAUNCH;
   GemmF8Args p;
   p.A = (const uint8_t*)Aq; p.W = (const uint8_t*)Wq; p.sa = (const float*)sa; p.sw = (const float*)sw;
@@ -400,13 +581,13 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
     hipLaunchKernelGGL(gemm_fp8_128x128_kernel, dim3(q.tiles_m * q.tiles_n), dim3(256), 0, stream, q);
   };
   if (work || forced == 4 || (!forced && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128))) {
-    hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(t4, p.ksplit), dim3(512), F8_LDS_BYTES, stream, p);
+    hipLaunchKernelGGL(k256, dim3(t4, p.ksplit), dim3(512), F8_LDS_BYTES, stream, p);
   } else if (!forced && M >= 1024 && t4 >= 768) {
     const int cols4 = (t4 / 256) * 256 / p.tiles_m;  // whole rounds only
     GemmF8Args q = p;
     q.N = cols4 * F8_B;
     q.tiles_n = cols4;
-    hipLaunchKernelGGL(gemm_fp8_256x256_kernel, dim3(q.tiles_m * q.tiles_n, 1), dim3(512), F8_LDS_BYTES, stream, q);
+    hipLaunchKernelGGL(k256, dim3(q.tiles_m * q.tiles_n, 1), dim3(512), F8_LDS_BYTES, stream, q);
     const int n_off = cols4 * F8_B;
     const int c_off = (act == F8_ACT_SWIGLU) ? n_off / 2 : n_off;
     GemmF8Args r = p;
