@@ -357,7 +357,7 @@ def main():
                        "weight_GBps": step_bytes * (new - 1) / t_dec / 1e9,
                        "sequences_per_step": args.batch},
         }
-        if not args.no_cpu_baseline and args.model == "7b":
+        if not args.no_cpu_baseline and args.model == "7b" and world == 1:     # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(cfg, n_patches, S, new)
         print(json.dumps(out), flush=True)
     if world > 1:
