@@ -22,6 +22,17 @@ if os.environ.get("VIS_ATTN_FULLS") is not None and not causal:   # experiment: 
     nf = int(os.environ["VIS_ATTN_FULLS"])
     items = [(q0, 128, 0, S) for q0 in range(0, nf * 128, 128)] + [(q0, min(64, S - q0), 0, S) for q0 in range(nf * 128, S, 64)]
     work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
+if os.environ.get("VIS_ATTN_CAUSAL") is not None and causal:   # experiment: causal item orders / block sizes
+    mode, bq = (int(x) for x in os.environ["VIS_ATTN_CAUSAL"].split(","))
+    items = [(q0, min(bq, S - q0), 0, S) for q0 in range(0, S, bq)]
+    items.sort(key=lambda it: -(it[0] + it[1]))
+    half = (len(items) + 1) // 2
+    if mode == 1:      # heavy half descending, light half ascending (lightest first)
+        items = items[:half] + items[half:][::-1]
+    elif mode == 2:    # alternate heavy / light
+        hv, lt = items[:half], items[half:][::-1]
+        items = [x for pair in zip(hv, lt + [None] * (len(hv) - len(lt))) for x in pair if x is not None]
+    work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
 print('items', work.shape[0], 'half', int((work[:, 1] <= 64).sum()))
 for _ in range(2):
     hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
