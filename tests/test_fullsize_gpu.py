@@ -74,3 +74,27 @@ def test_7b_decode_step_agrees_with_prompt_pass(big):
     top2 = torch.topk(via_prefill, 2).values
     if float(top2[0] - top2[1]) > 2 * diff:       # not a near-tie: the greedy pick must be the same
         assert int(via_decode.argmax()) == int(via_prefill.argmax()) == toks[3]
+
+
+def test_mllama_11b_properties(device):
+    """Row f2 at exact Llama-3.2-11B-Vision shapes (seeded random weights, 1024x1024 image = 2x2 tiles): reproducible,
+    graph == eager, and the decode step (GEMVs, cache self-attention, cached cross-attention keys) agrees with a prompt
+    pass over the extended prompt."""
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    from vision_inspection_system_amd.mllama_weights import MllamaConfig, random_device_weights
+    cfg = MllamaConfig.mllama_11b()
+    eng = MllamaEngine(cfg, random_device_weights(cfg, device, 0), device, max_ctx=1024)
+    rng = np.random.default_rng(3)
+    frame = torch.from_numpy(rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)).to(device)
+    ids = [1] + rng.integers(1000, cfg.vocab - 8, 150).tolist() + [cfg.image_token_id] + rng.integers(1000, cfg.vocab - 8, 20).tolist()
+    a = eng.generate(ids, frame, max_new_tokens=6, stop_on_eos=False, use_graph=True)
+    via_decode = eng.logits.float().clone()
+    b = eng.generate(ids, frame, max_new_tokens=6, stop_on_eos=False, use_graph=False)
+    assert a == b and len(a) == 6 and a == eng.generate(ids, frame, max_new_tokens=6, stop_on_eos=False)
+    eng.prefill(ids + a[:5], frame)
+    via_prefill = eng.logits.float().clone()
+    scale = float(via_prefill.abs().max())
+    diff = float((via_decode - via_prefill).abs().max())
+    assert diff <= 0.03 * scale, f"decode vs prefill logits differ by {diff} (scale {scale})"
+    del eng
+    torch.cuda.empty_cache()
