@@ -675,6 +675,7 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
 
 // merge the per-split partials of one query head (only the splits that ran): 256 threads = 128 dims x 2
 // split-halves; the first partial loads are issued before the position is known
+#define CB_PRE 16   // partial rows preloaded per thread: covers 32 splits = 4096 cached keys
 __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
                                                                   bf16_t* __restrict__ out, int nsplit,
@@ -690,15 +691,20 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
   out += (size_t)seq * gridDim.x * HD;
   step_ptr += seq;
   const float* po = part_o + (size_t)hq * nsplit * HD + d;
-  // partial loads first (independent of the position), then the statistics
-  float v[4];
+  const float* ml = part_ml + (size_t)hq * nsplit * 2;
+  // ONE level of loads: the partials of the first 2 x CB_PRE split slots, the statistics of every slot and the position
+  // are all requested at once; slots that did not run this step hold stale data and are masked (selected away, never
+  // multiplied) once the position has arrived.  Before, position -> statistics -> late partials were three dependent
+  // round trips in a kernel that does nothing else.
+  float v[CB_PRE];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = po[(size_t)min(half + 2 * j, nsplit - 1) * HD];
+  for (int j = 0; j < CB_PRE; ++j) v[j] = po[(size_t)min(half + 2 * j, nsplit - 1) * HD];
+  const int sl = min(tid, nsplit - 1);
+  const float m_raw = ml[sl * 2], l_raw = ml[sl * 2 + 1];
   const int ctx = min(*step_ptr, cache_tokens - 1) + 1;
   const int active = min((ctx + DA_MAXKEYS - 1) / DA_MAXKEYS, nsplit);  // splits that ran
-  const float* ml = part_ml + (size_t)hq * nsplit * 2;
-  float m = -1.0e30f, l = 0.f;
-  if (tid < active) { m = ml[tid * 2]; l = ml[tid * 2 + 1]; }
+  const float m = (tid < active) ? m_raw : -1.0e30f;
+  const float l = (tid < active) ? l_raw : 0.f;
   float M = wave_max(m);
   if ((tid & 63) == 0) wm[tid >> 6] = M;
   __syncthreads();
@@ -710,18 +716,11 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
   if ((tid & 63) == 0) wm[tid >> 6] = lw;
   float o = 0.f;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < CB_PRE; ++j) {
     const int s = half + 2 * j;
     if (s < active) o += wgt[s] * v[j];
   }
-  for (int s = half + 8; s < active; s += 8) {
-    const float a0 = po[(size_t)s * HD];
-    const float a1 = (s + 2 < active) ? po[(size_t)(s + 2) * HD] : 0.f;
-    const float a2 = (s + 4 < active) ? po[(size_t)(s + 4) * HD] : 0.f;
-    const float a3 = (s + 6 < active) ? po[(size_t)(s + 6) * HD] : 0.f;
-    o += wgt[s] * a0 + ((s + 2 < active) ? wgt[s + 2] * a1 : 0.f) + ((s + 4 < active) ? wgt[s + 4] * a2 : 0.f) +
-         ((s + 6 < active) ? wgt[s + 6] * a3 : 0.f);
-  }
+  for (int s = half + 2 * CB_PRE; s < active; s += 2) o += wgt[s] * po[(size_t)s * HD];   // contexts past 32 splits
   osum[half][d] = o;
   __syncthreads();
   if (tid < HD) {
