@@ -128,6 +128,29 @@ def test_batched_generation_matches_single(device):
     assert again[0] == batch[0][:6] and again[1] == batch[1][:6]
 
 
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_batched_generation_more_than_16_sequences(device, weights):
+    """17..32 in-flight sequences use two 16-row MFMA blocks in the batched projection: the tokens of a request are the
+    same as in a batch of <= 16 (rows are independent; the stream-K slot order depends on (N, K) only)."""
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=32, decode_weights=weights)
+    g = load_golden()
+    fa = [torch.from_numpy(g["frame_a"]).to(device)]
+    fb = [torch.from_numpy(g["frame_b1"]).to(device), torch.from_numpy(g["frame_b2"]).to(device)]
+    base = [(g["ids_a"].tolist(), fa), (g["ids_b"].tolist(), fb), ([256, 72, 105, 33], [])]
+    small = eng.generate_batch(base, max_new_tokens=10, ignore_eos=True)
+    for B in (17, 32):
+        reqs = [base[i % 3] for i in range(B)]
+        out = eng.generate_batch(reqs, max_new_tokens=10, ignore_eos=True)
+        assert len(out) == B
+        for i in range(B):
+            assert out[i] == small[i % 3], f"B={B}: sequence {i} differs from the same request in a batch of 3"
+
+
 def _dequantised_sd(cfg, sd):
     """State dict whose LLM projections / lm_head are the engine's e4m3 weights, de-quantised (CPU, same quantiser)."""
     from vision_inspection_system_amd import hip

@@ -405,7 +405,8 @@ def test_gemm_fp8_swiglu_and_asymmetric_identity(hip, device):
     _assert_close(o2, w2.float().t(), atol=1e-2, rtol=1e-2, what="fp8 identity")
 
 
-@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 768), (16, 4608, 3584), (8, 3584, 18944)])
+@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 768), (16, 4608, 3584), (8, 3584, 18944), (19, 1000, 768),
+                                   (32, 4608, 3584)])
 def test_decode_gemm_fp8_and_finalize(hip, device, B, N, K):
     """fp8 batched-decode projection + fp8 finalisation against fp32 arithmetic on the same quantised operands."""
     x = _randn((B, K), device, 180, 2.0)
@@ -415,7 +416,7 @@ def test_decode_gemm_fp8_and_finalize(hip, device, B, N, K):
     nw = _randn((N,), device, 184)
     xq, sx = hip.quant_rows_fp8(x)
     wq, sw = hip.quantize_fp8_rows(w)
-    part = torch.full((16 * 16 * N,), float("nan"), dtype=torch.float32, device=device)
+    part = torch.full((16 * hip.part_rows(B) * N,), float("nan"), dtype=torch.float32, device=device)
     y = torch.empty((B, N), dtype=torch.bfloat16, device=device)
     yn = torch.empty((B, N), dtype=torch.bfloat16, device=device)
     yq = torch.zeros((B, N), dtype=torch.uint8, device=device)
@@ -616,14 +617,15 @@ def test_patchify_matches_reference_layout(hip, device):
 
 
 # ----------------------------------------------------------------------------- K10 batched decode projection
-@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 704), (16, 4608, 3584), (8, 3584, 18944)])
+@pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 704), (16, 4608, 3584), (8, 3584, 18944),
+                                   (17, 1000, 704), (32, 4608, 3584), (24, 3584, 18944)])   # > 16: two 16-row MFMA blocks
 def test_decode_gemm_split_and_finalize(hip, device, B, N, K):
     x = _randn((B, K), device, 100, 2.0)
     w = _randn((N, K), device, 101, 1.0 / math.sqrt(K))
     b = _randn((N,), device, 102)
     r = _randn((B, N), device, 103)
     nw = _randn((N,), device, 104)
-    part = torch.empty(16 * 16 * N, dtype=torch.float32, device=device)
+    part = torch.empty(16 * hip.part_rows(B) * N, dtype=torch.float32, device=device)
     y = torch.empty((B, N), dtype=torch.bfloat16, device=device)
     yn = torch.empty((B, N), dtype=torch.bfloat16, device=device)
     ks = hip.decode_gemm(x, w, part=part)

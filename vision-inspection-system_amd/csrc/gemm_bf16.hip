@@ -791,7 +791,9 @@ __device__ __forceinline__ void gemm3_wait_stages(int younger) {
 }
 static_assert(GEMM3_DEPTH == 7 && GEMM3_PER == 5, "gemm3_wait_stages encodes (DEPTH-2) x PER");
 
-template <bool FP8>
+// MB = 16-row blocks of x: 1 for M <= 16 sequences, 2 for M <= 32 (the x tile always stages 32 rows); the partial slab
+// of a slot has 16 * MB rows.
+template <bool FP8, int MB>
 __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs p) {
   constexpr int EB = FP8 ? 1 : 2;  // bytes per element
   extern __shared__ __attribute__((aligned(16))) char lds3[];
@@ -844,9 +846,12 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
     }
   };
 
-  f32x4 acc[2];
-  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MB][2];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb) {
+    acc[mb][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[mb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const int sw = lane & 7;
   const int rd0 = l15 * 128 + (((0 + h) ^ sw) << 4);
   const int rd1 = l15 * 128 + (((4 + h) ^ sw) << 4);
@@ -872,15 +877,24 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
         const u32x4 lo = *(const u32x4*)(p0 + qlo), hi = *(const u32x4*)(p0 + qhi);
         return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
       };
-      const i32x8 xa = frag8(base);
+      i32x8 xa[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) xa[mb] = frag8(base + mb * 2048);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const i32x8 wa = frag8(base + w_rd + j * 2048);
-        acc[j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa, acc[j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+          acc[mb][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xa[mb], acc[mb][j], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                        0x7f7f7f7f);
       }
     } else {
-      const bf16x8 a0 = *(const bf16x8*)(base + rd0);
-      const bf16x8 a1 = *(const bf16x8*)(base + rd1);
+      bf16x8 a0[MB], a1[MB];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb) {
+        a0[mb] = *(const bf16x8*)(base + mb * 2048 + rd0);
+        a1[mb] = *(const bf16x8*)(base + mb * 2048 + rd1);
+      }
       bf16x8 wf[2][2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -888,54 +902,59 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
         wf[j][1] = *(const bf16x8*)(base + w_rd + j * 2048 + rd1);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], a0, acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], a1, acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][0], a0[mb], acc[mb][j], 0, 0, 0);
+          acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], a1[mb], acc[mb][j], 0, 0, 0);
+        }
     }
     slot = (slot + 1 == GEMM3_DEPTH) ? 0 : slot + 1;
 
     const bool tile_done = (++c_kt == p.nk_all);
     if (tile_done || st + 1 == nsteps) {
-      // flush: lane holds D[n = n0 + 32 wn + 16 j + 4 h + r][m = l15]
-      const int m = l15;
+      // flush: lane holds D[n = n0 + 32 wn + 16 j + 4 h + r][m = 16 mb + l15]
       const int nb = c_tile * GEMM_BN + wn * 32 + 4 * h;
-      if (m < p.M) {
-        if (p.part) {
-          const int seg = blockIdx.x - (c_tile * p.nk_all) / p.spb;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int n = nb + j * 16;
-            if (n >= p.N) continue;
-            *(f32x4*)(p.part + ((size_t)seg * 16 + m) * p.N + n) = acc[j];
-            if (tile_done)
-              for (int z = seg + 1; z < p.nslots; ++z)
-                *(f32x4*)(p.part + ((size_t)z * 16 + m) * p.N + n) = (f32x4){0.f, 0.f, 0.f, 0.f};
-          }
-        } else {
+      for (int mb = 0; mb < MB; ++mb) {
+        const int m = mb * 16 + l15;
+        if (m < p.M) {
+          if (p.part) {
+            const int seg = blockIdx.x - (c_tile * p.nk_all) / p.spb;
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const int n = nb + j * 16;
-            if (n >= p.N) continue;
-            if (FP8) {   // direct output of the fp8 form: apply the row scales here
-              const float sxm = p.sx[m];
-              const f32x4 s4 = *(const f32x4*)(p.sw + n);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[j][r] *= sxm * s4[r];
+            for (int j = 0; j < 2; ++j) {
+              const int n = nb + j * 16;
+              if (n >= p.N) continue;
+              *(f32x4*)(p.part + ((size_t)seg * (16 * MB) + m) * p.N + n) = acc[mb][j];
+              if (tile_done)
+                for (int z = seg + 1; z < p.nslots; ++z)
+                  *(f32x4*)(p.part + ((size_t)z * (16 * MB) + m) * p.N + n) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            if (p.out_f32) {
-              *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = acc[j];
-            } else {
-              u32x2 o;
-              o[0] = pack2bf(acc[j][0], acc[j][1]);
-              o[1] = pack2bf(acc[j][2], acc[j][3]);
-              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int n = nb + j * 16;
+              if (n >= p.N) continue;
+              if (FP8) {   // direct output of the fp8 form: apply the row scales here
+                const float sxm = p.sx[m];
+                const f32x4 s4 = *(const f32x4*)(p.sw + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[mb][j][r] *= sxm * s4[r];
+              }
+              if (p.out_f32) {
+                *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = acc[mb][j];
+              } else {
+                u32x2 o;
+                o[0] = pack2bf(acc[mb][j][0], acc[mb][j][1]);
+                o[1] = pack2bf(acc[mb][j][2], acc[mb][j][3]);
+                *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+              }
             }
           }
         }
+        acc[mb][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[mb][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (tile_done) { c_kt = 0; ++c_tile; }
     }
   }
@@ -972,11 +991,12 @@ static void gemm3_geometry(int N, int K, bool direct, int* spb, int* nslots, int
 }
 
 // Batched-decode projection, first half: part[slot][16][N] (f32, `ksplit` slots, all written) with
-// sum_slot part = x[B,K] * W[N,K]^T, or with part == NULL a direct C (bf16, or f32 when out_f32).  B <= 16.
+// sum_slot part = x[B,K] * W[N,K]^T, or with part == NULL a direct C (bf16, or f32 when out_f32).  B <= 32; a slot's
+// slab has 16 rows for B <= 16 and 32 rows for B > 16 (vis_skinny_finalize applies the same rule).
 // ksplit <= 0 means vis_gemm_decode_ksplit(N, K); a larger value only adds zero-filled slots.
 extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, void* C, int B, int N, int K, int lda,
                                     int ldw, int ldc, int ksplit, int out_f32, hipStream_t stream) {
-  if (!A || !W || (!part && !C) || B <= 0 || B > 16 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (!A || !W || (!part && !C) || B <= 0 || B > 32 || N <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % GEMM_BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || (C && ldc % 4 != 0)) return VIS_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)part | (uintptr_t)C) & 15) return VIS_ERR_ARG;
   int spb, need, nwg;
@@ -988,7 +1008,9 @@ extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, vo
     ksplit = 1;
   }
   static const bool attr3_ok = [] {
-    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM3_LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                GEMM3_LDS_BYTES) == hipSuccess;
   }();
   if (!attr3_ok) return VIS_ERR_LAUNCH;
@@ -999,11 +1021,12 @@ extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, vo
   p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
   p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32; p.sx = nullptr; p.sw = nullptr;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_decode_stream_kernel<false>, dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  if (B > 16) hipLaunchKernelGGL((gemm_decode_stream_kernel<false, 2>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((gemm_decode_stream_kernel<false, 1>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   return vis_check_launch();
 }
 
-// number of partial slots vis_gemm_decode_bf16 writes for (N, K): size part as slots x 16 x N floats
+// number of partial slots vis_gemm_decode_bf16 writes for (N, K): size part as slots x (B <= 16 ? 16 : 32) x N floats
 extern "C" int vis_gemm_decode_ksplit(int N, int K) {
   if (N <= 0 || K < GEMM_BK) return 0;
   int spb, slots, nwg;
@@ -1017,7 +1040,7 @@ extern "C" int vis_gemm_decode_ksplit(int N, int K) {
 extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* Wq, const void* sw, void* part, void* C,
                                    int B, int N, int K, int ldx, int ldw, int ldc, int ksplit, int out_f32,
                                    hipStream_t stream) {
-  if (!xq || !Wq || (!part && !C) || B <= 0 || B > 16 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (!xq || !Wq || (!part && !C) || B <= 0 || B > 32 || N <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % 128 != 0 || N % 4 != 0 || ldx % 16 != 0 || ldw % 16 != 0 || ldx < K || ldw < K || (C && ldc % 4 != 0))
     return VIS_ERR_ARG;
   if (!part && (!sx || !sw)) return VIS_ERR_ARG;
@@ -1031,7 +1054,9 @@ extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* W
     ksplit = 1;
   }
   static const bool attr_ok = [] {
-    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM3_LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                GEMM3_LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return VIS_ERR_LAUNCH;
@@ -1042,7 +1067,8 @@ extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* W
   p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
   p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32; p.sx = (const float*)sx; p.sw = (const float*)sw;
   vis_clear_error();
-  hipLaunchKernelGGL(gemm_decode_stream_kernel<true>, dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  if (B > 16) hipLaunchKernelGGL((gemm_decode_stream_kernel<true, 2>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((gemm_decode_stream_kernel<true, 1>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   return vis_check_launch();
 }
 

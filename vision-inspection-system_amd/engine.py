@@ -127,8 +127,8 @@ class Qwen2VLEngine:
         self.lock = threading.Lock()
         dev, bf = self.device, torch.bfloat16
         L, Hkv, Hq, D, H = cfg.layers, cfg.kv_heads, cfg.heads, cfg.head_dim, cfg.hidden
-        if not 1 <= max_batch <= 16:
-            raise ValueError("max_batch must be in 1..16 (one MFMA column block of in-flight sequences)")
+        if not 1 <= max_batch <= 32:
+            raise ValueError("max_batch must be in 1..32 (one or two 16-row MFMA blocks of in-flight sequences)")
         Bm = self.max_batch = max_batch
         # per-sequence ("slot") state; slot 0 doubles as the single-sequence engine
         self.kcache_b = torch.zeros((Bm, L, Hkv, self.max_ctx, D), dtype=bf, device=dev)
@@ -162,7 +162,8 @@ class Qwen2VLEngine:
             self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
             self.b_xn = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
-            self.b_part = torch.empty(16 * 16 * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32, device=dev)
+            self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
+                                      device=dev)   # 16 stream-K slots x (16 or 32) rows
         self.decode_weights = decode_weights
         if decode_weights not in ("bf16", "fp8"):
             raise ValueError("decode_weights must be 'bf16' or 'fp8'")

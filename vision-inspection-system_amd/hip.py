@@ -437,9 +437,14 @@ def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tok
     _check(rc, "vis_argmax_f32")
 
 
+def part_rows(B: int) -> int:
+    """Rows of one partial slab of the batched-decode projection: 16 for up to 16 sequences, 32 for up to 32."""
+    return 16 if B <= 16 else 32
+
+
 def decode_gemm(x: torch.Tensor, w: torch.Tensor, part: Optional[torch.Tensor] = None,
                 out: Optional[torch.Tensor] = None, ksplit: int = 0) -> int:
-    """Batched-decode projection, first half: f32 partials part[slot][16][N] whose sum over the returned number
+    """Batched-decode projection, first half: f32 partials part[slot][part_rows(B)][N] whose sum over the returned number
     of slots is x[B,K] @ w[N,K].T (every slot is written), or - with ``out`` instead of ``part`` - a direct
     bf16 / f32 result."""
     _bf16(x, "decode_gemm x"); _bf16(w, "decode_gemm w")
@@ -450,7 +455,7 @@ def decode_gemm(x: torch.Tensor, w: torch.Tensor, part: Optional[torch.Tensor] =
     lib = load()
     if part is not None:
         ks = ksplit or lib.vis_gemm_decode_ksplit(N, K)
-        if part.dtype != torch.float32 or part.numel() < ks * 16 * N:
+        if part.dtype != torch.float32 or part.numel() < ks * part_rows(B) * N:
             raise HipLibraryError("decode_gemm: partial workspace too small")
         rc = lib.vis_gemm_decode_bf16(_ptr(x), _ptr(w), _ptr(part), None, B, N, K, x.stride(0), w.stride(0), 0, ks, 0,
                                       _stream())
@@ -475,7 +480,7 @@ def decode_gemm_fp8(xq: torch.Tensor, sx: torch.Tensor, wq: torch.Tensor, sw: to
     lib = load()
     if part is not None:
         ks = ksplit or lib.vis_gemm_decode_fp8_ksplit(N, K)
-        if part.dtype != torch.float32 or part.numel() < ks * 16 * N:
+        if part.dtype != torch.float32 or part.numel() < ks * part_rows(B) * N:
             raise HipLibraryError("decode_gemm_fp8: partial workspace too small")
         rc = lib.vis_gemm_decode_fp8(_ptr(xq), _ptr(sx), _ptr(wq), _ptr(sw), _ptr(part), None, B, N, K, xq.stride(0),
                                      wq.stride(0), 0, ks, 0, _stream())
