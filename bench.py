@@ -52,12 +52,15 @@ def synthetic_frame(i: int, size: int) -> np.ndarray:
     return resize_for_model(Image.open(buf).convert("RGB"))
 
 
-def synthetic_prompt(cfg, n_image_tokens: int, n_text: int, seed: int = 99):
-    """[text_a(16) | <vision_start> | image pads | <vision_end> | text_b] with n_text text ids in total."""
+def synthetic_prompt(cfg, n_image_tokens: int, n_text: int, seed: int = 99, order: str = "image-first"):
+    """n_text text ids in total.  image-first: [text_a(16) | <vision_start> | image pads | <vision_end> | text_b];
+    text-first (the reference's part order, vlm_inspector.py:462-470): [text_a | <vision_start> | ... | <vision_end> |
+    text_b(8)] - the inspection prompt precedes the image, so the images of a batch share it."""
     rng = np.random.default_rng(seed)
     hi = min(151643, cfg.vocab - 16)
     text = rng.integers(0, hi, n_text - 2).tolist()
-    return text[:16] + [cfg.vision_start_id] + [cfg.image_token_id] * n_image_tokens + [cfg.vision_end_id] + text[16:]
+    cut = 16 if order == "image-first" else len(text) - 8
+    return text[:cut] + [cfg.vision_start_id] + [cfg.image_token_id] * n_image_tokens + [cfg.vision_end_id] + text[cut:]
 
 
 def prefill_flops(cfg, n_patches: int, S: int) -> float:
@@ -227,6 +230,9 @@ def main():
                          "headline precision; the JSON says so in dtype/config")
     ap.add_argument("--prefill-dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] (LLM prompt-pass projections on the fp8 MFMA) - NOT the headline precision")
+    ap.add_argument("--prompt-order", default="image-first", choices=["image-first", "text-first"],
+                    help="text-first: the reference's message order (text part, then image part); with --batch > 1 the "
+                         "common text prefix is then computed once per batch")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per step per GPU; > 1 uses the batched decode path (BASELINE configs[3]/[4] style "
                          "batch inspection) - NOT the headline single-image configuration")
@@ -256,7 +262,7 @@ def main():
     frame_np = synthetic_frame(rank, args.image_size)
     n_patches = (frame_np.shape[0] // cfg.patch) * (frame_np.shape[1] // cfg.patch)
     n_img_tok = n_patches // cfg.merge ** 2
-    ids = synthetic_prompt(cfg, n_img_tok, args.prompt_tokens)
+    ids = synthetic_prompt(cfg, n_img_tok, args.prompt_tokens, order=args.prompt_order)
     S = len(ids)
     frame = torch.from_numpy(frame_np).to(dev)
     ids_dev = torch.tensor(ids, dtype=torch.int32, device=dev)
@@ -344,7 +350,9 @@ def main():
                         f"{args.image_size} image, greedy decode {new} tok")
                        if args.batch == 1 else
                        (f"batch inspection: {args.batch} x {args.image_size}x{args.image_size} images per step per GPU, "
-                        f"per-image prefill + batched decode {new} tok (NOT the headline configuration)"),
+                        f"per-image prefill + batched decode {new} tok (NOT the headline configuration)"
+                        + ("; text part first as in the reference: the shared text prefix is computed once per batch"
+                           if args.prompt_order == "text-first" else "")),
                        "batch": args.batch,
                        "image_px": args.image_size, "resized_px": list(frame_np.shape[:2]),
                        "image_tokens": n_img_tok, "prompt_tokens": S, "new_tokens": new,

@@ -73,6 +73,13 @@ int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void
 int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
                      int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
                      float scale, vis_stream_t stream);
+/* Same with a row offset: the work items' query rows (and the causal rule key <= query) are positions of the whole
+ * sequence, Q / O hold only rows q_row0 .. q_row0 + Sq - 1 - the prompt pass of a request whose first q_row0 tokens
+ * (the text prefix the reference puts in front of the image, src/agents/vlm_inspector.py:462-470, identical for the
+ * images of a batch) were computed once and copied into its KV cache. */
+int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
+                          int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
+                          float scale, int q_row0, vis_stream_t stream);
 
 /* K10  y[N] = act(W[N,K] x[K] + bias) + R, optional fused RMSNorm of x (norm_w != NULL).
  * out_f32 != 0 writes float logits (lm_head).  One generated token streams every weight once. */

@@ -151,6 +151,43 @@ def test_batched_generation_more_than_16_sequences(device, weights):
             assert out[i] == small[i % 3], f"B={B}: sequence {i} differs from the same request in a batch of 3"
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8"])
+def test_shared_text_prefix_is_bit_identical(device, monkeypatch, dtype):
+    """Batch inspection sends the same text in front of every image: prefill_many computes that prefix once and copies
+    its K / V / V^T into every slot.  The tokens and the first-step logits must be exactly those of the unshared pass."""
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=512, max_batch=4,
+                        prefill_dtype=dtype, decode_weights=dtype)
+    eng.min_shared_prefix = 64
+    g = load_golden()
+    frames = [torch.from_numpy(g["frame_a"]).to(device), torch.from_numpy(g["frame_b1"]).to(device)]
+    rng = np.random.default_rng(5)
+    text = rng.integers(3, 200, 150).tolist()                      # 150 common text tokens -> shared prefix of 128
+
+    def ids_for(f, tail):
+        n = (f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2
+        return text + [cfg.vision_start_id] + [cfg.image_token_id] * n + [cfg.vision_end_id] + tail
+
+    reqs = [(ids_for(frames[0], [7, 8, 9]), [frames[0]]), (ids_for(frames[1], [11]), [frames[1]]),
+            (ids_for(frames[0], [7, 8, 9]), [frames[0]])]
+    assert eng.shared_prefix_len([r[0] for r in reqs]) == 128
+    shared = eng.generate_batch(reqs, max_new_tokens=8, ignore_eos=True)
+    logits_shared = eng.logits_b[:3].clone()
+    monkeypatch.setenv("VIS_SHARE_PREFIX", "0")
+    assert eng.shared_prefix_len([r[0] for r in reqs]) == 0
+    plain = eng.generate_batch(reqs, max_new_tokens=8, ignore_eos=True)
+    assert shared == plain
+    assert torch.equal(logits_shared, eng.logits_b[:3])
+    assert shared[0] == shared[2]
+    # prompts without a common text prefix, or with the image first, fall back to the plain pass
+    assert eng.shared_prefix_len([[1, 2, 3] * 100, [4, 5, 6] * 100]) == 0
+    assert eng.shared_prefix_len([[cfg.vision_start_id] + text, [cfg.vision_start_id] + text]) == 0
+
+
 def _dequantised_sd(cfg, sd):
     """State dict whose LLM projections / lm_head are the engine's e4m3 weights, de-quantised (CPU, same quantiser)."""
     from vision_inspection_system_amd import hip

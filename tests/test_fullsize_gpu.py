@@ -76,6 +76,24 @@ def test_7b_decode_step_agrees_with_prompt_pass(big):
         assert int(via_decode.argmax()) == int(via_prefill.argmax()) == toks[3]
 
 
+def test_7b_shared_text_prefix_is_bit_identical(big, monkeypatch):
+    """The reference's message order (text part, then the image): the ~1000-token inspection prompt is common to the
+    images of a batch; computing its K / V once per batch must not change a single token or logit."""
+    cfg, eng, (ra, rb) = big
+    rng = np.random.default_rng(11)
+    text = rng.integers(0, 1000, 1000).tolist()
+    n_img = (980 // 14) ** 2 // 4
+    mk = lambda tail: text + [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + tail
+    reqs = [(mk([5, 6, 7]), ra[1]), (mk([8]), rb[1]), (mk([5, 6, 7]), ra[1])]
+    assert eng.shared_prefix_len([r[0] for r in reqs]) == 960
+    shared = eng.generate_batch(reqs, max_new_tokens=8, ignore_eos=True)
+    logits = eng.logits_b[:3].clone()
+    monkeypatch.setenv("VIS_SHARE_PREFIX", "0")
+    plain = eng.generate_batch(reqs, max_new_tokens=8, ignore_eos=True)
+    assert shared == plain and torch.equal(logits, eng.logits_b[:3])
+    assert shared[0] == shared[2]
+
+
 def test_mllama_11b_properties(device):
     """Row f2 at exact Llama-3.2-11B-Vision shapes (seeded random weights, 1024x1024 image = 2x2 tiles): reproducible,
     graph == eager, and the decode step (GEMVs, cache self-attention, cached cross-attention keys) agrees with a prompt

@@ -438,6 +438,31 @@ def test_decode_gemm_fp8_and_finalize(hip, device, B, N, K):
     _assert_close(out, prod, atol=3e-2, rtol=1e-2, what="decode gemm fp8 direct")
 
 
+def test_attn_prefill_row_offset_equals_full_pass(hip, device):
+    """vis_attn_prefill_rows: the causal pass over rows P.. of a sequence (Q / O hold only those rows, keys 0.. come from
+    the cache) gives bit-identical rows to the pass over the whole sequence."""
+    Hq, Hkv, HD, S, P = 8, 2, 128, 700, 320
+    q = _randn((Hq, S, HD), device, 300)
+    k = _randn((Hkv, S, HD), device, 301)
+    v = _randn((Hkv, S, HD), device, 302)
+    ld = (S + 63) // 64 * 64
+    vt = torch.zeros((Hkv, HD, ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v.transpose(1, 2)
+    full = torch.empty((S, Hq * HD), dtype=torch.bfloat16, device=device)
+    hip.attn_prefill(q, k, vt, full, hip.make_attn_work([(0, S)], True, device), True, HD ** -0.5)
+    items = sorted([(q0, min(128, S - q0), 0, S) for q0 in range(P, S, 128)], key=lambda it: -(it[0] + it[1]))
+    work = torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+    part = torch.empty((S - P, Hq * HD), dtype=torch.bfloat16, device=device)
+    hip.attn_prefill(q[:, P:].contiguous(), k, vt, part, work, True, HD ** -0.5, q_row0=P)
+    assert torch.equal(part, full[P:])
+    # and against fp32 arithmetic
+    qf, kf, vf = q.float(), k.float().repeat_interleave(Hq // Hkv, 0), v.float().repeat_interleave(Hq // Hkv, 0)
+    sc = torch.einsum("hqd,hkd->hqk", qf[:, P:], kf) * HD ** -0.5
+    mask = torch.arange(S, device=device)[None, :] <= (torch.arange(P, S, device=device)[:, None])
+    ref = torch.einsum("hqk,hkd->qhd", torch.softmax(sc.masked_fill(~mask[None], float("-inf")), -1), vf).reshape(S - P, Hq * HD)
+    _assert_close(part, ref, atol=2e-2, rtol=2e-2, what="attention with row offset")
+
+
 # ----------------------------------------------------------------------------- K10 GEMV
 @pytest.mark.parametrize("N,K", [(512, 256), (4608, 3584), (3584, 18944), (1000, 704)])
 def test_gemv_plain(hip, device, N, K):

@@ -52,6 +52,7 @@ struct AttnArgs {
   const int4* work;  // [grid.x] {q0, qn, k0, k1}
   int Sq, k_tokens, vt_ld, ldo, group;
   float scale_log2;
+  int q_row0;        // work-list query rows are positions of the whole sequence; Q / O hold rows q_row0 .. q_row0 + Sq - 1
 };
 
 #define ATT_NEG (-1.0e30f)
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
   bf16x4s qt[2];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const int qrow = min(wq0 + qb * 16 + l15, p.Sq - 1);
+    const int qrow = min(wq0 + qb * 16 + l15, p.q_row0 + p.Sq - 1) - p.q_row0;
     const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
 #pragma unroll
     for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ds * 32 + 8 * h));
@@ -377,15 +378,28 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
     const int q = wq0 + row;
     if (q < q0 + qn) {
       const u32x4 o = *(const u32x4*)(ost + row * OROW + c * 16);
-      *(u32x4*)(p.O + (size_t)q * p.ldo + head * HD + c * 8) = o;
+      *(u32x4*)(p.O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
     }
   }
 }
 
+// vis_attn_prefill with a row offset: the work items' query rows (and the causal rule key <= query) are positions of
+// the whole sequence, while Q / O hold only rows q_row0 .. q_row0 + Sq - 1 (the prompt pass of a request whose first
+// q_row0 tokens were computed elsewhere: a text prefix shared by the images of a batch).
+extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O, const void* work,
+                                     int n_work, int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo,
+                                     int causal, float scale, int q_row0, hipStream_t stream);
+
 extern "C" int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, const void* work,
                                 int n_work, int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo,
                                 int causal, float scale, hipStream_t stream) {
-  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  return vis_attn_prefill_rows(Q, K, Vt, O, work, n_work, Hq, Hkv, HD, Sq, k_tokens, vt_ld, ldo, causal, scale, 0, stream);
+}
+
+extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O, const void* work,
+                                     int n_work, int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo,
+                                     int causal, float scale, int q_row0, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || q_row0 < 0) return VIS_ERR_ARG;
   if (HD != 128 && HD != 80) return VIS_ERR_ARG;
   if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * HD) return VIS_ERR_ARG;
   if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
@@ -394,6 +408,7 @@ extern "C" int vis_attn_prefill(const void* Q, const void* K, const void* Vt, vo
   p.work = (const int4*)work;
   p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
   p.scale_log2 = scale * 1.4426950408889634f;
+  p.q_row0 = q_row0;
   if (n_work > 65535) return VIS_ERR_ARG;
   const dim3 grid(Hq, n_work), block(256);
   // head_dim 80 is built for three workgroups per CU (768 slots, <= 168 VGPRs).  VIS_ATTN_OCC=2 caps residency at two

@@ -216,6 +216,7 @@ class Qwen2VLEngine:
         self.vit_streams = int(os.environ.get("VIS_VIT_STREAMS", "1"))   # 2: row-split ViT on two streams (opt-in; measured slower)
         self.vit_split_min_rows = 2048
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self.min_shared_prefix = 256     # shorter common prefixes are not worth a separate pass
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self.prompt_len = 0
@@ -360,9 +361,17 @@ class Qwen2VLEngine:
     def prefill(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (),
                 ids_dev: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
                 temperature: float = 0.0, seed: int = 0, max_new_tokens: Optional[int] = None,
-                slot: int = 0, split_vit: bool = True, image_embeds: Optional[torch.Tensor] = None) -> None:
+                slot: int = 0, split_vit: bool = True, image_embeds: Optional[torch.Tensor] = None,
+                prefix: Optional[dict] = None, collect_prefix: bool = False) -> Optional[dict]:
         """Run the prompt through the LLM, fill the KV cache of ``slot`` and pick the first token
-        (greedy when temperature == 0, Gumbel-max sampled otherwise)."""
+        (greedy when temperature == 0, Gumbel-max sampled otherwise).
+
+        ``prefix`` (from ``collect_prefix``): K / V / V^T of the first P tokens (P a multiple of 64, text only) computed by
+        another pass over the SAME leading tokens - the reference puts the ~1000-token inspection prompt in front of the
+        image (src/agents/vlm_inspector.py:462-470), so the images of a batch share it.  They are copied into this slot
+        and only rows P.. are computed; every row's arithmetic is unchanged (row-independent GEMMs, attention key tiles
+        on absolute 64-key boundaries), so the result is bit-identical to the full pass.
+        ``collect_prefix``: run rows 0..S-1 only (no lm_head, no token) and return that bundle."""
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
         if not 0 <= slot < self.max_batch:
             raise ValueError("slot out of range")
@@ -391,41 +400,67 @@ class Qwen2VLEngine:
         if ids_dev is None:
             ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
         H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
-        x = torch.empty((S, H), dtype=bf, device=dev)
-        hip.gather_rows(w.embed, ids_dev, x)
+        L = len(w.llm)
+        P = 0
+        if prefix is not None:
+            P = int(prefix["len"])
+            if P % 64 or not 0 < P < S or collect_prefix:
+                raise ValueError("bad shared prefix")
+            if not np.array_equal(ids_np[:P], prefix["ids"]):
+                raise ValueError("the shared prefix does not match this prompt")
+            if (ids_np[:P] == cfg.image_token_id).any():
+                raise ValueError("a shared prefix must be text only")
+        n = S - P                                   # rows computed here
+        x = torch.empty((n, H), dtype=bf, device=dev)
+        hip.gather_rows(w.embed, ids_dev[P:] if P else ids_dev, x)
         if len(frames):
             # image_embeds: the merged ViT output of these frames computed elsewhere (prefill_many batches the tower
             # over several requests' images)
             img = image_embeds if image_embeds is not None else self.vision_forward(frames, split_rows=split_vit)
-            idx = np.nonzero(ids_np == cfg.image_token_id)[0].astype(np.int32)
+            idx = np.nonzero(ids_np == cfg.image_token_id)[0].astype(np.int32) - P
             if idx.shape[0] != img.shape[0]:
                 raise ValueError(f"image tokens ({idx.shape[0]}) and image features ({img.shape[0]}) do not match")
             hip.scatter_rows(img, torch.from_numpy(idx).to(dev), x)
             if taps is not None:
                 taps["image_embeds"] = img
-        cos, sin = cos_t[:S], sin_t[:S]
-        work = hip.make_attn_work([(0, S)], True, dev)
+        cos, sin = cos_t[P:S], sin_t[P:S]
+        if P:
+            items = [(q0, min(128, S - q0), 0, S) for q0 in range(P, S, 128)]
+            items.sort(key=lambda it: -(it[0] + it[1]))
+            work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
+        else:
+            work = hip.make_attn_work([(0, S)], True, dev)
         ld = _round_up(S, 64)
         nq = (Hq + 2 * Hkv) * D
-        y = torch.empty((S, H), dtype=bf, device=dev)
-        qkv = torch.empty((S, nq), dtype=bf, device=dev)
-        q = torch.empty((Hq, S, D), dtype=bf, device=dev)
-        vt = torch.empty((Hkv, D, ld), dtype=bf, device=dev)
-        att = torch.empty((S, Hq * D), dtype=bf, device=dev)
-        act = torch.empty((S, cfg.intermediate), dtype=bf, device=dev)
+        y = torch.empty((n, H), dtype=bf, device=dev)
+        qkv = torch.empty((n, nq), dtype=bf, device=dev)
+        q = torch.empty((Hq, n, D), dtype=bf, device=dev)
+        # V^T per layer: one buffer re-used by all layers, or - when a prefix is involved - one per layer, so that the
+        # prefix columns can be copied in (or handed out) in one go
+        per_layer_vt = bool(P) or collect_prefix
+        vt_all = torch.empty((L if per_layer_vt else 1, Hkv, D, ld), dtype=bf, device=dev)
+        if P:
+            kcache[:, :, :P].copy_(prefix["k"])
+            vcache[:, :, :P].copy_(prefix["v"])
+            vt_all[:, :, :, :P].copy_(prefix["vt"])
+        att = torch.empty((n, Hq * D), dtype=bf, device=dev)
+        act = torch.empty((n, cfg.intermediate), dtype=bf, device=dev)
         scale = D ** -0.5
-        tiles4 = ((S + 255) // 256) * ((H + 255) // 256)
+        # The long-K down projection always runs as two K-slices (f32 partials, fixed-order sum): at S = 2249 its 126
+        # 256x256 tiles would leave half the chip idle, and making the choice a function of the LAYER only (never of the
+        # row count) keeps every row's summation order the same in the full, the prefix and the suffix pass.
         splitk_work = None
-        if S >= 1024 and cfg.intermediate >= 8192 and 96 <= tiles4 <= 128 and H % 8 == 0:
-            splitk_work = torch.empty(2 * S * H, dtype=torch.float32, device=dev)
+        if cfg.intermediate >= 8192 and H % 8 == 0:
+            splitk_work = torch.empty(2 * n * H, dtype=torch.float32, device=dev)
         if self.prefill_dtype == "fp8":
-            self._llm_layers_fp8(x, qkv, q, vt, att, act, cos, sin, kcache, vcache, work, S, taps)
+            self._llm_layers_fp8(x, qkv, q, vt_all, att, act, cos, sin, kcache, vcache, work, n, taps, P)
         else:
             for li, lw in enumerate(w.llm):
+                vt = vt_all[li if per_layer_vt else 0]
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
-                hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=0)
-                hip.attn_prefill(q, kcache[li], vt, att, work, True, scale)
+                hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=P, vt_col0=P)
+                hip.attn_prefill(q, kcache[li], vt, att, work, True, scale, q_row0=P)
                 hip.gemm(att, lw.o_w, residual=x, out=x)
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
@@ -435,8 +470,12 @@ class Qwen2VLEngine:
                     hip.gemm(act, lw.down_w, residual=x, out=x)
                 if taps is not None and li == 0:
                     taps["layer0"] = x.clone()
+        if collect_prefix:
+            Pn = (S // 64) * 64
+            return {"len": Pn, "ids": ids_np[:Pn].copy(), "k": kcache[:, :, :Pn].clone(), "v": vcache[:, :, :Pn].clone(),
+                    "vt": vt_all[:, :, :, :Pn].clone()}
         # first token: final norm fused into the lm_head GEMV of the last position only
-        hip.gemv(x[S - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+        hip.gemv(x[n - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
         if taps is not None:
             taps["first_logits"] = logits.clone()
         step.fill_(S - 1)
@@ -447,9 +486,11 @@ class Qwen2VLEngine:
         if slot == 0:
             self.prompt_len = S
             self._decoded = 0
+        return None
 
-    def _llm_layers_fp8(self, x, qkv, q, vt, att, act, cos, sin, kcache, vcache, work, S, taps) -> None:
-        """The decoder layers of the prompt pass with every projection on the fp8 MFMA (configs[4])."""
+    def _llm_layers_fp8(self, x, qkv, q, vt_all, att, act, cos, sin, kcache, vcache, work, S, taps, P: int = 0) -> None:
+        """The decoder layers of the prompt pass with every projection on the fp8 MFMA (configs[4]).  S = rows computed
+        here, P = rows of a shared prefix already in the cache (vt_all: one V^T buffer per layer when it has > 1)."""
         cfg, w, dev = self.cfg, self.w, self.device
         H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
         scale = D ** -0.5
@@ -457,15 +498,15 @@ class Qwen2VLEngine:
         aq = torch.empty((S, Hq * D), dtype=torch.uint8, device=dev)
         hq = torch.zeros((S, self.kpad), dtype=torch.uint8, device=dev)      # pad columns stay 0 (= +0.0 in e4m3)
         sx = torch.empty(S, dtype=torch.float32, device=dev)
-        tiles4 = ((S + 255) // 256) * ((H + 255) // 256)
         dwork = torch.empty(2 * S * H, dtype=torch.float32, device=dev) \
-            if (S >= 1024 and self.kpad >= 8192 and 96 <= tiles4 <= 128 and H % 8 == 0) else None
+            if (self.kpad >= 8192 and H % 8 == 0) else None      # as in the bf16 pass: a function of the layer only
         for li, lw in enumerate(w.llm):
             q8 = self.q8[li]
+            vt = vt_all[li if vt_all.shape[0] > 1 else 0]
             hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln1_w, eps=cfg.rms_eps)
             hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=lw.qkv_b, out=qkv)
-            hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=0)
-            hip.attn_prefill(q, kcache[li], vt, att, work, True, scale)
+            hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=P, vt_col0=P)
+            hip.attn_prefill(q, kcache[li], vt, att, work, True, scale, q_row0=P)
             hip.quant_rows_fp8(att, aq, sx)
             hip.gemm_fp8(aq, sx, *q8["o_w"], residual=x, out=x)
             hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln2_w, eps=cfg.rms_eps)
@@ -484,10 +525,17 @@ class Qwen2VLEngine:
         all of them."""
         B = len(requests)
         n_streams = max(1, min(B, int(os.environ.get("VIS_PREFILL_STREAMS", "2"))))
+        # The text in front of the first image is the same for every image of a batch inspection (the reference's
+        # INSPECTOR_PROMPT, vlm_inspector.py:452-470): its K / V / V^T are computed once and copied into every slot.
+        shared = None
+        P = self.shared_prefix_len([r[0] for r in requests])
+        if P:
+            shared = self.prefill(list(requests[0][0][:P]), (), temperature=temperature, seed=seed, max_new_tokens=0,
+                                  slot=0, collect_prefix=True)
         if n_streams == 1:
             for b, (ids, frames) in enumerate(requests):
                 self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
-                             max_new_tokens=max_new_tokens, slot=b)
+                             max_new_tokens=max_new_tokens, slot=b, prefix=shared)
             return
         cur = torch.cuda.current_stream(self.device)
         if len(self._prefill_streams) < n_streams:
@@ -520,9 +568,31 @@ class Qwen2VLEngine:
                 if embeds[b] is not None:
                     embeds[b].record_stream(st)
                 self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
-                             max_new_tokens=max_new_tokens, slot=b, split_vit=False, image_embeds=embeds[b])
+                             max_new_tokens=max_new_tokens, slot=b, split_vit=False, image_embeds=embeds[b], prefix=shared)
         for st in self._prefill_streams[:n_streams]:
             cur.wait_stream(st)
+        if shared is not None:
+            for t in (shared["k"], shared["v"], shared["vt"]):
+                for st in self._prefill_streams[:n_streams]:
+                    t.record_stream(st)
+
+    def shared_prefix_len(self, id_lists: Sequence[Sequence[int]]) -> int:
+        """Length (a multiple of 64, 0 = do not share) of the text-only token prefix common to all prompts of a batch."""
+        if len(id_lists) < 2 or os.environ.get("VIS_SHARE_PREFIX", "1") == "0":
+            return 0
+        cfg = self.cfg
+        first = np.asarray(list(id_lists[0]), dtype=np.int64)
+        P = len(first) - 1                       # every request keeps at least one row of its own
+        for ids in id_lists[1:]:
+            other = np.asarray(list(ids), dtype=np.int64)
+            m = min(P, len(other) - 1)
+            neq = np.nonzero(first[:m] != other[:m])[0]
+            P = int(neq[0]) if neq.size else m
+        special = np.nonzero((first[:P] == cfg.image_token_id) | (first[:P] == cfg.vision_start_id))[0]
+        if special.size:
+            P = int(special[0])
+        P = (P // 64) * 64
+        return P if P >= self.min_shared_prefix else 0
 
     # ------------------------------------------------------------------ decode
     def _decode_step(self) -> None:

@@ -29,6 +29,7 @@ _SIGS = {
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
+    "vis_attn_prefill_rows": "ppppp" + "iiiiiiiii" + "f" + "i" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_gemv_fp8w": "ppppppp" + "iiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
@@ -321,8 +322,9 @@ def make_attn_work(segments, causal: bool, device, block_q: int = 128, heads: in
 
 
 def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
-                 causal: bool, scale: float) -> torch.Tensor:
-    """q [Hq,S,HD], k [Hkv,T,HD], vt [Hkv,HD,ld] -> out [S, Hq*HD]."""
+                 causal: bool, scale: float, q_row0: int = 0) -> torch.Tensor:
+    """q [Hq,S,HD], k [Hkv,T,HD], vt [Hkv,HD,ld] -> out [S, Hq*HD].  q_row0 > 0: q / out hold rows q_row0.. of a longer
+    sequence whose positions the work items (and the causal rule) refer to."""
     _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
     Hq, S, HD = q.shape
     Hkv, T, _ = k.shape
@@ -332,9 +334,9 @@ def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.
         raise HipLibraryError("attn_prefill: bad shapes")
     if work.dtype != torch.int32 or work.dim() != 2 or work.shape[1] != 4 or not work.is_contiguous():
         raise HipLibraryError("attn_prefill: work must be int32 [n,4]")
-    rc = load().vis_attn_prefill(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
-                                 S, T, vt.shape[2], out.stride(0), 1 if causal else 0, scale, _stream())
-    _check(rc, "vis_attn_prefill")
+    rc = load().vis_attn_prefill_rows(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
+                                      S, T, vt.shape[2], out.stride(0), 1 if causal else 0, scale, int(q_row0), _stream())
+    _check(rc, "vis_attn_prefill_rows")
     return out
 
 
