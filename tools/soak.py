@@ -12,6 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--fp8", action="store_true")
 ap.add_argument("--iters", type=int, default=4)
 ap.add_argument("--batch", type=int, default=6)
+ap.add_argument("--text-first", action="store_true", help="the reference's part order: common text prefix, shared per batch")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = Qwen2VLConfig.qwen2_vl_7b()
@@ -22,6 +23,9 @@ frames = [torch.from_numpy(rng.integers(0, 256, (980, 980, 3), dtype=np.uint8)).
 n_img = (980 // 14) ** 2 // 4
 def ids_for(seed):
     r = np.random.default_rng(seed)
+    if a.text_first:
+        common = np.random.default_rng(1234).integers(0, 1000, 700).tolist()
+        return common + [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + r.integers(0, 1000, 5).tolist()
     return [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + r.integers(0, 1000, 300).tolist()
 reqs = [(ids_for(b % 2), [frames[b % 2]]) for b in range(a.batch)]      # two distinct requests, alternating over the slots
 first = None
