@@ -562,7 +562,7 @@ def test_decode_attention_fused(hip, device, Hq, Hkv, ctx0, steps, T):
     emb = torch.cat((ang, ang), -1)
     cos_t, sin_t = emb.cos().to(device), emb.sin().to(device)
     step = torch.full((1,), ctx0, dtype=torch.int32, device=device)
-    nsplit = T // 128
+    nsplit = T // hip.DECODE_KEYS_PER_SPLIT
     part_o = torch.empty(Hq * nsplit * HD, dtype=torch.float32, device=device)
     part_ml = torch.empty(Hq * nsplit * 2, dtype=torch.float32, device=device)
     out = torch.empty((Hq * HD,), dtype=torch.bfloat16, device=device)
@@ -705,7 +705,7 @@ def test_batched_decode_attention_and_argmax(hip, device):
     cos_t, sin_t = emb.cos().to(device), emb.sin().to(device)
     qkv = _randn((B, (Hq + 2 * Hkv) * HD), device, 113)
     step = torch.tensor(ctx, dtype=torch.int32, device=device)
-    ns = T // 128
+    ns = T // hip.DECODE_KEYS_PER_SPLIT
     po = torch.empty(B * Hq * ns * HD, dtype=torch.float32, device=device)
     pml = torch.empty(B * Hq * ns * 2, dtype=torch.float32, device=device)
     out = torch.empty((B, Hq * HD), dtype=torch.bfloat16, device=device)

@@ -474,7 +474,7 @@ extern "C" int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, c
 // The position lives in DEVICE memory: the launch is hipGraph-replayable.
 // Partials (unnormalised o, running max in the log2 domain, sum) are merged by
 // decode_attn_combine_kernel.
-#define DA_ITERS 8                  // 16 keys per block iteration
+#define DA_ITERS 4                  // 16 keys per block iteration
 #define DA_MAXKEYS (16 * DA_ITERS)  // keys per split
 
 struct DecAttnArgs {
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
 
 // merge the per-split partials of one query head (only the splits that ran): 256 threads = 128 dims x 2
 // split-halves; the first partial loads are issued before the position is known
-#define CB_PRE 16   // partial rows preloaded per thread: covers 32 splits = 4096 cached keys
+#define CB_PRE 32   // partial rows preloaded per thread: covers 64 splits = 4096 cached keys
 __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* __restrict__ part_o,
                                                                   const float* __restrict__ part_ml,
                                                                   bf16_t* __restrict__ out, int nsplit,
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
     const int s = half + 2 * j;
     if (s < active) o += wgt[s] * v[j];
   }
-  for (int s = half + 2 * CB_PRE; s < active; s += 2) o += wgt[s] * po[(size_t)s * HD];   // contexts past 32 splits
+  for (int s = half + 2 * CB_PRE; s < active; s += 2) o += wgt[s] * po[(size_t)s * HD];   // contexts past 64 splits
   osum[half][d] = o;
   __syncthreads();
   if (tid < HD) {

@@ -123,7 +123,7 @@ class Qwen2VLEngine:
             raise hip.HipLibraryError("Qwen2VLEngine needs a ROCm GPU (no CPU fallback exists)")
         self.cfg, self.w, self.device = cfg, weights, torch.device(device)
         self.max_ctx = _round_up(max_ctx, 64)
-        self.nsplit = decode_splits or max(1, self.max_ctx // 128)  # <= 128 keys per split
+        self.nsplit = decode_splits or max(1, -(-self.max_ctx // hip.DECODE_KEYS_PER_SPLIT))
         self.lock = threading.Lock()
         dev, bf = self.device, torch.bfloat16
         L, Hkv, Hq, D, H = cfg.layers, cfg.kv_heads, cfg.heads, cfg.head_dim, cfg.hidden

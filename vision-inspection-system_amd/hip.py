@@ -17,6 +17,7 @@ _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libvis_hip.so")
 
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
+DECODE_KEYS_PER_SPLIT = 64   # DA_MAXKEYS of csrc/decode.hip: a decode-attention split owns this many cached keys
 
 # name -> argtypes; every entry point returns int. 'p' = pointer, 'i' = int, 'f' = float
 _SIGS = {

@@ -102,8 +102,8 @@ class MllamaEngine:
         self.n_self, self.n_cross = len(self.self_idx), len(cfg.cross_layers)
         self.TP = cfg.max_tiles * cfg.tile_tokens
         self.Tk = _round_up(self.TP, 64)
-        self.nsplit = max(1, self.max_ctx // 128)
-        self.xsplit = (self.Tk + 127) // 128
+        self.nsplit = max(1, -(-self.max_ctx // hip.DECODE_KEYS_PER_SPLIT))
+        self.xsplit = -(-self.Tk // hip.DECODE_KEYS_PER_SPLIT)
         self.kcache = torch.zeros((self.n_self, Hkv, self.max_ctx, D), dtype=bf, device=dev)
         self.vcache = torch.zeros((self.n_self, Hkv, self.max_ctx, D), dtype=bf, device=dev)
         self.xk = torch.zeros((self.n_cross, Hkv, self.Tk, D), dtype=bf, device=dev)
