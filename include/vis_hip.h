@@ -109,9 +109,9 @@ int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_idx, void* 
 /* batch > 1: sequence b reads logits + b*ld_logits, writes tokens[b*max_tokens + step[b]], cur_token[b],
  * step_ptr[b]; ws_val / ws_idx need 256 entries per sequence. */
 
-/* K10 (batched decode), first half.  For up to 32 in-flight sequences the weight matrix is streamed from HBM
+/* K10 (batched decode), first half.  For up to 64 in-flight sequences the weight matrix is streamed from HBM
  * ONCE per step by <= 256 persistent workgroups (one per CU, 7-stage LDS-DMA ring, stream-K cut of the
- * (128-column tile, K-step) sequence).  part[slot][R][N] (f32), R = 16 for B <= 16 and 32 for B <= 32 (one or two
+ * (128-column tile, K-step) sequence).  part[slot][R][N] (f32), R = 16 / 32 / 64 for B <= 16 / 32 / 64 (one, two or four
  * 16-row MFMA blocks; vis_skinny_finalize uses the same rule): `ksplit` slots, ALL written (unused ones
  * zero-filled), sum over slots = x[B,K] * W[N,K]^T; the slot order is fixed by (N, K) alone, so results are
  * bitwise reproducible.  ksplit <= 0 means vis_gemm_decode_ksplit(N, K) = the slots the geometry needs (<= 16);

@@ -130,20 +130,20 @@ def test_batched_generation_matches_single(device):
 
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
 def test_batched_generation_more_than_16_sequences(device, weights):
-    """17..32 in-flight sequences use two 16-row MFMA blocks in the batched projection: the tokens of a request are the
-    same as in a batch of <= 16 (rows are independent; the stream-K slot order depends on (N, K) only)."""
+    """17..32 (33..64) in-flight sequences use two (four) 16-row MFMA blocks in the batched projection: the tokens of a
+    request are the same as in a batch of <= 16 (rows are independent; the stream-K slot order depends on (N, K) only)."""
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
     from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
     cfg = Qwen2VLConfig.tiny()
     sd = synth_state_dict(cfg, seed=0)
-    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=32, decode_weights=weights)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=64, decode_weights=weights)
     g = load_golden()
     fa = [torch.from_numpy(g["frame_a"]).to(device)]
     fb = [torch.from_numpy(g["frame_b1"]).to(device), torch.from_numpy(g["frame_b2"]).to(device)]
     base = [(g["ids_a"].tolist(), fa), (g["ids_b"].tolist(), fb), ([256, 72, 105, 33], [])]
     small = eng.generate_batch(base, max_new_tokens=10, ignore_eos=True)
-    for B in (17, 32):
+    for B in (17, 32, 40, 64):
         reqs = [base[i % 3] for i in range(B)]
         out = eng.generate_batch(reqs, max_new_tokens=10, ignore_eos=True)
         assert len(out) == B

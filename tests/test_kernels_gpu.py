@@ -406,7 +406,7 @@ def test_gemm_fp8_swiglu_and_asymmetric_identity(hip, device):
 
 
 @pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 768), (16, 4608, 3584), (8, 3584, 18944), (19, 1000, 768),
-                                   (32, 4608, 3584)])
+                                   (32, 4608, 3584), (40, 1000, 768), (64, 4608, 3584)])
 def test_decode_gemm_fp8_and_finalize(hip, device, B, N, K):
     """fp8 batched-decode projection + fp8 finalisation against fp32 arithmetic on the same quantised operands."""
     x = _randn((B, K), device, 180, 2.0)
@@ -643,7 +643,8 @@ def test_patchify_matches_reference_layout(hip, device):
 
 # ----------------------------------------------------------------------------- K10 batched decode projection
 @pytest.mark.parametrize("B,N,K", [(1, 512, 256), (5, 1000, 704), (16, 4608, 3584), (8, 3584, 18944),
-                                   (17, 1000, 704), (32, 4608, 3584), (24, 3584, 18944)])   # > 16: two 16-row MFMA blocks
+                                   (17, 1000, 704), (32, 4608, 3584), (24, 3584, 18944),   # > 16: two 16-row MFMA blocks
+                                   (33, 1000, 704), (64, 4608, 3584), (48, 3584, 18944)])  # > 32: four, 64-row x tile
 def test_decode_gemm_split_and_finalize(hip, device, B, N, K):
     x = _randn((B, K), device, 100, 2.0)
     w = _randn((N, K), device, 101, 1.0 / math.sqrt(K))

@@ -198,7 +198,7 @@ def run_multi_image_inspection(image_paths: List[str], criticality: str = "mediu
     pre: Dict[int, Dict[str, Any]] = {}
     if _inspect is run_inspection and len(my_idx) > 1 and _local_batching():
         try:  # shared-decode fast path; any problem falls back to the per-image loop below
-            group = int(os.environ.get("VIS_MAX_BATCH", "32"))
+            group = int(os.environ.get("VIS_MAX_BATCH", "64"))
             for g0 in range(0, len(my_idx), group):
                 chunk = my_idx[g0:g0 + group]
                 outs = run_inspections_batched([image_paths[i] for i in chunk], criticality, domain, user_notes)

@@ -97,7 +97,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
         if key in _ENGINES:
             return _ENGINES[key]
         max_ctx = int(os.environ.get("VIS_MAX_CTX", "4096"))
-        max_batch = max(1, min(32, int(os.environ.get("VIS_MAX_BATCH", "32"))))
+        max_batch = max(1, min(64, int(os.environ.get("VIS_MAX_BATCH", "64"))))
         mllama = _load_mllama(model_id, device, max_ctx)
         if mllama is not None:
             _ENGINES[key] = mllama

@@ -68,7 +68,7 @@ __device__ __forceinline__ f32x4 fin_sum_dyn(const float* base, size_t stride, i
 
 __global__ __launch_bounds__(FIN_THREADS) void skinny_finalize_kernel(FinArgs p) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  const size_t stride = (size_t)(gridDim.x > 16 ? 32 : 16) * p.N;  // between K-slices: a slab has 16 rows (B <= 16) or 32
+  const size_t stride = (size_t)(gridDim.x > 32 ? 64 : gridDim.x > 16 ? 32 : 16) * p.N;  // a slab has 16 / 32 / 64 rows
   const float* pb = p.part + (size_t)b * p.N;
   const int n_out = p.swiglu ? (p.N >> 1) : p.N;
   float ss = 0.f;
@@ -181,7 +181,7 @@ extern "C" int vis_skinny_finalize_fp8(const void* part, int ksplit, const void*
                                        const void* R, const void* norm_w, void* y, void* yn, void* yq, void* yq_scale,
                                        int B, int N, int ldr, int ldy, int ldyn, int ldyq, int swiglu, float eps,
                                        hipStream_t stream) {
-  if (!part || !y || B <= 0 || B > 32 || N <= 0 || N % 4 != 0 || ksplit < 1 || ksplit > FIN_MAXKS) return VIS_ERR_ARG;
+  if (!part || !y || B <= 0 || B > 64 || N <= 0 || N % 4 != 0 || ksplit < 1 || ksplit > FIN_MAXKS) return VIS_ERR_ARG;
   if (swiglu && (N % 32 != 0 || bias || R)) return VIS_ERR_ARG;
   if ((yn != nullptr) != (norm_w != nullptr)) return VIS_ERR_ARG;
   if ((sx != nullptr) != (sw != nullptr) || (yq != nullptr) != (yq_scale != nullptr)) return VIS_ERR_ARG;
@@ -200,7 +200,7 @@ extern "C" int vis_skinny_finalize_fp8(const void* part, int ksplit, const void*
 extern "C" int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const void* R, const void* norm_w,
                                    void* y, void* yn, int B, int N, int ldr, int ldy, int ldyn, int swiglu,
                                    float eps, hipStream_t stream) {
-  if (!part || !y || B <= 0 || B > 32 || N <= 0 || N % 4 != 0 || ksplit < 1 || ksplit > FIN_MAXKS) return VIS_ERR_ARG;
+  if (!part || !y || B <= 0 || B > 64 || N <= 0 || N % 4 != 0 || ksplit < 1 || ksplit > FIN_MAXKS) return VIS_ERR_ARG;
   if (swiglu && (N % 32 != 0 || bias || R)) return VIS_ERR_ARG;
   if ((yn != nullptr) != (norm_w != nullptr)) return VIS_ERR_ARG;
   if (ldy % 4 != 0 || (R && ldr % 4 != 0) || (yn && ldyn % 4 != 0)) return VIS_ERR_ARG;

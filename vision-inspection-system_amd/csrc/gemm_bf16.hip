@@ -790,9 +790,23 @@ __device__ __forceinline__ void gemm3_wait_stages(int younger) {
   }
 }
 static_assert(GEMM3_DEPTH == 7 && GEMM3_PER == 5, "gemm3_wait_stages encodes (DEPTH-2) x PER");
+// MB = 4 (33..64 sequences): the x tile is 64 rows (8 KiB), a stage 24 KiB, six LDS-DMA instructions per thread per
+// stage, and the ring is 6 deep (6 x 24 KiB = 144 KiB)
+#define GEMM3W_DEPTH 6
+#define GEMM3W_STAGE_BYTES ((64 + GEMM_BN) * GEMM_BK * 2)        // 24576
+#define GEMM3W_LDS_BYTES (GEMM3W_DEPTH * GEMM3W_STAGE_BYTES)     // 147456
+__device__ __forceinline__ void gemm3w_wait_stages(int younger) {
+  switch (younger) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+  }
+}
 
-// MB = 16-row blocks of x: 1 for M <= 16 sequences, 2 for M <= 32 (the x tile always stages 32 rows); the partial slab
-// of a slot has 16 * MB rows.
+// MB = 16-row blocks of x: 1 for M <= 16 sequences, 2 for M <= 32 (x tile of 32 rows, 7-deep ring), 4 for M <= 64 (x tile
+// of 64 rows, 6-deep ring); the partial slab of a slot has 16 * MB rows.
 template <bool FP8, int MB>
 __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs p) {
   constexpr int EB = FP8 ? 1 : 2;  // bytes per element
@@ -805,11 +819,16 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
   const int nsteps = min(s0 + p.spb, p.total) - s0;
   if (nsteps <= 0) return;  // whole workgroup
 
-  // staging slots: x tile 32 rows x 8 chunks (1 per thread; rows >= M repeat row M-1), W tile 128 x 8 (4 per thread)
-  uint32_t a_off, w_off[4];
-  {
-    const int row = tid >> 3, ch = (tid & 7) ^ (row & 7);
-    a_off = (uint32_t)min(row, p.M - 1) * (uint32_t)(p.lda * EB) + ch * 16;
+  // staging slots: x tile 32 (MB = 4: 64) rows x 8 chunks (1 or 2 per thread; rows >= M repeat row M-1), W tile 128 x 8
+  // (4 per thread)
+  constexpr int XI = (MB == 4) ? 2 : 1;                 // x LDS-DMA instructions per thread per stage
+  constexpr int DEPTH = (MB == 4) ? GEMM3W_DEPTH : GEMM3_DEPTH;
+  constexpr int STAGE_BYTES = (MB == 4) ? GEMM3W_STAGE_BYTES : GEMM3_STAGE_BYTES;
+  uint32_t a_off[XI], w_off[4];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int row = i * 32 + (tid >> 3), ch = (tid & 7) ^ (row & 7);
+    a_off[i] = (uint32_t)min(row, p.M - 1) * (uint32_t)(p.lda * EB) + ch * 16;
   }
   int p_tile = s0 / p.nk_all, p_kt = s0 - p_tile * p.nk_all;  // producer cursor
   const char* a_ptr;
@@ -827,12 +846,14 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
   };
   enter_tile(p_tile, p_kt);
   const int wave_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
-  constexpr int A_BYTES = GEMM3_BM * GEMM_BK * 2;  // 4 KiB
+  constexpr int A_BYTES = XI * GEMM3_BM * GEMM_BK * 2;  // 4 KiB (MB = 4: 8 KiB)
 
   auto stage = [&](int slot) {  // next step of this workgroup's range -> ring slot
-    char* base = lds3 + slot * GEMM3_STAGE_BYTES + wave_base;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr + a_off),
-                                     (__attribute__((address_space(3))) void*)(base), 16, 0, 0);
+    char* base = lds3 + slot * STAGE_BYTES + wave_base;
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_ptr + a_off[i]),
+                                       (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_ptr + w_off[i]),
@@ -858,17 +879,18 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
   const int w_rd = A_BYTES + wn * 32 * 128;
 
   int c_tile = s0 / p.nk_all, c_kt = s0 - c_tile * p.nk_all;  // consumer cursor
-  const int pre = min(GEMM3_DEPTH - 1, nsteps);
+  const int pre = min(DEPTH - 1, nsteps);
   for (int s = 0; s < pre; ++s) stage(s);
-  int slot = 0, fill = pre % GEMM3_DEPTH;  // slot consumed this step / slot refilled this step
+  int slot = 0, fill = pre % DEPTH;  // slot consumed this step / slot refilled this step
   for (int st = 0; st < nsteps; ++st) {
-    gemm3_wait_stages(min(GEMM3_DEPTH - 2, nsteps - 1 - st));
+    if constexpr (MB == 4) gemm3w_wait_stages(min(DEPTH - 2, nsteps - 1 - st));
+    else gemm3_wait_stages(min(DEPTH - 2, nsteps - 1 - st));
     __builtin_amdgcn_s_barrier();  // stage st visible to all waves; every wave is past compute(st-1)
-    if (st + GEMM3_DEPTH - 1 < nsteps) {
+    if (st + DEPTH - 1 < nsteps) {
       stage(fill);
-      fill = (fill + 1 == GEMM3_DEPTH) ? 0 : fill + 1;
+      fill = (fill + 1 == DEPTH) ? 0 : fill + 1;
     }
-    const char* base = lds3 + slot * GEMM3_STAGE_BYTES;
+    const char* base = lds3 + slot * STAGE_BYTES;
     if constexpr (FP8) {
       // lane holds row l15, k = 32 h .. 32 h + 31: 16-byte chunks 2h and 2h+1 at their swizzled positions
       typedef int i32x8 __attribute__((ext_vector_type(8)));
@@ -909,7 +931,7 @@ __global__ __launch_bounds__(256, 1) void gemm_decode_stream_kernel(DecGemmArgs 
           acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][1], a1[mb], acc[mb][j], 0, 0, 0);
         }
     }
-    slot = (slot + 1 == GEMM3_DEPTH) ? 0 : slot + 1;
+    slot = (slot + 1 == DEPTH) ? 0 : slot + 1;
 
     const bool tile_done = (++c_kt == p.nk_all);
     if (tile_done || st + 1 == nsteps) {
@@ -991,12 +1013,12 @@ static void gemm3_geometry(int N, int K, bool direct, int* spb, int* nslots, int
 }
 
 // Batched-decode projection, first half: part[slot][16][N] (f32, `ksplit` slots, all written) with
-// sum_slot part = x[B,K] * W[N,K]^T, or with part == NULL a direct C (bf16, or f32 when out_f32).  B <= 32; a slot's
-// slab has 16 rows for B <= 16 and 32 rows for B > 16 (vis_skinny_finalize applies the same rule).
+// sum_slot part = x[B,K] * W[N,K]^T, or with part == NULL a direct C (bf16, or f32 when out_f32).  B <= 64; a slot's
+// slab has 16 rows for B <= 16, 32 rows for B <= 32 and 64 rows beyond (vis_skinny_finalize applies the same rule).
 // ksplit <= 0 means vis_gemm_decode_ksplit(N, K); a larger value only adds zero-filled slots.
 extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, void* C, int B, int N, int K, int lda,
                                     int ldw, int ldc, int ksplit, int out_f32, hipStream_t stream) {
-  if (!A || !W || (!part && !C) || B <= 0 || B > 32 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (!A || !W || (!part && !C) || B <= 0 || B > 64 || N <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % GEMM_BK != 0 || N % 4 != 0 || lda % 8 != 0 || ldw % 8 != 0 || (C && ldc % 4 != 0)) return VIS_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)part | (uintptr_t)C) & 15) return VIS_ERR_ARG;
   int spb, need, nwg;
@@ -1011,7 +1033,9 @@ extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, vo
     return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                GEMM3_LDS_BYTES) == hipSuccess &&
            hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               GEMM3_LDS_BYTES) == hipSuccess;
+                               GEMM3_LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM3W_LDS_BYTES) == hipSuccess;
   }();
   if (!attr3_ok) return VIS_ERR_LAUNCH;
   DecGemmArgs p;
@@ -1021,12 +1045,13 @@ extern "C" int vis_gemm_decode_bf16(const void* A, const void* W, void* part, vo
   p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
   p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32; p.sx = nullptr; p.sw = nullptr;
   vis_clear_error();
-  if (B > 16) hipLaunchKernelGGL((gemm_decode_stream_kernel<false, 2>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  if (B > 32) hipLaunchKernelGGL((gemm_decode_stream_kernel<false, 4>), dim3(nwg), dim3(256), GEMM3W_LDS_BYTES, stream, p);
+  else if (B > 16) hipLaunchKernelGGL((gemm_decode_stream_kernel<false, 2>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   else hipLaunchKernelGGL((gemm_decode_stream_kernel<false, 1>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   return vis_check_launch();
 }
 
-// number of partial slots vis_gemm_decode_bf16 writes for (N, K): size part as slots x (B <= 16 ? 16 : 32) x N floats
+// number of partial slots vis_gemm_decode_bf16 writes for (N, K): size part as slots x (B <= 16 ? 16 : B <= 32 ? 32 : 64) x N floats
 extern "C" int vis_gemm_decode_ksplit(int N, int K) {
   if (N <= 0 || K < GEMM_BK) return 0;
   int spb, slots, nwg;
@@ -1040,7 +1065,7 @@ extern "C" int vis_gemm_decode_ksplit(int N, int K) {
 extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* Wq, const void* sw, void* part, void* C,
                                    int B, int N, int K, int ldx, int ldw, int ldc, int ksplit, int out_f32,
                                    hipStream_t stream) {
-  if (!xq || !Wq || (!part && !C) || B <= 0 || B > 32 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (!xq || !Wq || (!part && !C) || B <= 0 || B > 64 || N <= 0 || K <= 0) return VIS_ERR_ARG;
   if (K % 128 != 0 || N % 4 != 0 || ldx % 16 != 0 || ldw % 16 != 0 || ldx < K || ldw < K || (C && ldc % 4 != 0))
     return VIS_ERR_ARG;
   if (!part && (!sx || !sw)) return VIS_ERR_ARG;
@@ -1057,7 +1082,9 @@ extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* W
     return hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                GEMM3_LDS_BYTES) == hipSuccess &&
            hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               GEMM3_LDS_BYTES) == hipSuccess;
+                               GEMM3_LDS_BYTES) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemm_decode_stream_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               GEMM3W_LDS_BYTES) == hipSuccess;
   }();
   if (!attr_ok) return VIS_ERR_LAUNCH;
   DecGemmArgs p;
@@ -1067,7 +1094,8 @@ extern "C" int vis_gemm_decode_fp8(const void* xq, const void* sx, const void* W
   p.total = ((N + GEMM_BN - 1) / GEMM_BN) * p.nk_all;
   p.spb = spb; p.nslots = ksplit; p.out_f32 = out_f32; p.sx = (const float*)sx; p.sw = (const float*)sw;
   vis_clear_error();
-  if (B > 16) hipLaunchKernelGGL((gemm_decode_stream_kernel<true, 2>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
+  if (B > 32) hipLaunchKernelGGL((gemm_decode_stream_kernel<true, 4>), dim3(nwg), dim3(256), GEMM3W_LDS_BYTES, stream, p);
+  else if (B > 16) hipLaunchKernelGGL((gemm_decode_stream_kernel<true, 2>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   else hipLaunchKernelGGL((gemm_decode_stream_kernel<true, 1>), dim3(nwg), dim3(256), GEMM3_LDS_BYTES, stream, p);
   return vis_check_launch();
 }

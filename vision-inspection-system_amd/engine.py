@@ -127,8 +127,8 @@ class Qwen2VLEngine:
         self.lock = threading.Lock()
         dev, bf = self.device, torch.bfloat16
         L, Hkv, Hq, D, H = cfg.layers, cfg.kv_heads, cfg.heads, cfg.head_dim, cfg.hidden
-        if not 1 <= max_batch <= 32:
-            raise ValueError("max_batch must be in 1..32 (one or two 16-row MFMA blocks of in-flight sequences)")
+        if not 1 <= max_batch <= 64:
+            raise ValueError("max_batch must be in 1..64 (one, two or four 16-row MFMA blocks of in-flight sequences)")
         Bm = self.max_batch = max_batch
         # per-sequence ("slot") state; slot 0 doubles as the single-sequence engine
         self.kcache_b = torch.zeros((Bm, L, Hkv, self.max_ctx, D), dtype=bf, device=dev)

@@ -441,8 +441,8 @@ def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tok
 
 
 def part_rows(B: int) -> int:
-    """Rows of one partial slab of the batched-decode projection: 16 for up to 16 sequences, 32 for up to 32."""
-    return 16 if B <= 16 else 32
+    """Rows of one partial slab of the batched-decode projection: 16 / 32 / 64 for up to 16 / 32 / 64 sequences."""
+    return 16 if B <= 16 else 32 if B <= 32 else 64
 
 
 def decode_gemm(x: torch.Tensor, w: torch.Tensor, part: Optional[torch.Tensor] = None,
