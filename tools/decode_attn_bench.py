@@ -8,7 +8,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 ctx = int(sys.argv[2]) if len(sys.argv) > 2 else 2300
 dev = torch.device("cuda:0")
 hip.load()
-Hq, Hkv, HD, T = 28, 4, 128, 4096
+Hq, Hkv, HD, T = 28, 4, 128, (int(sys.argv[3]) if len(sys.argv) > 3 else 4096)
 g = torch.Generator(device="cpu").manual_seed(0)
 kc = torch.randn((B, Hkv, T, HD), generator=g).to(torch.bfloat16).to(dev)
 vc = torch.randn((B, Hkv, T, HD), generator=g).to(torch.bfloat16).to(dev)
