@@ -9,16 +9,27 @@ offline), so timing is valid and the generated text is noise.
 
     python bench.py --gpus N --steps K --warmup W
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): whole images are sharded across
-ranks (weak scaling: every rank inspects its own image stream), each step ends with one RCCL all_gather
-of the per-image result records, and the reported time is the max over ranks.
+N > 1: one rank per GPU over RCCL.  Either the caller starts the ranks (``python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N``: RANK / WORLD_SIZE are then in the environment) or - when
+WORLD_SIZE is unset - this script starts them ITSELF before it has touched the GPU (a child
+``torch.distributed.run`` process; the parent only relays rank 0's JSON line and the exit status).  Whole
+images are sharded across ranks (weak scaling: every rank inspects its own image stream), each step ends with
+one RCCL all_gather of the per-image result records, and the reported time is the max over ranks.
+``--backend gloo --dry-device cpu`` runs the same launcher / rendezvous / gather / max-over-ranks plumbing
+with NO model (records only) - the CPU rehearsal of the N > 1 path used by tests/test_bench_launcher.py.
 
 The single JSON line also carries
   roofline     - the dominant kernel (decode weight-streaming GEMV, HBM-bound): algorithmic bytes per
                  launch / average launch duration, measured live with HIP events;
   prefill_mfma - prefill FLOPs / prefill time against the dense bf16 MFMA peak (BASELINE.md section 3);
   cpu_baseline - the oracle (CPU port of the same arithmetic) timed on this host's cores on a bounded
-                 sample of the same workload.
+                 sample of the same workload;
+  microbench   - measured peak-GEMM and stream-copy figures of THIS box with the
+                 fractions of the prefill / decode rates against them;
+  e2e          - what one ``chat.completions.create`` costs on the same 1024x1024 JPEG (data-URI decode, GPU
+                 resize, tokenise, prefill, decode, detokenise) next to the kernel-only step;
+  plumbing     - BASELINE configs[0]: run_multi_image_inspection with a canned-response client on 448x448
+                 frames (host logic only, no GPU), images/s.
 """
 import argparse
 import io
@@ -214,6 +225,255 @@ def cpu_baseline(cfg, n_patches: int, S: int, new_tokens: int):
                        f"= {t_img:.1f}s. The reference has no CPU arithmetic path (remote API).")}
 
 
+def measure_decode_gemm(engine, B: int, reps: int = 5):
+    """Batched decode (--batch B): average duration of one gemm_decode_stream_kernel launch - the 113 weight-streaming
+    projections of one step for B sequences, same weights and buffers as the real step, captured alone into a
+    hipGraph and replayed between two HIP events (the finalisation / attention / sampling kernels are left out)."""
+    from vision_inspection_system_amd import hip
+    cfg, w = engine.cfg, engine.w
+    fp8 = engine.decode_weights == "fp8" and engine.fp8_batched
+    n = [0]
+
+    def projections():
+        xn, xn2, att, act, part = engine.b_xn[:B], engine.b_xn2[:B], engine.b_attn[:B], engine.b_act[:B], engine.b_part
+        if fp8:
+            xq, x2q, aq = engine.b_xq[:B], engine.b_x2q[:B], engine.b_actq[:B]
+            s0, s1, s2 = engine.b_sx[0, :B], engine.b_sx[1, :B], engine.b_sx[2, :B]
+            for lw, q8 in zip(w.llm, engine.q8):
+                hip.decode_gemm_fp8(xq, s0, *q8["qkv_w"], part=part)
+                hip.decode_gemm(att, lw.o_w, part=part)
+                hip.decode_gemm_fp8(x2q, s1, *q8["gateup_w"], part=part)
+                hip.decode_gemm_fp8(aq, s2, *q8.get("down_w_pad", q8["down_w"]), part=part)
+                n[0] += 4
+            hip.decode_gemm_fp8(xq, s0, *engine.q8_lm_head, out=engine.logits_b[:B])
+        else:
+            for lw in w.llm:
+                hip.decode_gemm(xn, lw.qkv_w, part=part)
+                hip.decode_gemm(att, lw.o_w, part=part)
+                hip.decode_gemm(xn2, lw.gateup_w, part=part)
+                hip.decode_gemm(act, lw.down_w, part=part)
+                n[0] += 4
+            hip.decode_gemm(xn, w.lm_head, out=engine.logits_b[:B])
+        n[0] += 1
+
+    side = torch.cuda.Stream(device=engine.device)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        projections()
+    torch.cuda.current_stream().wait_stream(side)
+    launches = n[0]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        projections()
+    g.replay()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e-3 / reps / launches, launches
+
+
+def microbench(dev):
+    """What THIS box delivers, next to the spec-sheet peaks the roofline fractions are quoted against (BASELINE.md
+    section 3): a dense bf16 GEMM at 8192^3 on N(0,1) operands - the vendor library through torch.matmul (hipBLASLt;
+    an independent yardstick, not on the product path) and this repository's own tile kernel - and a 1 GiB
+    device-to-device stream copy (read + write bytes)."""
+    from vision_inspection_system_amd import hip
+    out = {}
+    n = 8192
+    a = torch.randn((n, n), dtype=torch.bfloat16, device=dev)
+    b = torch.randn((n, n), dtype=torch.bfloat16, device=dev)
+    c = torch.empty((n, n), dtype=torch.bfloat16, device=dev)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(reps):
+            fn()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) * 1e-3 / reps
+
+    flops = 2.0 * n ** 3
+    try:
+        t = timed(lambda: torch.matmul(a, b.t(), out=c), 10)
+        out["gemm_bf16_8192_library_TFLOPs"] = flops / t / 1e12
+    except Exception as ex:     # the yardstick must never take the benchmark down
+        out["gemm_bf16_8192_library_TFLOPs"] = None
+        out["library_error"] = str(ex)[:120]
+    t = timed(lambda: hip.gemm(a, b, out=c), 10)
+    out["gemm_bf16_8192_own_kernel_TFLOPs"] = flops / t / 1e12
+    del a, b, c
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    src.fill_(1)
+    t = timed(lambda: dst.copy_(src), 10)
+    out["stream_copy_GBps"] = 2.0 * (1 << 30) / t / 1e9
+    out["note"] = "8192^3 bf16 on N(0,1) operands; copy = 1 GiB device-to-device, read + write bytes"
+    return out
+
+
+def e2e_request(engine, cfg, image_size: int, prompt_tokens: int, new: int, reps: int = 3):
+    """One ``LocalVLMClient.chat.completions.create`` on the same synthetic frame, the way an agent calls it: a
+    base64 JPEG data URI (a3's output) + a text part -> decode JPEG (host libjpeg), upload, GPU bicubic resize,
+    tokenise, prefill, ``new`` decode steps (EOS ignored so that the work equals the kernel-only step), detokenise."""
+    import base64
+    from PIL import Image
+    from vision_inspection_system_amd import client as CL
+    from vision_inspection_system_amd.tokenizer import ByteTokenizer
+    rng = np.random.default_rng(1234)
+    img = Image.fromarray(rng.integers(0, 256, (image_size, image_size, 3), dtype=np.uint8))
+    buf = io.BytesIO()
+    img.save(buf, format="JPEG", quality=85, optimize=True)
+    uri = "data:image/jpeg;base64," + base64.b64encode(buf.getvalue()).decode()
+    tok = ByteTokenizer(cfg.vocab, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
+    model_id = "synthetic:bench-engine"
+    CL.register_model(model_id, str(engine.device), CL.LoadedModel(engine, tok, cfg, model_id))
+    text = ("inspect this part for defects and answer in JSON. " * 64)[:max(16, prompt_tokens - 64)]  # 1 byte = 1 token
+    messages = [{"role": "user", "content": [{"type": "text", "text": text},
+                                             {"type": "image_url", "image_url": {"url": uri}}]}]
+    cl = CL.LocalVLMClient(device=str(engine.device))
+    os.environ["VIS_IGNORE_EOS"] = "1"
+    try:
+        times, usage = [], None
+        for i in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = cl.chat.completions.create(model=model_id, messages=messages, temperature=0.0, max_tokens=new)
+            torch.cuda.synchronize()
+            if i:
+                times.append(time.perf_counter() - t0)
+            usage = r.usage
+    finally:
+        os.environ.pop("VIS_IGNORE_EOS", None)
+        CL.unregister_model(model_id, str(engine.device))
+    t = sum(times) / len(times)
+    return {"ms": t * 1e3, "images_per_s": 1.0 / t, "jpeg_bytes": len(buf.getvalue()),
+            "prompt_tokens": usage["prompt_tokens"], "completion_tokens": usage["completion_tokens"],
+            "what": "LocalVLMClient.chat.completions.create: base64 JPEG decode (host) + H2D + GPU bicubic resize + "
+                    "tokenise + prefill + decode + detokenise, one request at a time"}
+
+
+GOOD_REPLY = ('```json\n{"object_identified": "steel bracket", "overall_condition": "damaged", "defects": [{"type": '
+              '"crack", "location": "upper left weld seam", "bbox": {"x": 12.5, "y": 20.0, "width": 18.0, "height": 9.5},'
+              ' "safety_impact": "CRITICAL", "reasoning": "a dark linear discontinuity crosses the weld bead", '
+              '"confidence": "high", "recommended_action": "replace"}], "overall_confidence": "high", '
+              '"analysis_reasoning": "one clear crack at the weld"}\n```')
+
+
+def plumbing_baseline(n_images: int = 24, size: int = 448):
+    """BASELINE configs[0] / SURVEY section 8(d)(i): the host side of the path with NO model - the counterpart of
+    run_multi_image_inspection (src/orchestration/graph.py:269-387) driven by a canned-response client: PNG open ->
+    thumbnail/JPEG q85/base64 (a3) x 2 agents -> parse (a6) -> validate (a7) -> pydantic (a8) -> consensus -> gates ->
+    aggregate, on seeded uniform-random frames; one process, images/s."""
+    import tempfile
+    from PIL import Image
+    from vision_inspection_system_amd import client as CL, config as C
+    from vision_inspection_system_amd.batch import run_multi_image_inspection
+    old = C.get_config()
+    CL.set_mock_reply(GOOD_REPLY)
+    C.set_config(C.Config(vlm_inspector_provider="mock", vlm_auditor_provider="mock"))
+    try:
+        with tempfile.TemporaryDirectory() as d:
+            paths = []
+            for i in range(n_images):
+                rng = np.random.default_rng(1234 + i)
+                path = os.path.join(d, f"frame{i:03d}.png")
+                Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(path)
+                paths.append(path)
+            run_multi_image_inspection(paths[:2])
+            t0 = time.perf_counter()
+            out = run_multi_image_inspection(paths, criticality="medium", domain="general")
+            t = time.perf_counter() - t0
+        done = out["session_results"]["completed_images"]
+    finally:
+        CL.set_mock_reply(None)
+        C.set_config(old)
+    return {"value": n_images / t, "unit": "images/s", "images": n_images, "completed": done, "image_px": size,
+            "cores": 1, "host_cpus": os.cpu_count(),
+            "what": "configs[0]: run_multi_image_inspection, canned-response client, no model, no GPU (host logic only)"}
+
+
+def free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher around it: start N ranks as ONE child process group
+    (torch.distributed.run, 127.0.0.1 rendezvous) and relay their output.  Called before this process has made any
+    GPU call - nothing here touches torch.cuda, and the GPU work happens only in the children, so no process that
+    has initialised the GPU is ever replaced.  Returns the exit status (non-zero if any rank failed or rank 0 printed
+    no JSON line)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    got_json = False
+    for line in proc.stdout:
+        if line.startswith("{") and '"metric"' in line:
+            got_json = True
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and not got_json:
+        print("bench.py: the ranks exited cleanly but rank 0 printed no result line", file=sys.stderr)
+        return 1
+    return rc
+
+
+def run_dry(args, rank: int, world: int) -> None:
+    """CPU rehearsal of the N > 1 plumbing: rendezvous, per-step record exchange, barriers, max over ranks, rank 0's
+    JSON line - with synthetic token records instead of a model.  The figure it prints measures nothing."""
+    import torch.distributed as dist
+    from vision_inspection_system_amd.batch import gather_records
+    if world > 1:
+        dist.init_process_group(args.backend)
+    rng = np.random.default_rng(rank)
+
+    def one_step():
+        toks = rng.integers(0, 1000, args.new_tokens).tolist()
+        rec = gather_records([{"image": f"synthetic_{rank}_{b}", "tokens": toks} for b in range(args.batch)], world)
+        if len(rec) != world * args.batch:
+            raise RuntimeError(f"rank {rank}: gathered {len(rec)} records, expected {world * args.batch}")
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (no model): record exchange only", "value": world * args.steps * args.batch / elapsed,
+                          "unit": "records/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic", "dry": True,
+                          "config": {"workload": "launcher / gather rehearsal on CPU", "backend": args.backend,
+                                     "parallelism": f"dp{world}"}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,7 +484,12 @@ def main():
     ap.add_argument("--prompt-tokens", type=int, default=1024)
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the microbench / e2e / plumbing blocks")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the product path) or gloo (CPU rehearsal, with --dry-device cpu)")
+    ap.add_argument("--dry-device", default=None, choices=["cpu"],
+                    help="cpu: no model, no GPU - exercise launcher, rendezvous, record gather and timing only")
     ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] slice (e4m3 weights for the single-sequence decode GEMVs) - NOT the "
                          "headline precision; the JSON says so in dtype/config")
@@ -238,16 +503,25 @@ def main():
                          "batch inspection) - NOT the headline single-image configuration")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # nobody launched ranks for us: do it here, BEFORE any GPU call (see launch_ranks)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_device == "cpu":
+        return run_dry(args, rank, world)
+    if args.backend != "nccl":
+        raise SystemExit("bench.py: --backend gloo is only for --dry-device cpu; the product path is RCCL")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        from datetime import timedelta
+        dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=900))  # nccl == RCCL on ROCm
 
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
@@ -267,6 +541,7 @@ def main():
     frame = torch.from_numpy(frame_np).to(dev)
     ids_dev = torch.tensor(ids, dtype=torch.int32, device=dev)
     new = args.new_tokens
+    B = args.batch
 
     pre_ev, step_records = [], []
 
@@ -274,7 +549,6 @@ def main():
         s = torch.cuda.Event(enable_timing=True)
         m = torch.cuda.Event(enable_timing=True)
         e = torch.cuda.Event(enable_timing=True)
-        B = args.batch
         s.record()
         engine.prefill_many([(ids, [frame])] * B, max_new_tokens=new, ids_dev=[ids_dev] * B)
         m.record()
@@ -292,7 +566,7 @@ def main():
             step_records.append(len(rec))
 
     def one_step(timed: bool):
-        if args.batch > 1:
+        if B > 1:
             return one_step_batched(timed)
         s = torch.cuda.Event(enable_timing=True)
         m = torch.cuda.Event(enable_timing=True)
@@ -326,48 +600,71 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        t_pre = sum(s.elapsed_time(m) for s, m, e in pre_ev) / len(pre_ev) * 1e-3
+        if any(n != world * B for n in step_records):
+            raise SystemExit(f"bench.py: a step gathered {step_records} records, expected {world * B} each")
+        t_pre = sum(s.elapsed_time(m) for s, m, e in pre_ev) / len(pre_ev) * 1e-3      # all B prompt passes of a step
         t_dec = sum(m.elapsed_time(e) for s, m, e in pre_ev) / len(pre_ev) * 1e-3
-        gemv_avg, gemv_launches = measure_gemv(engine)
         fp8 = args.decode_weights == "fp8"
         p8 = args.prefill_dtype == "fp8"
+        if B > 1:
+            k_avg, k_launches = measure_decode_gemm(engine, B)
+            kernel = "gemm_decode_stream_kernel" + ("<fp8>" if fp8 and engine.fp8_batched else "") + \
+                f" (batched decode projection, weights streamed once for {B} sequences)"
+        else:
+            k_avg, k_launches = measure_gemv(engine)
+            kernel = ("gemv_fp8w_kernel" if fp8 else "gemv_bf16_kernel") + " (decode weight streaming)"
         step_bytes = gemv_bytes_per_step(cfg) / (2 if fp8 else 1)
-        bytes_per_launch = step_bytes / gemv_launches
-        achieved = bytes_per_launch / gemv_avg / 1e9
-        flops = prefill_flops(cfg, n_patches, S)
+        if B > 1 and fp8 and engine.fp8_batched:      # the o projection stays bf16 in the batched fp8 step
+            step_bytes += cfg.layers * cfg.heads * cfg.head_dim * cfg.hidden
+        bytes_per_launch = step_bytes / k_launches
+        achieved = bytes_per_launch / k_avg / 1e9
+        flops = prefill_flops(cfg, n_patches, S) * B          # B full prompt passes' worth of arithmetic per step
         out = {
             "metric": "inspected images/sec (1024x1024, Qwen2-VL-7B)" if args.model == "7b" else "images/sec (tiny)",
-            "value": world * args.steps * args.batch / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "value": world * args.steps * B / elapsed, "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if not (fp8 or p8) else
             f"{'fp8-e4m3 (LLM projections)' if p8 else 'bf16'} prefill / {'fp8-e4m3' if fp8 else 'bf16'} decode weights",
             "data": "synthetic",
             "config": {"workload": (f"configs[1]: Qwen2-VL-7B Inspector bf16, single {args.image_size}x"
                                     f"{args.image_size} image per step per GPU, greedy decode {new} tok")
-                       if args.batch == 1 and not (fp8 or p8) else
+                       if B == 1 and not (fp8 or p8) else
                        (f"configs[4] (NOT the headline precision): Qwen2-VL-7B, {'fp8 MFMA' if p8 else 'bf16'} LLM prefill, "
                         f"{'fp8-e4m3' if fp8 else 'bf16'} weights in the decode GEMVs, single {args.image_size}x"
                         f"{args.image_size} image, greedy decode {new} tok")
-                       if args.batch == 1 else
-                       (f"batch inspection: {args.batch} x {args.image_size}x{args.image_size} images per step per GPU, "
+                       if B == 1 else
+                       (f"batch inspection: {B} x {args.image_size}x{args.image_size} images per step per GPU, "
                         f"per-image prefill + batched decode {new} tok (NOT the headline configuration)"
                         + ("; text part first as in the reference: the shared text prefix is computed once per batch"
                            if args.prompt_order == "text-first" else "")),
-                       "batch": args.batch,
+                       "batch": B,
                        "image_px": args.image_size, "resized_px": list(frame_np.shape[:2]),
                        "image_tokens": n_img_tok, "prompt_tokens": S, "new_tokens": new,
                        "weights": "seeded random bf16 at exact 7B shapes", "parallelism": f"dp{world} (whole images)"},
-            "roofline": {"bound": "hbm", "kernel": ("gemv_fp8w_kernel" if fp8 else "gemv_bf16_kernel") +
-                         " (decode weight streaming)",
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if fp8 else measured_traffic(), "bytes_per_launch": bytes_per_launch, "avg_launch_us": gemv_avg * 1e6,
-                         "launches_per_token": gemv_launches},
-            "prefill_mfma": {"flops": flops, "ms": t_pre * 1e3, "achieved": flops / t_pre / 1e12,
-                             "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t_pre / 1e12 / MFMA_BF16_PEAK_TF},
+                         "traffic": None if (fp8 or B > 1) else measured_traffic(), "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": k_avg * 1e6, "launches_per_token": k_launches},
+            "prefill_mfma": {"flops": flops, "ms": t_pre * 1e3, "images": B, "achieved": flops / t_pre / 1e12,
+                             "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t_pre / 1e12 / MFMA_BF16_PEAK_TF,
+                             "note": ("FLOPs of B full prompt passes / time of the B prompt passes of a step; with a "
+                                      "shared text prefix less arithmetic is actually executed, so this is an "
+                                      "effective rate") if B > 1 else "one prompt pass"},
             "decode": {"ms": t_dec * 1e3, "ms_per_token": t_dec / (new - 1) * 1e3,
                        "weight_GBps": step_bytes * (new - 1) / t_dec / 1e9,
-                       "sequences_per_step": args.batch},
+                       "sequences_per_step": B},
         }
+        extras = not args.no_extras and args.model == "7b" and world == 1
+        if extras:
+            mb = microbench(dev)
+            best = max(v for k, v in mb.items() if k.startswith("gemm_") and v)
+            mb["prefill_frac_of_measured_gemm"] = out["prefill_mfma"]["achieved"] / best
+            mb["roofline_frac_of_measured_copy"] = achieved / mb["stream_copy_GBps"]
+            out["microbench"] = mb
+            if B == 1 and not (fp8 or p8):
+                out["e2e"] = e2e_request(engine, cfg, args.image_size, args.prompt_tokens, new)
+                out["e2e"]["kernel_only_ms"] = elapsed / args.steps * 1e3
+            out["plumbing"] = plumbing_baseline()
         if not args.no_cpu_baseline and args.model == "7b" and world == 1:     # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(cfg, n_patches, S, new)
         print(json.dumps(out), flush=True)

@@ -230,3 +230,30 @@ def test_chat_layout_and_tokenizer():
     assert tok.decode(list(b"ok") + [503]) == "ok"
     with pytest.raises(ValueError):
         build_chat_ids(tok, msgs, [])
+
+
+def test_unsupported_model_type_is_refused_up_front(tmp_path):
+    """The reference's code default is Qwen/Qwen2.5-VL-7B-Instruct (utils/config.py:42-45); a local directory of a
+    family the engines do not implement must fail with a clear message, not a KeyError inside a weight loader."""
+    from vision_inspection_system_amd import client
+    d = tmp_path / "some-model"
+    d.mkdir()
+    (d / "config.json").write_text(json.dumps({"model_type": "llava_next", "text_config": {}}))
+    with pytest.raises(ValueError, match="model_type 'llava_next'"):
+        client.get_model(str(d), device="cuda:0")
+    (d / "config.json").unlink()
+    with pytest.raises(FileNotFoundError, match="config.json"):
+        client.get_model(str(d), device="cuda:0")
+    with pytest.raises(FileNotFoundError, match="not a local directory"):
+        client.get_model("Qwen/Qwen2.5-VL-7B-Instruct", device="cuda:0")
+
+
+def test_plumbing_baseline_runs_without_gpu():
+    """BASELINE configs[0]: the canned-client batch run bench.py reports as ``plumbing``."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out = bench.plumbing_baseline(n_images=4, size=64)
+    assert out["images"] == 4 and out["completed"] == 4 and out["value"] > 0 and out["unit"] == "images/s"

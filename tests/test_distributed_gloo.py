@@ -61,3 +61,61 @@ def test_two_rank_batch(tmp_path):
     assert sr["total_images"] == 5 and sr["completed_images"] == 4 and sr["failed_images"] == 1
     assert sr["aggregate_verdict"] == "SAFE" and sr["cosmetic_defects"] == 4
     assert res[list(res)[2]]["error"] == "decode error"
+
+
+def _worker_failure(rank, world, port, paths, outdir, mode):
+    """mode 'dead': the last rank exits before the exchange; 'late': it arrives after the others gave up."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      VIS_RANK_TIMEOUT_S="2")
+    import time
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vision_inspection_system_amd import config as C
+    from vision_inspection_system_amd.batch import run_multi_image_inspection
+    C.set_config(C.Config(vlm_inspector_provider="mock", vlm_auditor_provider="mock"))
+    if rank == world - 1:
+        if mode == "dead":
+            os._exit(0)
+
+    def fake_inspect(image_path, criticality, domain, user_notes):
+        if rank == world - 1 and mode == "late":
+            time.sleep(1.2)          # 3 images x 1.2 s > the 2 s the others wait
+        return {"inspector_result": {"who": rank}, "auditor_result": {}, "safety_verdict": {"verdict": "SAFE"},
+                "consensus": {"combined_defects": []}, "processing_time": 0.01}
+    t0 = time.monotonic()
+    out = run_multi_image_inspection(paths, session_id="sess", _inspect=fake_inspect)
+    out["_elapsed"] = time.monotonic() - t0
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump(out, f, default=str)
+    # no barrier / destroy: the default group is unusable once a rank is gone, which is the point of the test
+    if mode == "late" and rank == 0:     # rank 0 hosts the rendezvous store: stay until the late rank has read it
+        for _ in range(200):
+            if os.path.exists(os.path.join(outdir, f"rank{world - 1}.json")):
+                break
+            time.sleep(0.1)
+    os._exit(0)
+
+
+@pytest.mark.parametrize("mode", ["dead", "late"])
+def test_rank_failure_is_a_result_not_a_hang(tmp_path, mode):
+    """SURVEY section 5 / graph.py:349-357: a rank that dies (or hangs past VIS_RANK_TIMEOUT_S) turns into
+    completed=False records for ITS images on every surviving rank; nobody blocks in a collective."""
+    world = 3
+    paths = [str(tmp_path / f"img{i}.png") for i in range(8)]
+    port = _free_port()
+    mp.spawn(_worker_failure, args=(world, port, paths, str(tmp_path), mode), nprocs=world, join=True)
+    outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world) if (tmp_path / f"rank{r}.json").exists()]
+    assert len(outs) == (2 if mode == "dead" else 3)
+    for o in outs[:2]:
+        assert o["_elapsed"] < 15
+        res = o["image_results"]
+        assert [v["image_path"] for v in res.values()] == paths
+        done = [v.get("completed") for v in res.values()]
+        assert done == [i % world != world - 1 for i in range(8)]
+        bad = [v for v in res.values() if not v["completed"]]
+        assert all("rank 2 did not report" in v["error"] for v in bad)
+        assert o["session_results"]["failed_images"] == len(bad) == 2
+    assert outs[0]["image_results"] == outs[1]["image_results"]
+    if mode == "late":       # the late rank sees the same verdict about itself
+        assert outs[2]["image_results"] == outs[0]["image_results"]

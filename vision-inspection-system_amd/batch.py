@@ -51,16 +51,29 @@ def _dist():
     return None
 
 
-def gather_records(records: List[dict], world: Optional[int] = None) -> List[dict]:
-    """All ranks contribute a list of JSON-serialisable records; every rank receives the concatenation in
-    rank order.  One length all_gather + one padded-bytes all_gather (RCCL when the group is nccl)."""
-    dist = _dist()
-    if dist is None or dist.get_world_size() == 1:
-        return list(records)
+class RankFailure(RuntimeError):
+    """Raised by nothing the caller sees: carried inside ``gather_records_ft``'s return value."""
+
+
+_GATHER_SEQ = [0]            # collectives are SPMD: every rank numbers its gathers the same way
+_DEAD_RANKS: set = set()     # once a rank missed a vote the default group is unusable: stay on the store path
+
+
+def rank_timeout_s() -> float:
+    """How long a rank that has finished its shard waits for the others before it declares them failed."""
+    return float(os.environ.get("VIS_RANK_TIMEOUT_S", "600"))
+
+
+def _default_store():
+    from torch.distributed import distributed_c10d as c10d
+    return c10d._get_default_store()
+
+
+def _all_gather_bytes(dist, payload: bytes) -> List[bytes]:
+    """The data-path collective: one length all_gather + one padded-bytes all_gather (RCCL when the group is nccl)."""
     import torch
     backend = dist.get_backend()
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    payload = json.dumps(records, default=str).encode("utf-8")
     W = dist.get_world_size()
     n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(W)]
@@ -72,11 +85,103 @@ def gather_records(records: List[dict], world: Optional[int] = None) -> List[dic
         buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
     outs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(W)]
     dist.all_gather(outs, buf)
+    return [bytes(o[:sz].cpu().numpy().tobytes()) for o, sz in zip(outs, sizes)]
+
+
+def gather_records_ft(records: List[dict], timeout_s: Optional[float] = None) -> tuple:
+    """Fault-tolerant form of the exchange: returns ``(merged records in rank order, sorted list of ranks that did
+    not report)``.
+
+    A dead or hung rank must never leave the others blocked inside a collective (a rank failure
+    surfaces as failed images, never as a crashed or frozen batch; the reference's per-image try/except at
+    src/orchestration/graph.py:349-357 is the single-process form of that rule).  So the collective is preceded by a
+    vote through the rendezvous store torch.distributed already runs:
+      1. every rank that reaches the exchange sets ``ready/<rank>``;
+      2. rank 0 waits for each key up to ``timeout_s`` (VIS_RANK_TIMEOUT_S, default 600) and publishes the list of
+         ranks that reported; the others wait for that list;
+      3. all ranks reported -> the payload moves with ONE all_gather pair on the default group (RCCL over xGMI);
+         otherwise the survivors exchange their payloads through the store (KBs per image) and the default group is
+         not touched again in this process.
+    If the coordinator itself is unreachable a rank returns its own records and reports every other rank missing."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return list(records), []
+    from datetime import timedelta
+    W, rank = dist.get_world_size(), dist.get_rank()
+    T = rank_timeout_s() if timeout_s is None else float(timeout_s)
+    seq = _GATHER_SEQ[0]
+    _GATHER_SEQ[0] += 1
+    payload = json.dumps(records, default=str).encode("utf-8")
+    pre = f"vis/gather{seq}"
+    try:
+        store = _default_store()
+        store.set(f"{pre}/ready/{rank}", b"1")
+        if rank == 0:
+            alive, deadline = [0], time.monotonic() + T
+            for r in range(1, W):
+                if r in _DEAD_RANKS:
+                    continue
+                try:
+                    store.wait([f"{pre}/ready/{r}"], timedelta(seconds=max(0.05, deadline - time.monotonic())))
+                    alive.append(r)
+                except Exception:
+                    logger.error(f"rank {r} did not reach the result exchange within {T:.0f} s: its images are "
+                                 f"reported as failed")
+            store.set(f"{pre}/alive", json.dumps(alive).encode())
+        else:
+            store.wait([f"{pre}/alive"], timedelta(seconds=2 * T + 5))
+            alive = json.loads(bytes(store.get(f"{pre}/alive")).decode())
+        dead = sorted(set(range(W)) - set(alive))
+        if not dead and not _DEAD_RANKS:
+            blobs = _all_gather_bytes(dist, payload)
+        else:
+            _DEAD_RANKS.update(dead)
+            if rank in alive:
+                store.set(f"{pre}/payload/{rank}", payload)
+            blobs = []
+            for r in range(W):
+                if r not in alive:
+                    blobs.append(b"")
+                    continue
+                store.wait([f"{pre}/payload/{r}"], timedelta(seconds=T + 5))
+                blobs.append(bytes(store.get(f"{pre}/payload/{r}")))
+    except Exception as e:       # coordinator (rank 0 / the store) unreachable: report what this rank has
+        logger.error(f"result exchange failed on rank {rank} ({e}); returning this rank's records only", exc_info=True)
+        _DEAD_RANKS.update(r for r in range(W) if r != rank)
+        return list(records), [r for r in range(W) if r != rank]
     merged: List[dict] = []
-    for o, sz in zip(outs, sizes):
-        if sz:
-            merged.extend(json.loads(bytes(o[:sz].cpu().tolist()).decode("utf-8")))
-    return merged
+    for b in blobs:
+        if b:
+            merged.extend(json.loads(b.decode("utf-8")))
+    return merged, dead
+
+
+def gather_records(records: List[dict], world: Optional[int] = None) -> List[dict]:
+    """All ranks contribute a list of JSON-serialisable records; every rank receives the concatenation in
+    rank order (records of ranks that failed to report are simply absent: see ``gather_records_ft``)."""
+    return gather_records_ft(records)[0]
+
+
+def agree_on(value: str, name: str) -> str:
+    """Rank 0's ``value`` on every rank, through the rendezvous store (no collective: a rank that died before the
+    batch started must not block the others here either)."""
+    dist = _dist()
+    if dist is None or dist.get_world_size() == 1:
+        return value
+    from datetime import timedelta
+    seq = _GATHER_SEQ[0]
+    _GATHER_SEQ[0] += 1
+    key = f"vis/agree{seq}/{name}"
+    try:
+        store = _default_store()
+        if dist.get_rank() == 0:
+            store.set(key, value.encode())
+            return value
+        store.wait([key], timedelta(seconds=rank_timeout_s()))
+        return bytes(store.get(key)).decode()
+    except Exception as e:
+        logger.error(f"could not agree on {name} ({e}); keeping the local value")
+        return value
 
 
 # ----------------------------------------------------------------------------- single image
@@ -189,9 +294,7 @@ def run_multi_image_inspection(image_paths: List[str], criticality: str = "mediu
     if not session_id:
         session_id = str(uuid.uuid4())[:8]
     if world > 1:  # ids must agree across ranks: rank 0's choice wins
-        box = [session_id]
-        dist.broadcast_object_list(box, src=0)
-        session_id = box[0]
+        session_id = agree_on(session_id, "session_id")
 
     mine: List[dict] = []
     my_idx = list(range(rank, len(image_paths), world))
@@ -222,7 +325,15 @@ def run_multi_image_inspection(image_paths: List[str], criticality: str = "mediu
         rec["_rank"] = rank
         mine.append(rec)
 
-    records = gather_records(mine, world)
+    records, missing = gather_records_ft(mine)
+    for r in missing:      # a rank that died or hung: its images come back as failed, in place (graph.py:349-357)
+        for idx in range(r, len(image_paths), world):
+            image_path = image_paths[idx]
+            image_id = image_id_map[image_path] if image_id_map and image_path in image_id_map \
+                else f"{session_id}-{idx:04d}"
+            why = f"rank {r} did not report its results within {rank_timeout_s():.0f} s"
+            records.append({"image_id": image_id, "image_path": image_path, "error": why, "failure_history": [why],
+                            "completed": False, "_index": idx, "_rank": r})
     records.sort(key=lambda r: r["_index"])
     image_results: Dict[str, Dict[str, Any]] = {}
     verdicts: List[str] = []

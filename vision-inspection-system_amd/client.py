@@ -122,6 +122,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
                 raise FileNotFoundError(
                     f"model {model_id!r} is not a local directory and VIS_MODEL_ROOT has no copy of it; the "
                     f"'{LOCAL_PROVIDER}' provider only loads local files (config.json, *.safetensors, tokenizer.json)")
+            local_model_type(path)          # refuses anything but qwen2_vl (mllama was handled above)
             cfg = Qwen2VLConfig.from_hf_dir(path)
             w = W.load_safetensors_dir(cfg, path, device)
             tok = HFTokenizer(path, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
@@ -168,6 +169,39 @@ def _load_mllama(model_id: str, device, max_ctx: int) -> Optional[LoadedModel]:
 def drop_models() -> None:
     with _ENGINES_LOCK:
         _ENGINES.clear()
+
+
+def register_model(model_id: str, device: str, lm: LoadedModel) -> None:
+    """Serve ``model_id`` on ``device`` from an engine the caller already built (bench.py times the client on the
+    engine it has just measured instead of loading a second 16.6 GB replica)."""
+    with _ENGINES_LOCK:
+        _ENGINES[(model_id, str(device))] = lm
+
+
+def unregister_model(model_id: str, device: str) -> None:
+    with _ENGINES_LOCK:
+        _ENGINES.pop((model_id, str(device)), None)
+
+
+SUPPORTED_MODEL_TYPES = ("qwen2_vl", "mllama")
+
+
+def local_model_type(path: str) -> str:
+    """``model_type`` of a local HuggingFace directory, checked against what the engines implement.  The
+    reference's code default for both agents is Qwen/Qwen2.5-VL-7B-Instruct (utils/config.py:42-45,:59-64), its
+    README names Qwen2-VL-7B and Llama-3.2-11B-Vision; anything else is refused HERE with a clear message instead of
+    failing with a KeyError deep inside a weight loader."""
+    import json
+    cfg_path = os.path.join(path, "config.json")
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError(f"{cfg_path} not found: a local model directory needs config.json, *.safetensors and "
+                                f"tokenizer.json")
+    with open(cfg_path) as f:
+        mt = json.load(f).get("model_type")
+    if mt not in SUPPORTED_MODEL_TYPES:
+        raise ValueError(f"model directory {path!r} has model_type {mt!r}; the '{LOCAL_PROVIDER}' provider serves "
+                         f"{', '.join(SUPPORTED_MODEL_TYPES)} only")
+    return mt
 
 
 # ----------------------------------------------------------------------------- clients
@@ -233,7 +267,8 @@ class LocalVLMClient:
                 from . import hip
                 reqs = [(ids, [hip.resize_rgb(torch.from_numpy(f).to(eng.device), th, tw) for f, (th, tw) in frames])
                         for ids, frames in chunk]
-                toks = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed)
+                toks = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed,
+                                          ignore_eos=os.environ.get("VIS_IGNORE_EOS") == "1")
                 for (ids, _), t in zip(chunk, toks):
                     out.append(ChatCompletion([_Choice(_Message(tok.decode(t)))], model=model_id,
                                               usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
@@ -268,13 +303,22 @@ class LocalVLMClient:
                                      "total_tokens": len(ids) + len(toks)})
 
 
+_MOCK_REPLY: List[Optional[Any]] = [None]
+
+
+def set_mock_reply(reply) -> None:
+    """Reply (string, or callable messages -> string) of every ``CannedResponseClient`` built without one - i.e.
+    of the clients the agents build under provider ``mock`` (None restores the default "OK")."""
+    _MOCK_REPLY[0] = reply
+
+
 class CannedResponseClient:
     """Mock backend (the reference declares ``use_mock_responses``, utils/config.py:191, but ships none):
     returns a fixed reply.  Used for the no-GPU plumbing configuration (BASELINE config 1) and by tests;
     it performs no model arithmetic and is never selected implicitly."""
 
-    def __init__(self, reply: str = "OK", **_ignored):
-        self.reply = reply
+    def __init__(self, reply: Optional[str] = None, **_ignored):
+        self.reply = reply if reply is not None else (_MOCK_REPLY[0] if _MOCK_REPLY[0] is not None else "OK")
         self.calls: List[dict] = []
         self.chat = _Chat(self)
 
