@@ -29,3 +29,50 @@ def oracle_inputs(frames):
 
 def load_golden():
     return np.load(os.path.join(GOLDEN, "qwen2vl_tiny.npz"))
+
+
+# ----------------------------------------------------------------------------- a3 fixtures: seeded image recipes
+ENCODE_RECIPES = [
+    # name, PIL mode, (w, h), seed, file format
+    {"name": "rgb_small", "mode": "RGB", "size": [120, 90], "seed": 1, "format": "PNG"},
+    {"name": "rgb_448", "mode": "RGB", "size": [448, 448], "seed": 2, "format": "PNG"},
+    {"name": "rgba", "mode": "RGBA", "size": [200, 150], "seed": 3, "format": "PNG"},
+    {"name": "palette", "mode": "P", "size": [160, 160], "seed": 4, "format": "PNG"},
+    {"name": "gray_alpha", "mode": "LA", "size": [96, 64], "seed": 5, "format": "PNG"},
+    {"name": "gray", "mode": "L", "size": [77, 131], "seed": 6, "format": "PNG"},
+    {"name": "wide_over_max", "mode": "RGB", "size": [2500, 700], "seed": 7, "format": "PNG"},
+    {"name": "tall_over_auditor_max", "mode": "RGB", "size": [600, 1500], "seed": 8, "format": "PNG"},
+    {"name": "jpeg_source", "mode": "RGB", "size": [320, 240], "seed": 9, "format": "JPEG"},
+    {"name": "noise_2048", "mode": "RGB", "size": [2048, 2048], "seed": 10, "format": "PNG"},
+    {"name": "smooth_1024", "mode": "RGB", "size": [1024, 1024], "seed": 11, "format": "PNG", "smooth": True},
+]
+
+
+LARGE_RECIPES = [   # encoded with max_size 6000 (no thumbnail): q85 > 5 MB -> the q60 retry; the second also > 10 MB at q60
+    {"name": "noise_3400_q60", "mode": "RGB", "size": [3400, 3400], "seed": 12, "format": "PNG"},
+    {"name": "noise_5200_refused", "mode": "RGB", "size": [5200, 5200], "seed": 13, "format": "PNG"},
+]
+
+
+def make_recipe_image(recipe: dict, path) -> None:
+    """Write the image a recipe describes (seeded; identical in the generator and in the test)."""
+    from PIL import Image
+    w, h = recipe["size"]
+    rng = np.random.default_rng(1000 + recipe["seed"])
+    bands = {"RGB": 3, "RGBA": 4, "LA": 2, "L": 1, "P": 1}[recipe["mode"]]
+    if recipe.get("smooth"):
+        yy, xx = np.mgrid[0:h, 0:w]
+        a = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) % 256)], axis=-1).astype(np.uint8)
+    else:
+        a = rng.integers(0, 256, (h, w, bands), dtype=np.uint8)
+    if recipe["mode"] == "P":
+        img = Image.fromarray(a[:, :, 0], "P")
+        img.putpalette(rng.integers(0, 256, 768, dtype=np.uint8).tobytes())
+    elif bands == 1:
+        img = Image.fromarray(a[:, :, 0], "L")
+    else:
+        img = Image.fromarray(a, recipe["mode"])
+    if recipe["format"] == "JPEG":
+        img.save(path, format="JPEG", quality=92)
+    else:
+        img.save(path, format="PNG")
