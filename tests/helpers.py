@@ -76,3 +76,29 @@ def make_recipe_image(recipe: dict, path) -> None:
         img.save(path, format="JPEG", quality=92)
     else:
         img.save(path, format="PNG")
+
+
+# ----------------------------------------------------------------------------- token criterion (GPU tests)
+def teacher_forced_parity(eng, first_logits, ref_toks, ref_logits, tol, use_graph=False):
+    """EVERY generated step against the oracle, not only a prefix: after the prompt pass the engine is fed the ORACLE's
+    token at each step (its own pick is overwritten in ``cur_token``), so a near-tie at step t cannot hide what
+    happens at steps t+1.. .  Per step: logits within ``tol`` (absolute) of the oracle's, and the greedy pick equal to
+    the oracle's unless the oracle's top-2 margin at that step is below 2 x tol (a genuine near-tie).
+    Call right after ``eng.prefill``.  Returns the number of near-tie steps whose pick differed."""
+    ties = 0
+    logits = first_logits.float().cpu()
+    for t in range(len(ref_toks)):
+        ref = ref_logits[t].float()
+        err = float((logits - ref).abs().max())
+        assert err < tol, f"step {t}: logits differ from the oracle by {err:.4f} (tolerance {tol})"
+        if int(logits.argmax()) != int(ref.argmax()):
+            top2 = torch.topk(ref, 2).values
+            margin = float(top2[0] - top2[1])
+            assert margin < 2 * tol, f"step {t}: pick {int(logits.argmax())} vs oracle {int(ref.argmax())}, " \
+                                     f"oracle margin {margin:.4f} is not a near-tie"
+            ties += 1
+        if t + 1 < len(ref_toks):
+            eng.cur_token.fill_(int(ref_toks[t]))
+            eng.decode(1, use_graph=use_graph)
+            logits = eng.logits.float().cpu()
+    return ties

@@ -3,13 +3,15 @@ vs the transformers-recorded golden vectors, tiny kernel-compatible config.
 
 Stated tolerance (north_star: "within a stated float tolerance on the logits"): first-step logits
 within 6e-2 absolute (logit scale here is ~3, i.e. 2 % of range: bf16 activations through ~10
-GEMM stages), image embeddings within 5e-2.  Greedy tokens must equal the oracle's up to the
-first step whose oracle top-2 margin is below 2x that tolerance (a genuine near-tie)."""
+GEMM stages), image embeddings within 5e-2.  Token criterion: ALL 16 generated steps are checked with the
+oracle's tokens teacher-forced (helpers.teacher_forced_parity): every step's logits within the tolerance and
+every greedy pick equal to the oracle's unless the oracle's top-2 margin at that step is below 2x the tolerance
+(a genuine near-tie); the free-running tokens must equal the oracle's up to the first such near-tie."""
 import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, oracle_inputs, ref_config
+from helpers import load_golden, oracle_inputs, ref_config, teacher_forced_parity
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 6e-2
@@ -57,8 +59,82 @@ def test_engine_matches_oracle_and_golden(setup, device, case, frames):
     pv, grids = oracle_inputs(fr)
     ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, pv, grids, 16)
     assert np.abs(logits - ref_logits[0].numpy()).max() < LOGIT_TOL
-    agreed = _check_tokens(toks, ref_toks, ref_logits)
-    assert agreed >= 4, f"only {agreed} leading tokens agree: {toks} vs {ref_toks}"
+    _check_tokens(toks, ref_toks, ref_logits)          # free-running: equal up to the first near-tie (asserted inside)
+    # all 16 steps, teacher-forced: logits within tolerance and picks equal off near-ties at EVERY step
+    eng.prefill(ids, dev_frames, taps=taps)
+    ties = teacher_forced_parity(eng, taps["first_logits"], ref_toks, ref_logits, LOGIT_TOL)
+    assert ties <= 2, f"{ties} near-tie steps in 16 is implausible for seeded weights"
+
+
+def _outlier_state_dict(cfg, sd, compensated: bool):
+    """Massive-activation channels, as real checkpoints have them: 4 hidden channels carry values x100 in the token
+    embeddings and in the image features (merger output).  ``compensated``: the norm weights of those channels are
+    small (what trained models do); otherwise the projections see the outliers at full size."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    ch = [3, 77, 130, 201]
+    sd["model.embed_tokens.weight"][:, ch] *= 100.0
+    sd["visual.merger.mlp.2.weight"][ch, :] *= 100.0
+    sd["visual.merger.mlp.2.bias"][ch] *= 100.0
+    if compensated:
+        for k in sd:
+            if k.endswith("input_layernorm.weight") or k.endswith("post_attention_layernorm.weight") or k == "model.norm.weight":
+                sd[k][ch] *= 0.02
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("compensated", [True, False])
+def test_outlier_channels_bf16(setup, device, compensated):
+    """bf16 residual stream with 4 channels at ~+-170 next to O(1) channels (logit range grows to ~+-10..40): the
+    tolerance is stated RELATIVE to the logit range - 2 % of max|oracle logit| - and all 12 steps are teacher-forced."""
+    from oracle import qwen2vl_ref as R
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights
+    cfg, sd0, _ = setup
+    sd = _outlier_state_dict(cfg, sd0, compensated)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, decode_splits=4)
+    g = load_golden()
+    ids, fr = g["ids_a"].tolist(), [g["frame_a"]]
+    pv, grids = oracle_inputs(fr)
+    ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, pv, grids, 12)
+    rng_ = max(float(l.abs().max()) for l in ref_logits)
+    taps = {}
+    eng.prefill(ids, [torch.from_numpy(f).to(device) for f in fr], taps=taps)
+    x = taps["layer0"].float().abs()
+    assert float(x.max()) > 50.0                              # the outliers really are in the residual stream
+    teacher_forced_parity(eng, taps["first_logits"], ref_toks, ref_logits, 0.02 * rng_)
+
+
+@pytest.mark.parametrize("compensated", [True, False])
+def test_outlier_channels_fp8(setup, device, compensated):
+    """The same outlier model through the fp8 configuration (e4m3 weights with per-row scales, per-token e4m3
+    activations): per-row amax scaling keeps the O(1) channels representable next to a 100x outlier (e4m3 is a
+    floating-point format: 3 mantissa bits down to 2^-9 of the row maximum).  Statistical tolerance as for the plain
+    fp8 test, relative to the logit range: mean |dlogit| < 2 %, max < 12 % of max|oracle logit| against the fake-quant
+    oracle."""
+    from oracle import qwen2vl_ref as R
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights
+    cfg, sd0, _ = setup
+    sd = _outlier_state_dict(cfg, sd0, compensated)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, decode_splits=4,
+                        prefill_dtype="fp8", decode_weights="fp8")
+    g = load_golden()
+    ids, fr = g["ids_a"].tolist(), [g["frame_a"]]
+    pv, grids = oracle_inputs(fr)
+    dsd = _dequantised_sd(cfg, sd)
+    psd = dict(dsd)
+    psd["lm_head.weight"] = sd["lm_head.weight"]            # first token: bf16 lm_head
+    _, l8 = R.generate(ref_config(cfg), sd, ids, pv, grids, 1, prefill_fp8_sd=psd)
+    taps = {}
+    eng.prefill(ids, [torch.from_numpy(f).to(device) for f in fr], taps=taps)
+    got = taps["first_logits"].float().cpu()
+    assert torch.isfinite(got).all()
+    rng_ = float(l8[0].abs().max())
+    e8 = (got - l8[0]).abs()
+    print(f"[outlier fp8 compensated={compensated}] range {rng_:.2f} mean {float(e8.mean()) / rng_:.4f} max {float(e8.max()) / rng_:.4f}")
+    assert e8.mean() < 0.02 * rng_ and e8.max() < 0.12 * rng_, (float(e8.mean()), float(e8.max()), rng_)
+    toks = eng.generate(ids, [torch.from_numpy(f).to(device) for f in fr], max_new_tokens=6, ignore_eos=True)
+    assert len(toks) == 6 and all(0 <= t < cfg.vocab for t in toks)
 
 
 def test_graph_replay_equals_eager(setup, device):
@@ -78,7 +154,10 @@ def test_text_only_prompt_and_eos(setup, device):
     ids = [256, 72, 105, 33]
     toks = eng.generate(ids, [], max_new_tokens=8, ignore_eos=True)
     ref_toks, ref_logits = R.generate(ref_config(cfg), sd, ids, None, [], 8)
-    assert _check_tokens(toks, ref_toks, ref_logits) >= 3
+    _check_tokens(toks, ref_toks, ref_logits)
+    taps = {}
+    eng.prefill(ids, [], taps=taps)
+    teacher_forced_parity(eng, taps["first_logits"], ref_toks, ref_logits, LOGIT_TOL, use_graph=True)
     # EOS truncation: declare the 3rd generated token to be EOS
     import dataclasses
     eng.cfg = dataclasses.replace(cfg, eos_ids=(toks[2],))

@@ -2,8 +2,9 @@
 and vs the transformers-recorded golden vectors, tiny kernel-compatible config.
 
 Stated tolerance: cross-attention states within 6e-2 absolute (values are O(1); bf16 activations through the
-6-layer tiny tower), first-step logits within 8e-2 absolute (logit scale ~3).  Greedy tokens must equal the
-oracle's up to the first step whose oracle top-2 margin is below 2x the logit tolerance (a genuine near-tie)."""
+6-layer tiny tower), logits within 8e-2 absolute (logit scale ~3) at EVERY one of the 12 generated steps with the
+oracle's tokens teacher-forced (helpers.teacher_forced_parity), greedy picks equal to the oracle's unless its top-2
+margin at that step is below 2x the tolerance; free-running tokens equal up to the first such near-tie."""
 import os
 
 import numpy as np
@@ -83,8 +84,11 @@ def test_engine_matches_oracle_and_golden(setup, device, case):
         a = taps[f"layer{li}"].float().cpu().numpy()
         b = rtaps[f"layer{li}"].numpy()
         assert np.abs(a - b).max() < 0.15, f"layer {li}: {np.abs(a - b).max()}"
-    agreed = _check_tokens(toks, ref_toks, ref_logits)
-    assert agreed >= 4, f"only {agreed} leading tokens agree: {toks} vs {ref_toks}"
+    _check_tokens(toks, ref_toks, ref_logits)
+    from helpers import teacher_forced_parity
+    eng.prefill(ids, frame, taps=taps)
+    ties = teacher_forced_parity(eng, taps["first_logits"], ref_toks, ref_logits, LOGIT_TOL)
+    assert ties <= 2
 
 
 def test_graph_replay_equals_eager_and_text_only(setup, device):

@@ -153,14 +153,18 @@ def tensor_shapes(cfg: MllamaConfig) -> Dict[str, tuple]:
     return s
 
 
-def synth_state_dict(cfg: MllamaConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+def synth_state_dict(cfg: MllamaConfig, seed: int = 0, rng: str = "hash", device=None) -> Dict[str, torch.Tensor]:
     """Deterministic fp32 CPU weights in checkpoint naming, rounded to bf16-representable values (the oracle, the
     transformers golden generator and the HIP engine all consume exactly these numbers).  Gates are non-trivial
     (|gate| up to 0.8) so every gated path is exercised."""
     out: Dict[str, torch.Tensor] = {}
+    gen = torch.Generator(device=device or "cpu").manual_seed(seed) if rng == "torch" else None      # fast path for 11B-shape tests
     for name, shape in tensor_shapes(cfg).items():
         n = int(np.prod(shape))
-        u = _hash_uniform(n, seed * 100003 + (zlib.crc32(name.encode()) & 0xFFFFFFF))
+        if gen is not None:
+            u = torch.rand(n, generator=gen, dtype=torch.float32, device=gen.device).mul_(2.0).sub_(1.0)
+        else:
+            u = _hash_uniform(n, seed * 100003 + (zlib.crc32(name.encode()) & 0xFFFFFFF))
         if name.endswith("layernorm.weight") or name.endswith("norm.weight") or name.endswith("layernorm_pre.weight") \
                 or name.endswith("layernorm_post.weight"):
             v = 1.0 + 0.1 * u
@@ -169,13 +173,14 @@ def synth_state_dict(cfg: MllamaConfig, seed: int = 0) -> Dict[str, torch.Tensor
         elif name.endswith("gate") or name.endswith("gate_attn") or name.endswith("gate_ffn"):
             v = 0.3 + 0.5 * u
         elif name.endswith("embed_tokens.weight"):
-            v = u * np.sqrt(3.0)
+            v = u * float(np.sqrt(3.0))
         elif "positional_embedding" in name or name.endswith("class_embedding"):
             v = 0.5 * u
         else:
             fan_in = int(np.prod(shape[1:]))
-            v = u * np.sqrt(3.0 / fan_in)
-        out[name] = torch.from_numpy(v.astype(np.float32).reshape(shape)).to(torch.bfloat16).float()
+            v = u * float(np.sqrt(3.0 / fan_in))
+        t = v.reshape(shape) if gen is not None else torch.from_numpy(v.astype(np.float32).reshape(shape))
+        out[name] = t.to(torch.bfloat16).float().cpu()
     return out
 
 

@@ -94,8 +94,11 @@ def _hash_uniform(n: int, stream: int) -> np.ndarray:
     return (z >> np.uint64(11)).astype(np.float64) * (2.0 / (1 << 53)) - 1.0
 
 
-def synth_state_dict(cfg: Qwen2VLConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+def synth_state_dict(cfg: Qwen2VLConfig, seed: int = 0, rng: str = "hash", device=None) -> Dict[str, torch.Tensor]:
     """Deterministic fp32 CPU weights (variance-preserving scales) in checkpoint naming.
+    ``rng="torch"`` draws from a seeded torch generator (on ``device`` when given; the result is always returned on
+    the CPU) instead of the portable hash: for the full-size (7B-shape) parity tests, where 10^9 values are needed
+    within seconds and nothing is compared across machines.
 
     Used for the tiny parity model: the same dict feeds the oracle, the transformers golden
     generator and the HIP engine.  Values are rounded to bf16-representable numbers so every
@@ -103,21 +106,25 @@ def synth_state_dict(cfg: Qwen2VLConfig, seed: int = 0) -> Dict[str, torch.Tenso
     """
     import zlib
     out: Dict[str, torch.Tensor] = {}
+    gen = torch.Generator(device=device or "cpu").manual_seed(seed) if rng == "torch" else None
     for name, shape in tensor_shapes(cfg).items():
         n = int(np.prod(shape))
-        u = _hash_uniform(n, seed * 100003 + (zlib.crc32(name.encode()) & 0xFFFFFFF))
+        if gen is not None:
+            u = torch.rand(n, generator=gen, dtype=torch.float32, device=gen.device).mul_(2.0).sub_(1.0)
+        else:
+            u = _hash_uniform(n, seed * 100003 + (zlib.crc32(name.encode()) & 0xFFFFFFF))
         if name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight") \
                 or name.endswith("layernorm.weight") or name.endswith("ln_q.weight"):
             v = 1.0 + 0.1 * u
         elif name.endswith(".bias"):
             v = 0.1 * u
         elif name.endswith("embed_tokens.weight"):
-            v = u * np.sqrt(3.0)  # unit-variance rows
+            v = u * float(np.sqrt(3.0))  # unit-variance rows
         else:
             fan_in = int(np.prod(shape[1:]))
-            v = u * np.sqrt(3.0 / fan_in)
-        t = torch.from_numpy(v.astype(np.float32).reshape(shape))
-        out[name] = t.to(torch.bfloat16).float()
+            v = u * float(np.sqrt(3.0 / fan_in))
+        t = v.reshape(shape) if gen is not None else torch.from_numpy(v.astype(np.float32).reshape(shape))
+        out[name] = t.to(torch.bfloat16).float().cpu()
     return out
 
 
