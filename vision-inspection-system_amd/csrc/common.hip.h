@@ -49,6 +49,17 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
+// x * sigmoid(k x) = x / (1 + e^(-k x)) with ONE v_exp_f32 and ONE v_rcp_f32 (each 1 ulp): the IEEE division the
+// plain expression compiles to costs ~10 VALU instructions per element, which made the activation epilogues of the
+// prefill GEMMs (128 elements per thread on a 256 x 256 tile) 16 us per tile round (tools/gemm_kscan.py: fixed cost
+// 32.4 us per round with QuickGELU against 16.4 us without).  SiLU: k = 1; QuickGELU: k = 1.702.
+#define VIS_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float x_sigmoid(float x, float k_log2e) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-k_log2e * x));
+}
+__device__ __forceinline__ float silu_fast(float x) { return x_sigmoid(x, VIS_LOG2E); }
+__device__ __forceinline__ float quickgelu_fast(float x) { return x_sigmoid(x, 1.702f * VIS_LOG2E); }
+
 // Cross-row exchanges without the LDS crossbar: gfx950's v_permlane16_swap / v_permlane32_swap swap 16- / 32-lane
 // halves between two registers in one VALU op (a ds_bpermute round trip costs ~100+ cycles of latency).
 // With both operands a copy of x: swap16 -> {rows 0,0,2,2 | rows 1,1,3,3}, swap32 -> {low half twice | high half twice}.

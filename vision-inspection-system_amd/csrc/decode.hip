@@ -96,7 +96,7 @@ __device__ __forceinline__ void gv_finish(const GemvArgs& p, bool swiglu, int pa
   a1 = wave_sum(a1);
   if (lane != 0) return;
   if (swiglu) {
-    ((bf16_t*)p.y)[pair] = f2bf(a0 / (1.0f + __expf(-a0)) * a1);
+    ((bf16_t*)p.y)[pair] = f2bf(silu_fast(a0) * a1);
     return;
   }
   const int o = 2 * pair;
@@ -358,7 +358,7 @@ __device__ __forceinline__ void gf_finish(const GemvF8Args& p, bool swiglu, int 
 #pragma unroll
     for (int i = 0; i < ROWS / 2; ++i) {
       const float g = a[2 * i] * p.scale[r[2 * i]], u = a[2 * i + 1] * p.scale[r[2 * i + 1]];
-      ((bf16_t*)p.y)[(ROWS / 2) * quad + i] = f2bf(g / (1.0f + __expf(-g)) * u);
+      ((bf16_t*)p.y)[(ROWS / 2) * quad + i] = f2bf(silu_fast(g) * u);
     }
     return;
   }

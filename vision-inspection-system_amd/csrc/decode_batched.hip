@@ -86,7 +86,7 @@ __global__ __launch_bounds__(FIN_THREADS) void skinny_finalize_kernel(FinArgs p)
         for (int r = 0; r < 4; ++r) { ga[r] *= sxb * sg[r]; ua[r] *= sxb * su[r]; }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = ga[r] / (1.0f + __expf(-ga[r])) * ua[r];
+      for (int r = 0; r < 4; ++r) v[r] = silu_fast(ga[r]) * ua[r];
     } else {
       f32x4 a = fin_sum_dyn(pb + o, stride, p.ksplit);
       if (p.sx) {

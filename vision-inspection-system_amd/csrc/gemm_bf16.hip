@@ -47,11 +47,18 @@ struct GemmArgs {
   // 32-row (batched decode) tile only: K split over grid.y, f32 partials part[ks][16][N]; out_f32: direct f32 C
   float* part;
   int ksplit, out_f32;
+  int wide;   // host-checked alignment preconditions of gemm_epilogue_wide hold
 };
 
+// exact-erf GELU (merger only: 1225 x 5120 elements per image).  Deliberately NOT inlined: erff expands to ~60
+// instructions, and the epilogues instantiate the activation up to 128 times per kernel.
+__device__ __attribute__((noinline)) float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+
 __device__ __forceinline__ float act_apply(float x, int act) {
-  if (act == ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
-  if (act == ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  if (act == ACT_QUICKGELU) return quickgelu_fast(x);
+  if (act == ACT_GELU_ERF) return gelu_erf(x);
   return x;
 }
 
@@ -83,7 +90,7 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& p, f32x4 (&acc)[
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float g = acc[i][j][r], u = acc[i][j + 1][r];
-          v[r] = g / (1.0f + __expf(-g)) * u;
+          v[r] = silu_fast(g) * u;
         }
         u32x2 o;
         o[0] = pack2bf(v[0], v[1]);
@@ -122,6 +129,149 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& p, f32x4 (&acc)[
         *(u32x2*)(p.C + (size_t)m * p.ldc + n) = o;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Wide epilogue: the wave's accumulator tile goes through a wave-private 16 KiB LDS region and leaves as whole
+// 16-byte chunks of C rows (8 lanes cover one 128-byte row segment), instead of 8-byte stores at a row stride
+// (every store instruction of the direct form touches 16 different rows in 32-byte pieces: tools/gemm_kscan.py put
+// the fixed cost of a 256 x 256 tile round at 16.4 us, most of it this store tail).  The residual is read the same
+// way (16 bytes per lane) and added in f32 BEFORE the one rounding to bf16, so results are bit-identical to the
+// direct epilogue; bias and activation are applied in the accumulator layout (4 consecutive columns per lane).
+//   plain / bias / act      : bf16 staging, 128-byte rows, chunk c of row r at slot c ^ ((r >> 1) & 7)
+//   residual                : f32 staging in 64-row halves, 256-byte rows, chunk c at slot c ^ (r & 15)
+//   SwiGLU (gate/up pairs)  : bf16 staging of the 8 NT output columns, 64-byte rows, slot c ^ ((r >> 2) & 3)
+// (slot maps chosen so that the ds_write_b64 / b128 lane groups and the ds_read_b128 lane groups hit distinct banks).
+// DS operations of one wave execute in order, so no barrier is needed between a wave's writes and its own reads.
+// Preconditions (checked on the host, p.wide): N % 8 == 0, ldc % 8 == 0, ldr % 8 == 0, C / R 16-byte aligned.
+template <int ACT, int MI, int NT>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4 (&acc)[MI][NT], int mbase, int nbase,
+                                                   int lane, char* st) {
+  const int l15 = lane & 15, h = lane >> 4;
+  if constexpr (ACT == ACT_SWIGLU) {
+    static_assert(NT % 2 == 0, "gate/up pairs");
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int row = i * 16 + l15;
+#pragma unroll
+      for (int j = 0; j < NT; j += 2) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[i][j][r]) * acc[i][j + 1][r];
+        u32x2 o;
+        o[0] = pack2bf(v[0], v[1]);
+        o[1] = pack2bf(v[2], v[3]);
+        const int c = (j >> 1) * 2 + (h >> 1);                       // 16-byte chunk of the 64-byte staging row
+        *(u32x2*)(st + row * 64 + ((c ^ ((row >> 2) & 3)) << 4) + (h & 1) * 8) = o;
+      }
+    }
+    const int ocol0 = (nbase >> 1);
+    const int cvalid = NT;                                           // NT/2 pairs x 16 columns = 2 NT / 2 chunks
+#pragma unroll 2
+    for (int it = 0; it < MI; ++it) {
+      const int row = it * 16 + (lane >> 2), c = lane & 3;
+      const int m = mbase + row, oc = ocol0 + c * 8;
+      if (c < cvalid && m < p.M && oc * 2 < p.N) {
+        const u32x4 o = *(const u32x4*)(st + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+        *(u32x4*)(p.C + (size_t)m * p.ldc + oc) = o;
+      }
+    }
+    return;
+  } else {
+    const bool has_r = p.R != nullptr;
+    if (!has_r) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int row = i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = nbase + j * 16 + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+          if (p.bias && n < p.N) {
+            const u32x2 b = *(const u32x2*)(p.bias + n);
+            v[0] += __uint_as_float(b[0] << 16);
+            v[1] += __uint_as_float(b[0] & 0xffff0000u);
+            v[2] += __uint_as_float(b[1] << 16);
+            v[3] += __uint_as_float(b[1] & 0xffff0000u);
+          }
+          if constexpr (ACT != ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], ACT);
+          }
+          u32x2 o;
+          o[0] = pack2bf(v[0], v[1]);
+          o[1] = pack2bf(v[2], v[3]);
+          const int c = j * 2 + (h >> 1);
+          *(u32x2*)(st + row * 128 + ((c ^ ((row >> 1) & 7)) << 4) + (h & 1) * 8) = o;
+        }
+      }
+#pragma unroll 2
+      for (int it = 0; it < 2 * MI; ++it) {
+        const int row = it * 8 + (lane >> 3), c = lane & 7;
+        const int m = mbase + row, n = nbase + c * 8;
+        if (c < 2 * NT && m < p.M && n < p.N) {
+          const u32x4 o = *(const u32x4*)(st + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+          *(u32x4*)(p.C + (size_t)m * p.ldc + n) = o;
+        }
+      }
+      return;
+    }
+    // residual: f32 staging, 64 rows at a time
+#pragma unroll
+    for (int hm = 0; hm < MI / 4; ++hm) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int n = nbase + j * 16 + 4 * h;
+          f32x4 v = acc[hm * 4 + i][j];
+          if (p.bias && n < p.N) {
+            const u32x2 b = *(const u32x2*)(p.bias + n);
+            v[0] += __uint_as_float(b[0] << 16);
+            v[1] += __uint_as_float(b[0] & 0xffff0000u);
+            v[2] += __uint_as_float(b[1] << 16);
+            v[3] += __uint_as_float(b[1] & 0xffff0000u);
+          }
+          if constexpr (ACT != ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], ACT);
+          }
+          const int c = j * 4 + h;                                    // 16-byte chunk (4 floats) of the 256-byte row
+          *(f32x4*)(st + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+        }
+      }
+#pragma unroll 2
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), g = lane & 7;
+        const int m = mbase + hm * 64 + row, n = nbase + g * 8;
+        if (g < 2 * NT && m < p.M && n < p.N) {
+          const f32x4 a = *(const f32x4*)(st + row * 256 + (((2 * g) ^ (row & 15)) << 4));
+          const f32x4 b = *(const f32x4*)(st + row * 256 + (((2 * g + 1) ^ (row & 15)) << 4));
+          float f[8];
+          unpack8(*(const u32x4*)(p.R + (size_t)m * p.ldr + n), f);
+          float v[8] = {a[0] + f[0], a[1] + f[1], a[2] + f[2], a[3] + f[3], b[0] + f[4], b[1] + f[5], b[2] + f[6], b[3] + f[7]};
+          *(u32x4*)(p.C + (size_t)m * p.ldc + n) = pack8(v);
+        }
+      }
+    }
+  }
+}
+
+// run-time activation -> compile-time epilogue instance (keeps every instance branch-free and small)
+template <int MI, int NT>
+__device__ __forceinline__ void gemm_epilogue_wide_dispatch(const GemmArgs& p, f32x4 (&acc)[MI][NT], int mbase, int nbase,
+                                                            int lane, char* st) {
+  switch (p.act) {
+    case ACT_QUICKGELU: gemm_epilogue_wide<ACT_QUICKGELU, MI, NT>(p, acc, mbase, nbase, lane, st); break;
+    case ACT_GELU_ERF: gemm_epilogue_wide<ACT_GELU_ERF, MI, NT>(p, acc, mbase, nbase, lane, st); break;
+    case ACT_SWIGLU:
+      if constexpr (NT % 2 == 0) gemm_epilogue_wide<ACT_SWIGLU, MI, NT>(p, acc, mbase, nbase, lane, st);
+      break;
+    default: gemm_epilogue_wide<ACT_NONE, MI, NT>(p, acc, mbase, nbase, lane, st); break;
   }
 }
 
@@ -209,7 +359,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128x128_kernel(GemmArgs p) {
     cur ^= 1;
   }
 
-  gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
+  // the loop's last __syncthreads() retired every LDS read and every LDS-DMA: the buffers are free for staging
+  if (p.wide) gemm_epilogue_wide_dispatch<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, lds + wave * 16384);
+  else gemm_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
 }
 
 // ---------------------------------------------------------------------------
@@ -525,6 +677,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256xN_kernel(GemmArgs p) {
     }
     return;
   }
+  if (p.wide && !(p.act == ACT_SWIGLU && (NT & 1))) {
+    // every wave's fragment reads have been consumed by its MFMAs and its LDS-DMA drained (vmcnt(0) above); one
+    // barrier makes that true for the whole workgroup before the buffers become staging space
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_wide_dispatch<8, NT>(p, acc, m0 + wm * 128, n0 + wn * (16 * NT), lane, lds4 + wave * 16384);
+    return;
+  }
   // epilogue: two 64-row halves through the shared 4x4 epilogue
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
@@ -726,6 +886,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p
         if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
       }
     }
+    return;
+  }
+  if (p.wide) {
+    // all waves have executed the same number of barriers and drained their own LDS-DMA (vmcnt(0) above), but a
+    // faster wave must not overwrite a half-tile a trailing redundant stage of ANOTHER wave is still landing in, nor
+    // fragments a slower wave has yet to read: one more barrier for everyone, then the buffers are staging space
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_wide_dispatch<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane, lds5 + wave * 16384);
     return;
   }
 #pragma unroll
@@ -1258,6 +1427,9 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
   p.act = act;
   p.part = nullptr; p.ksplit = 1; p.out_f32 = 0;
+  static const int wide_env = [] { const char* e = getenv("VIS_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0: direct epilogue (A/B)
+  p.wide = wide_env && N % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && !(((uintptr_t)C | (uintptr_t)R) & 15) &&
+           !(act == ACT_SWIGLU && N % 16 != 0);
   vis_clear_error();
   const int st = gemm_dispatch(p, stream);
   return st != VIS_OK ? st : vis_check_launch();
@@ -1284,7 +1456,7 @@ extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bi
   GemmArgs p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R; p.C = (bf16_t*)C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
-  p.part = (float*)work; p.ksplit = ksplit; p.out_f32 = 0;
+  p.part = (float*)work; p.ksplit = ksplit; p.out_f32 = 0; p.wide = 0;
   p.tiles_m = (M + GEMM4_B - 1) / GEMM4_B;
   p.tiles_n = (N + GEMM4_B - 1) / GEMM4_B;
   vis_clear_error();

@@ -39,7 +39,7 @@ struct GemmF8Args {
 };
 
 __device__ __forceinline__ float f8_act(float x, int act) {
-  if (act == F8_ACT_QUICKGELU) return x / (1.0f + __expf(-1.702f * x));
+  if (act == F8_ACT_QUICKGELU) return quickgelu_fast(x);
   if (act == F8_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
   return x;
 }
@@ -63,7 +63,7 @@ __device__ __forceinline__ void f8_epilogue(const GemmF8Args& p, f32x4 (&acc)[4]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float g = acc[i][j][r] * sam * sg[r], u = acc[i][j + 1][r] * sam * su[r];
-          v[r] = g / (1.0f + __expf(-g)) * u;
+          v[r] = silu_fast(g) * u;
         }
         u32x2 o;
         o[0] = pack2bf(v[0], v[1]);
