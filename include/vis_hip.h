@@ -59,7 +59,9 @@ int vis_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int
  * qkv[S, (Hq+2Hkv)*HD] packed projections; cos/sin [S, HD] f32 rows (M-RoPE sections already
  * selected per channel, TF modeling_qwen2_vl.py:180-222; ViT 2-D rope :225-236).
  * q -> [Hq][S][HD]; k,v -> [Hkv][k_tokens][HD] rows k_pos0.. (v may be NULL);
- * vt -> [Hkv][HD][vt_ld] keys contiguous (may be NULL).  HD in {128, 80}.
+ * vt -> [Hkv][HD][vt_ld] keys contiguous (may be NULL), in the k-slot column order vis_attn_prefill reads: inside
+ * every aligned group of 32 keys, key 16a + 4h + r (a < 2, h < 4, r < 4) is column 8h + 4a + r (ABI version 2).
+ * HD in {128, 80}.
  * Hq == 0 (k/v only) or Hkv == 0 (q only) give a partial split; cosv == sinv == NULL means no rotation (mllama
  * vision tower and cross-attention operands, TF:models/mllama/modeling_mllama.py:234-268,:411-440). */
 int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void* q, void* k, void* v,
@@ -80,6 +82,13 @@ int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, cons
 int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
                           int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
                           float scale, int q_row0, vis_stream_t stream);
+
+/* K7, balanced form (HD = 128, causal, keys from 0): work = n_work x int4 {qB0, qBn, qA0, qAn}, a late and an early
+ * 128-row query block of one sequence per 512-thread workgroup (qAn = 0: none), so that every workgroup of the causal
+ * grid carries the same number of key tiles.  Results equal vis_attn_prefill_rows(..., causal = 1). */
+int vis_attn_prefill_pairs(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
+                           int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, float scale,
+                           int q_row0, vis_stream_t stream);
 
 /* K10  y[N] = act(W[N,K] x[K] + bias) + R, optional fused RMSNorm of x (norm_w != NULL).
  * out_f32 != 0 writes float logits (lm_head).  One generated token streams every weight once. */
@@ -157,6 +166,16 @@ int vis_scatter_rows(const void* src, const void* idx, void* dst, int n, int D, 
  * second launch sums them in a fixed order and applies bias / act (0..2) / residual.  N % 8 == 0, no SwiGLU. */
 int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* R, void* C, void* work, int M, int N,
                          int K, int lda, int ldw, int ldc, int ldr, int act, int ksplit, vis_stream_t stream);
+/* The K-sliced tiles of vis_gemm_bf16_splitk alone: work[ksplit][M][N] f32 partial sums of A W^T (no finalisation). */
+int vis_gemm_bf16_splitk_part(const void* A, const void* W, void* work, int M, int N, int K, int lda, int ldw,
+                              int ksplit, vis_stream_t stream);
+/* Their finalisation fused with the NEXT norm of the block (K3 / K5; the row owner exists here):
+ * x = bf16(sum_s part[s] + bias + R); y = RMSNorm(x) * norm_w (norm_b == NULL) or LayerNorm(x) (norm_b != NULL), with
+ * the statistics of the rounded x - bit-identical to vis_gemm_bf16_splitk followed by vis_rmsnorm_bf16 /
+ * vis_layernorm_bf16.  y == NULL: finalisation only.  N <= 5120, N % 8 == 0. */
+int vis_splitk_finalize_norm(const void* part, int ksplit, const void* bias, const void* R, void* x,
+                             const void* norm_w, const void* norm_b, void* y, int M, int N, int ldr, int ldx, int ldy,
+                             float eps, vis_stream_t stream);
 
 /* BASELINE configs[4] slice - fp8 weights for the HBM-bound decode projections ("W8A16"):
  * y = act((Wq x) * scale + bias) + R with Wq OCP e4m3 bytes [N][ldw] and a per-output-row f32 scale; x bf16 with the

@@ -327,24 +327,6 @@ def test_fp8_decode_weights_match_oracle_with_dequantised_weights(setup, device)
     assert (eng16.logits - eng.logits).abs().max() > 1e-3
 
 
-def test_vit_two_stream_split_equals_single_stream(setup, device):
-    """The row-split / two-stream ViT schedule is a pure re-scheduling: same kernels, same per-row arithmetic."""
-    cfg, sd, eng = setup
-    rng = np.random.default_rng(3)
-    frame = torch.from_numpy(rng.integers(0, 256, (28 * 14, 28 * 12, 3), dtype=np.uint8)).to(device)   # 28x24 patches
-    old = eng.vit_split_min_rows
-    try:
-        eng.vit_split_min_rows = 1 << 30
-        a = eng.vision_forward([frame]).float().cpu()
-        eng.vit_split_min_rows = 64
-        b = eng.vision_forward([frame]).float().cpu()
-        c = eng.vision_forward([frame]).float().cpu()
-    finally:
-        eng.vit_split_min_rows = old
-    assert torch.equal(b, c)
-    assert (a - b).abs().max() < 1e-6 * max(1.0, float(a.abs().max())) or torch.equal(a, b)
-
-
 def test_vit_features_do_not_depend_on_batch_position(setup, device):
     """An image's features are bit-identical alone, second in a request, or batched behind other images: every image
     starts on a 64-row boundary, so the attention kernel's absolute 64-key tiles group its keys the same way."""

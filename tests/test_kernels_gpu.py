@@ -214,8 +214,11 @@ def test_qkv_rope_split(hip, device, S, Hq, Hkv, HD):
     _assert_close(q, qr.permute(1, 0, 2), atol=2e-2, rtol=1e-2, what="rope q")
     _assert_close(k[:, pos0:pos0 + S], kr.permute(1, 0, 2), atol=2e-2, rtol=1e-2, what="rope k")
     assert torch.equal(v[:, pos0:pos0 + S].float().cpu(), vr.permute(1, 0, 2).cpu())
-    assert torch.equal(vt[:, :, :S].float().cpu(), vr.permute(1, 2, 0).cpu())
-    assert float(vt[:, :, S:ld].float().abs().max().cpu()) == 0.0 if ld > S else True
+    # V^T columns are in the attention kernel's k-slot order (hip.vt_key_order): column c holds key key_of_col[c]
+    key_of_col = hip.vt_key_order(ld).cpu()
+    plain = torch.zeros((Hkv, HD, ld))
+    plain[:, :, :S] = vr.permute(1, 2, 0).cpu()
+    assert torch.equal(vt.float().cpu(), plain[:, :, key_of_col])
     assert float(k[:, :pos0].float().abs().max().cpu()) == 0.0
 
 
@@ -258,6 +261,7 @@ def test_attn_prefill(hip, device, S, Hq, Hkv, HD, causal, segments):
     ld = ((S + 63) // 64) * 64
     vt = torch.zeros((Hkv, HD, ld), dtype=torch.bfloat16, device=device)
     vt[:, :, :S] = v.permute(0, 2, 1)
+    vt = vt[:, :, hip.vt_key_order(ld, device)].contiguous()
     out = torch.zeros((S, Hq * HD), dtype=torch.bfloat16, device=device)
     work = hip.make_attn_work(segments, causal, device, heads=Hq)
     scale = HD ** -0.5
@@ -286,6 +290,7 @@ def test_attn_prefill_spiked_max(hip, device):
     ld = 320
     vt = torch.zeros((H, HD, ld), dtype=torch.bfloat16, device=device)
     vt[:, :, :S] = v.permute(0, 2, 1)
+    vt = vt[:, :, hip.vt_key_order(ld, device)].contiguous()
     out = torch.zeros((S, H * HD), dtype=torch.bfloat16, device=device)
     work = hip.make_attn_work([(0, S)], True, device)
     hip.attn_prefill(q, k, vt, out, work, True, HD ** -0.5)
@@ -448,6 +453,7 @@ def test_attn_prefill_row_offset_equals_full_pass(hip, device):
     ld = (S + 63) // 64 * 64
     vt = torch.zeros((Hkv, HD, ld), dtype=torch.bfloat16, device=device)
     vt[:, :, :S] = v.transpose(1, 2)
+    vt = vt[:, :, hip.vt_key_order(ld, device)].contiguous()
     full = torch.empty((S, Hq * HD), dtype=torch.bfloat16, device=device)
     hip.attn_prefill(q, k, vt, full, hip.make_attn_work([(0, S)], True, device), True, HD ** -0.5)
     items = sorted([(q0, min(128, S - q0), 0, S) for q0 in range(P, S, 128)], key=lambda it: -(it[0] + it[1]))
@@ -730,3 +736,60 @@ def test_batched_decode_attention_and_argmax(hip, device):
     assert cur.cpu().tolist() == [100, 200, 300] and st.cpu().tolist() == [1, 4, 8]
     t = tokens.cpu()
     assert t[0, 0] == 100 and t[1, 3] == 200 and t[2, 7] == 300 and int((t >= 0).sum()) == 3
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,P", [(2249, 28, 4, 0), (300, 4, 2, 0), (129, 2, 1, 0), (64, 2, 2, 0), (1000, 8, 2, 448),
+                                         (17, 2, 1, 0)])
+def test_attn_prefill_pairs_equals_unpaired_and_reference(hip, device, S, Hq, Hkv, P):
+    """K7, balanced form: a late and an early 128-row query block per workgroup.  Against the fp32 reference and - bit
+    for bit - against the one-block-per-workgroup kernel (same tiles, same order, same rounding points), including an
+    odd block count, a ragged last block, a single short block and a shared-prefix pass (rows P.. only)."""
+    HD = 128
+    q = _randn((Hq, S, HD), device, 70)
+    k = _randn((Hkv, S + 5, HD), device, 71)
+    v = _randn((Hkv, S + 5, HD), device, 72)
+    ld = (S + 63) // 64 * 64
+    vt = torch.zeros((Hkv, HD, ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v[:, :S].transpose(1, 2)
+    vt = vt[:, :, hip.vt_key_order(ld, device)].contiguous()
+    n = S - P
+    qs = q[:, P:].contiguous()
+    paired = torch.full((n, Hq * HD), 7.0, dtype=torch.bfloat16, device=device)
+    hip.attn_prefill_pairs(qs, k, vt, paired, hip.make_attn_pairs(P, S, device), HD ** -0.5, q_row0=P)
+    items = [(q0, min(128, S - q0), 0, S) for q0 in range(P, S, 128)]
+    work = torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+    plain = torch.empty_like(paired)
+    hip.attn_prefill(qs, k, vt, plain, work, True, HD ** -0.5, q_row0=P)
+    assert torch.equal(paired, plain)
+    g = Hq // Hkv
+    kk, vv = k[:, :S].float().repeat_interleave(g, 0), v[:, :S].float().repeat_interleave(g, 0)
+    sc = torch.einsum("hqd,hkd->hqk", q.float(), kk) * HD ** -0.5
+    sc = sc.masked_fill(torch.ones(S, S, dtype=torch.bool, device=device).triu(1), float("-inf"))
+    ref = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, -1), vv).reshape(S, Hq * HD)[P:]
+    _assert_close(paired, ref, atol=2e-2, rtol=2e-2, what="paired causal attention")
+
+
+@pytest.mark.parametrize("M,N,K,ln", [(2249, 3584, 18944, False), (4900, 1280, 5120, True), (70, 256, 704 - 64, False),
+                                       (33, 320, 1280, True)])
+def test_splitk_finalize_fused_with_norm_is_bit_identical(hip, device, M, N, K, ln):
+    """K-slice partials -> x = sum + bias + residual and y = norm(x) in ONE row pass (vis_splitk_finalize_norm) equals
+    vis_gemm_bf16_splitk followed by vis_rmsnorm_bf16 / vis_layernorm_bf16 bit for bit (same slice order, norm statistics
+    of the rounded x), with the residual aliasing the output as the engines use it; y = None finalises only."""
+    a = _randn((M, K), device, 80)
+    w = _randn((N, K), device, 81, scale=K ** -0.5)
+    bias = _randn((N,), device, 82) if ln else None
+    res = _randn((M, N), device, 83)
+    nw, nb = _randn((N,), device, 84), (_randn((N,), device, 85) if ln else None)
+    work = torch.empty(2 * M * N, dtype=torch.float32, device=device)
+    x_ref = hip.gemm_splitk(a, w, work, 2, bias=bias, residual=res)
+    y_ref = hip.layernorm(x_ref, nw, nb, 1e-6) if ln else hip.rmsnorm(x_ref, nw, 1e-6)
+    x = res.clone()                                      # residual aliases the output
+    y = torch.empty_like(x)
+    hip.gemm_splitk_part(a, w, work, 2)
+    hip.splitk_finalize_norm(work, 2, x, bias=bias, residual=x, norm_w=nw, norm_b=nb, y_out=y, eps=1e-6)
+    assert torch.equal(x, x_ref) and torch.equal(y, y_ref)
+    x2 = res.clone()
+    hip.splitk_finalize_norm(work, 2, x2, bias=bias, residual=x2)
+    assert torch.equal(x2, x_ref)
+    ref = a.float() @ w.float().t() + res.float() + (bias.float() if ln else 0.0)
+    _assert_close(x, ref, atol=3e-2, rtol=2e-2, what="split-K sum")

@@ -31,13 +31,14 @@
 //  * the exponentiated tile is already the A operand of P*V: two S^T blocks
 //    (32 keys) pack in-lane into one bf16x8 fragment; the k-slot order this
 //    implies (slot (h,j) <-> key 16*(j>>2) + 4h + (j&3)) is applied to the B
-//    operand instead, which is read from a V^T tile ([d][key], keys
-//    contiguous) with two ds_read_b64 per fragment.  No cross-lane movement of
-//    P and no transposed LDS read are needed.
+//    operand instead: vis_qkv_rope_split writes V^T ([d][key]) with exactly that
+//    column order inside every 32-key group, so a lane's B fragment is one
+//    aligned 16-byte chunk (one ds_read_b128; it used to be two ds_read_b64 plus
+//    register moves).  No cross-lane movement of P and no transposed LDS read.
 //  * K tile: 256-B rows, 16-B chunk index XOR (row & 15)   -> conflict-free b128
 //    (head_dim 80: 224-B padded rows - 16-B slot (14 r + c) mod 16 is distinct over every ds_read_b128
 //    lane group - with zero-filled d 80..95);
-//    V^T tile: 128-B rows, 8-B slot index XOR (d & 14)     -> conflict-free b64.
+//    V^T tile: 128-B rows, 16-B chunk index XOR ((d >> 1) & 7) -> conflict-free b128.
 // Online softmax in the log2 domain with a finite -1e30 sentinel (no inf-inf).
 // Output O[s][head*HD + d] is staged through LDS and written as whole 16-B
 // chunks so the following projection GEMM reads a plain row-major matrix.
@@ -56,6 +57,39 @@ struct AttnArgs {
 };
 
 #define ATT_NEG (-1.0e30f)
+
+// Timing probes (tools/probes/attn_probe.sh builds this file with -DATT_PROBE=<bits>; the product build has 0 and
+// every probe branch is compiled out).  Results of a probe build are WRONG by construction - only its duration is read.
+//   1: stage only the first two key tiles (no K/V traffic afterwards)     2: v_exp_f32 -> v_mul_f32 (no transcendental)
+//   4: skip the P*V MFMAs                                                 8: skip the QK^T MFMAs
+//  16: no barrier / no wait at the end of a tile
+#ifndef ATT_PROBE
+#define ATT_PROBE 0
+#endif
+__device__ __forceinline__ float att_exp2(float x) {
+  if constexpr ((ATT_PROBE & 2) != 0) return x * 0.00390625f;
+  else return __builtin_amdgcn_exp2f(x);
+}
+
+__device__ __forceinline__ float att_max3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+__device__ __forceinline__ float att_max(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// max over lanes l, l^16, l^32, l^48 (hmax4 of common.hip.h without the canonicalising self-maxes)
+__device__ __forceinline__ float att_hmax4(float x) {
+  const uint32_t u = __float_as_uint(x);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = att_max(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const uint32_t v = __float_as_uint(s);
+  const auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return att_max(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 
 template <int HD, bool CAUSAL>
 __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(AttnArgs p) {
@@ -210,7 +244,7 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
   for (int t = 0; t < nt; ++t) {
     const int kt = kt_begin + t * 64;
     const bool more = (t + 1 < nt);
-    if (more) load_tile(kt + 64, cur ^ 1);
+    if (more && !((ATT_PROBE & 1) && t >= 1)) load_tile(kt + 64, cur ^ 1);
 
     const bool active = !CAUSAL || (kt <= wq0 + wrows - 1);
     auto tile_body = [&](auto nq_tag) {
@@ -218,11 +252,10 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
       const char* kb = lds + cur * BUF;
       const char* vb = kb + K_BYTES;
       // ---- S^T = K * Q^T
+      // the first k-step takes a literal zero as its C operand (an inline constant of the MFMA): zero-initialising
+      // the 8 accumulators first cost 32 v_mov per tile and wave
       f32x4 sacc[4][NQ];
-#pragma unroll
-      for (int kbk = 0; kbk < 4; ++kbk)
-#pragma unroll
-        for (int qb = 0; qb < NQ; ++qb) sacc[kbk][qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < DKF; ++ds) {
         bf16x8 kf[4];
@@ -236,8 +269,10 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-          for (int qb = 0; qb < NQ; ++qb)
-            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], sacc[kbk][qb], 0, 0, 0);
+          for (int qb = 0; qb < NQ; ++qb) {
+            if constexpr ((ATT_PROBE & 8) != 0) { sacc[kbk][qb] = (f32x4){kf[kbk][0], kf[kbk][1], qf[qb][ds][0], 1.0f}; continue; }
+            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], ds == 0 ? zero4 : sacc[kbk][qb], 0, 0, 0);
+          }
       }
 
       const bool need_mask = (kt < k0) || (kt + 64 > k1) || (CAUSAL && (kt + 63 > wq0));
@@ -279,25 +314,27 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
               sacc[kbk][qb][r] = ok ? sacc[kbk][qb][r] : ATT_NEG;
             }
         }
-        float mx = fmaxf(fmaxf(sacc[0][qb][0], sacc[0][qb][1]), sacc[0][qb][2]);  // chains -> v_max3_f32
-        mx = fmaxf(fmaxf(mx, sacc[0][qb][3]), sacc[1][qb][0]);
-        mx = fmaxf(fmaxf(mx, sacc[1][qb][1]), sacc[1][qb][2]);
-        mx = fmaxf(fmaxf(mx, sacc[1][qb][3]), sacc[2][qb][0]);
-        mx = fmaxf(fmaxf(mx, sacc[2][qb][1]), sacc[2][qb][2]);
-        mx = fmaxf(fmaxf(mx, sacc[2][qb][3]), sacc[3][qb][0]);
-        mx = fmaxf(fmaxf(mx, sacc[3][qb][1]), sacc[3][qb][2]);
-        mx = fmaxf(mx, sacc[3][qb][3]);
-        mx = hmax4(mx);  // over the four 16-lane rows (keys 4h..4h+3): two permlane swaps, no LDS round trip
+        // 8 x v_max3_f32 through att_max3 (inline asm): plain fmaxf on MFMA results makes hipcc put a canonicalising
+        // v_max_f32 x, x, x in front of every chain
+        float mx = att_max3(sacc[0][qb][0], sacc[0][qb][1], sacc[0][qb][2]);
+        mx = att_max3(mx, sacc[0][qb][3], sacc[1][qb][0]);
+        mx = att_max3(mx, sacc[1][qb][1], sacc[1][qb][2]);
+        mx = att_max3(mx, sacc[1][qb][3], sacc[2][qb][0]);
+        mx = att_max3(mx, sacc[2][qb][1], sacc[2][qb][2]);
+        mx = att_max3(mx, sacc[2][qb][3], sacc[3][qb][0]);
+        mx = att_max3(mx, sacc[3][qb][1], sacc[3][qb][2]);
+        mx = att_max3(mx, sacc[3][qb][3], sacc[3][qb][3]);
+        mx = att_hmax4(mx);  // over the four 16-lane rows (keys 4h..4h+3): two permlane swaps, no LDS round trip
         // raw scores are masked with -1e30; scaled they stay a huge negative number
-        const float mnew = fmaxf(mrow[qb], mx * p.scale_log2);
-        alpha[qb] = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
+        const float mnew = att_max(mrow[qb], mx * p.scale_log2);
+        alpha[qb] = att_exp2(mrow[qb] - mnew);
         mrow[qb] = mnew;
         float pv[4][4];
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
+            const float e = att_exp2(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
             pv[kbk][r] = e;
           }
 #pragma unroll
@@ -325,20 +362,19 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
           }
       }
 
-      // ---- O += P * V  (B operand from the V^T tile, permuted k-slots)
-      const int vsw = l15 & 14;
+      // ---- O += P * V  (B operand: chunk 4 ks + h of V^T row d, keys already in k-slot order)
+      const int vsw = (l15 >> 1) & 7;
 #pragma unroll
       for (int nb = 0; nb < ND; ++nb) {
         const char* vrow = vb + (nb * 16 + l15) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const u32x2 lo = *(const u32x2*)(vrow + (((8 * ks + h) ^ vsw) << 3));
-          const u32x2 hi = *(const u32x2*)(vrow + (((8 * ks + 4 + h) ^ vsw) << 3));
-          const u32x4 vv = (u32x4){lo[0], lo[1], hi[0], hi[1]};
-          const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+          const bf16x8 vf = *(const bf16x8*)(vrow + (((4 * ks + h) ^ vsw) << 4));
 #pragma unroll
-          for (int qb = 0; qb < NQ; ++qb)
+          for (int qb = 0; qb < NQ; ++qb) {
+            if constexpr ((ATT_PROBE & 4) != 0) { oacc[qb][nb][0] += (float)vf[0] + (float)pf[ks][qb][0]; continue; }
             oacc[qb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], vf, oacc[qb][nb], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -353,7 +389,7 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
     }
 
     if (more) store_tile(cur ^ 1);
-    __syncthreads();
+    if constexpr ((ATT_PROBE & 16) == 0) __syncthreads();
     cur ^= 1;
   }
 
@@ -381,6 +417,248 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
       *(u32x4*)(p.O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Causal prefill, head_dim 128, BALANCED: one workgroup = 8 waves = a PAIR of 128-row query blocks, a late ("heavy")
+// block B and an early ("light") block A of the same sequence.  With one block per workgroup (the kernel above) the
+// causal grid is a single round of the chip whose duration is the LAST block's (S = 2249: 36 key tiles, while the
+// average block has 18) - half of the chip's time is idle.  Here wave w owns 16 rows of B (its q-block 0) AND 16 rows
+// of A (its q-block 1): while the key tile is still below A's diagonal every wave runs the two-block tile body, after
+// it the one-block body on B alone - every wave of every workgroup does the same number of (16-row block x key tile)
+// units (pairs (last, first), (last-1, second) ...), and the K / V^T tile is staged once for both blocks.
+// Work item {qB0, qBn, qA0, qAn} (qAn == 0: no partner); keys [0, min(k_tokens, q + 1)); rows are sequence positions,
+// Q / O hold rows q_row0 .. q_row0 + Sq - 1 as in vis_attn_prefill_rows.  Same MFMA formulation, LDS images, online
+// softmax and bf16 rounding points as attn_prefill_kernel<128, true>; the summation order over key tiles is the same,
+// so a row's result is bit-identical to the unpaired kernel's.
+__global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
+  constexpr int HD = 128, DKF = 4, ND = 8, KCH = 16, KROW = 256;
+  constexpr int K_BYTES = 64 * KROW, V_BYTES = HD * 128, BUF = K_BYTES + V_BYTES;   // 16 KiB + 16 KiB
+  constexpr int OROW = HD * 2 + 16;
+  static_assert(2 * BUF >= 8 * 16 * OROW, "O staging (16 rows per wave per pass) must fit in the KV buffers");
+  __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, h = lane >> 4;
+  const int head = blockIdx.x, hkv = head / p.group;
+  const int4 wk = p.work[blockIdx.y];
+  // q-block 0 = heavy block B, q-block 1 = light block A
+  const int qblk0[2] = {wk.x, wk.z}, qblkn[2] = {wk.y, wk.w};
+  const int kend[2] = {min(p.k_tokens, wk.x + wk.y), min(p.k_tokens, wk.z + wk.w)};   // one past the last key of a block
+  const int nt = (kend[0] + 63) >> 6;
+  const int wrow0[2] = {wk.x + wave * 16, wk.z + wave * 16};            // first row of this wave in each block
+  const bool have[2] = {wave * 16 < wk.y, wk.w > 0 && wave * 16 < wk.w};
+
+  const bf16_t* Kh = p.K + (size_t)hkv * p.k_tokens * HD;
+  const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
+
+  bf16x8 qf[2][DKF];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int qrow = min(max(wrow0[qb] + l15, p.q_row0), p.q_row0 + p.Sq - 1) - p.q_row0;
+    const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
+#pragma unroll
+    for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ds * 32 + 8 * h));
+  }
+
+  // staging: K tile 64 rows x 16 chunks, V^T tile 128 rows x 8 chunks = 1024 16-byte slots each, 2 per thread
+  int k_goff[2], k_loff[2], k_row[2], v_goff[2], v_loff[2];
+  u32x4 kreg[2], vreg[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int it = tid + i * 512;
+    const int row = it >> 4, c = it & 15;
+    k_row[i] = row;
+    k_goff[i] = c * 8;
+    k_loff[i] = row * KROW + ((c ^ (row & 15)) << 4);
+    const int d = it >> 3, cv = it & 7;
+    v_goff[i] = d * p.vt_ld + cv * 8;
+    v_loff[i] = K_BYTES + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4);
+  }
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int key = min(kt + k_row[i], p.k_tokens - 1);
+      kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + k_goff[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vreg[i] = *(const u32x4*)(Vh + v_goff[i] + kt);
+  };
+  auto store_tile = [&](int buf) {
+    char* base = lds + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(base + k_loff[i]) = kreg[i];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(u32x4*)(base + v_loff[i]) = vreg[i];
+  };
+
+  f32x4 oacc[2][ND + 1];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float mrow[2] = {ATT_NEG, ATT_NEG};
+  const uint32_t one2 = (l15 == 0) ? 0x3f803f80u : 0u;
+  const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
+
+  if (nt > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int kt = t * 64;
+    const bool more = (t + 1 < nt);
+    if (more) load_tile(kt + 64);
+
+    // a 16-row block of this wave is live while the tile starts at or below its last row
+    const bool live0 = have[0] && kt <= wrow0[0] + 15;
+    const bool live1 = have[1] && kt <= wrow0[1] + 15;
+    auto tile_body = [&](auto nq_tag) {
+      constexpr int NQ = decltype(nq_tag)::value;
+      const char* kb = lds + cur * BUF;
+      const char* vb = kb + K_BYTES;
+      f32x4 sacc[4][NQ];
+      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < DKF; ++ds) {
+        bf16x8 kf[4];
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk) {
+          const int row = kbk * 16 + l15;
+          kf[kbk] = *(const bf16x8*)(kb + row * KROW + (((ds * 4 + h) ^ l15) << 4));
+        }
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+          for (int qb = 0; qb < NQ; ++qb)
+            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], ds == 0 ? zero4 : sacc[kbk][qb], 0, 0, 0);
+      }
+      float alpha[NQ];
+      bf16x8 pf[2][NQ];
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) {
+        const int q = wrow0[qb] + l15;
+        const bool need_mask = (kt + 63 > wrow0[qb]) || (kt + 64 > kend[qb]);
+        if (need_mask) {
+          const int kbase = kt + 4 * h;
+          int hi = min(kend[qb], q + 1) - kbase;
+          asm volatile("" : "+v"(hi));
+#pragma unroll
+          for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[kbk][qb][r] = (hi > 16 * kbk + r) ? sacc[kbk][qb][r] : ATT_NEG;
+        }
+        float mx = att_max3(sacc[0][qb][0], sacc[0][qb][1], sacc[0][qb][2]);
+        mx = att_max3(mx, sacc[0][qb][3], sacc[1][qb][0]);
+        mx = att_max3(mx, sacc[1][qb][1], sacc[1][qb][2]);
+        mx = att_max3(mx, sacc[1][qb][3], sacc[2][qb][0]);
+        mx = att_max3(mx, sacc[2][qb][1], sacc[2][qb][2]);
+        mx = att_max3(mx, sacc[2][qb][3], sacc[3][qb][0]);
+        mx = att_max3(mx, sacc[3][qb][1], sacc[3][qb][2]);
+        mx = att_max3(mx, sacc[3][qb][3], sacc[3][qb][3]);
+        mx = att_hmax4(mx);
+        const float mnew = att_max(mrow[qb], mx * p.scale_log2);
+        alpha[qb] = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
+        mrow[qb] = mnew;
+        float pv[4][4];
+#pragma unroll
+        for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[kbk][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          u32x4 pk;
+          pk[0] = pack2bf(pv[2 * ks][0], pv[2 * ks][1]);
+          pk[1] = pack2bf(pv[2 * ks][2], pv[2 * ks][3]);
+          pk[2] = pack2bf(pv[2 * ks + 1][0], pv[2 * ks + 1][1]);
+          pk[3] = pack2bf(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
+          pf[ks][qb] = __builtin_bit_cast(bf16x8, pk);
+        }
+      }
+      const bool resc = !__all((alpha[0] == 1.0f) && (alpha[NQ - 1] == 1.0f));
+      if (resc) {
+        asm volatile("" : "+v"(alpha[0]));
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(alpha[qb], 4 * h + r, 64);
+#pragma unroll
+            for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb][r] *= a;
+          }
+      }
+      const int vsw = (l15 >> 1) & 7;
+#pragma unroll
+      for (int nb = 0; nb < ND; ++nb) {
+        const char* vrow = vb + (nb * 16 + l15) * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 vf = *(const bf16x8*)(vrow + (((4 * ks + h) ^ vsw) << 4));
+#pragma unroll
+          for (int qb = 0; qb < NQ; ++qb)
+            oacc[qb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], vf, oacc[qb][nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb)
+          oacc[qb][ND] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], ones_frag, oacc[qb][ND], 0, 0, 0);
+    };
+    if (live1) tile_body(std::integral_constant<int, 2>{});        // A live implies B live (A lies before B)
+    else if (live0) tile_body(std::integral_constant<int, 1>{});
+
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- normalise and store: 16 rows per wave per pass through a wave-private staging area
+  char* ost = lds + wave * 16 * OROW;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    if (qb == 1) __syncthreads();          // (also keeps the two passes' LDS traffic apart)
+    if (!have[qb]) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float l = __shfl(oacc[qb][ND][r], 16 * h, 64);
+      const float a = (l > 0.f) ? 1.0f / l : 0.f;
+      const int row = 4 * h + r;
+#pragma unroll
+      for (int nb = 0; nb < ND; ++nb)
+        *(bf16_t*)(ost + row * OROW + (nb * 16 + l15) * 2) = f2bf(oacc[qb][nb][r] * a);
+    }
+    for (int it = lane; it < 16 * KCH; it += 64) {
+      const int row = it >> 4, c = it & 15;
+      const int q = wrow0[qb] + row;
+      if (q < qblk0[qb] + qblkn[qb]) {
+        const u32x4 o = *(const u32x4*)(ost + row * OROW + c * 16);
+        *(u32x4*)(p.O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
+      }
+    }
+  }
+}
+
+// Paired causal prefill (head_dim 128): work = n_work x int4 {qB0, qBn, qA0, qAn}, see attn_prefill_pair_kernel.
+extern "C" int vis_attn_prefill_pairs(const void* Q, const void* K, const void* Vt, void* O, const void* work,
+                                      int n_work, int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo,
+                                      float scale, int q_row0, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || q_row0 < 0) return VIS_ERR_ARG;
+  if (HD != 128) return VIS_ERR_ARG;
+  if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * HD || n_work > 65535) return VIS_ERR_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
+  AttnArgs p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.work = (const int4*)work;
+  p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.q_row0 = q_row0;
+  vis_clear_error();
+  hipLaunchKernelGGL(attn_prefill_pair_kernel, dim3(Hq, n_work), dim3(512), 0, stream, p);
+  return vis_check_launch();
 }
 
 // vis_attn_prefill with a row offset: the work items' query rows (and the causal rule key <= query) are positions of

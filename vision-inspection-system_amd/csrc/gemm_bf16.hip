@@ -1439,12 +1439,13 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
 // (LLM down projection: 9 x 14 = 126 tiles, K = 18944): `ksplit` K-slices run as independent 256x256 tiles
 // (126 x 2 = 252 workgroups), f32 partials go to `work` (ksplit x M x N floats), a second launch sums them and
 // applies bias / activation / residual.  SwiGLU is not supported here.
-extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* R, void* C, void* work,
-                                    int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act, int ksplit,
-                                    hipStream_t stream) {
-  if (!A || !W || !C || !work || M <= 0 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+static int gemm_splitk_launch(const void* A, const void* W, const void* bias, const void* R, void* C, void* work,
+                              int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act, int ksplit,
+                              bool finalize, hipStream_t stream) {
+  if (!A || !W || !work || M <= 0 || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (finalize && !C) return VIS_ERR_ARG;
   if (K % GEMM_BK != 0 || N % 8 != 0) return VIS_ERR_ARG;
-  if (lda % 8 != 0 || ldw % 8 != 0 || ldc % 8 != 0 || (R && ldr % 8 != 0)) return VIS_ERR_ARG;
+  if (lda % 8 != 0 || ldw % 8 != 0 || (finalize && (ldc % 8 != 0 || (R && ldr % 8 != 0)))) return VIS_ERR_ARG;
   if (act < ACT_NONE || act >= ACT_SWIGLU) return VIS_ERR_ARG;
   if (ksplit < 2 || ksplit > 8 || K / GEMM_BK < 2 * ksplit) return VIS_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)R | (uintptr_t)work) & 15) return VIS_ERR_ARG;
@@ -1471,8 +1472,23 @@ extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bi
   } else {
     hipLaunchKernelGGL(gemm_bf16_256xN_kernel<4>, dim3(p.tiles_m * p.tiles_n, ksplit), dim3(512), GEMM4_LDS_BYTES, stream, p);
   }
-  const long long total = (long long)M * (N / 8);
-  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(gemm_splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  if (finalize) {
+    const long long total = (long long)M * (N / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(gemm_splitk_finalize_kernel, dim3(blocks), dim3(256), 0, stream, p);
+  }
   return vis_check_launch();
+}
+
+extern "C" int vis_gemm_bf16_splitk(const void* A, const void* W, const void* bias, const void* R, void* C, void* work,
+                                    int M, int N, int K, int lda, int ldw, int ldc, int ldr, int act, int ksplit,
+                                    hipStream_t stream) {
+  return gemm_splitk_launch(A, W, bias, R, C, work, M, N, K, lda, ldw, ldc, ldr, act, ksplit, true, stream);
+}
+
+// The K-sliced tiles alone: work[ksplit][M][N] f32 partial sums of A * W^T; the caller finalises them
+// (vis_splitk_finalize_norm: sum + bias + residual fused with the next RMSNorm / LayerNorm).
+extern "C" int vis_gemm_bf16_splitk_part(const void* A, const void* W, void* work, int M, int N, int K, int lda, int ldw,
+                                         int ksplit, hipStream_t stream) {
+  return gemm_splitk_launch(A, W, nullptr, nullptr, nullptr, work, M, N, K, lda, ldw, 0, 0, ACT_NONE, ksplit, false, stream);
 }

@@ -81,6 +81,131 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict
   }
 }
 
+// Split-K finalisation fused with the NEXT norm (the row owner exists here: one wave per row):
+//   x[m] = bf16( sum_s part[s][m] + bias + R[m] )      (fixed slice order: bitwise reproducible)
+//   y[m] = norm(x[m]) * w (+ b)                         (statistics of the ROUNDED x, exactly what a separate
+//                                                         vis_rmsnorm_bf16 / vis_layernorm_bf16 of x would compute)
+// replaces gemm_splitk_finalize_kernel + norm_rows_kernel: one pass over the partials instead of a pass over the
+// partials and a read-modify-write pass over x.  y == NULL: finalisation only.
+template <bool LAYERNORM>
+__global__ __launch_bounds__(256) void finalize_norm_rows_kernel(const float* __restrict__ part, int ksplit, size_t slice,
+                                                                 const bf16_t* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ R, int ldr,
+                                                                 bf16_t* __restrict__ xo, int ldxo,
+                                                                 const bf16_t* __restrict__ w,
+                                                                 const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                                 int ldy, int rows, int N, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = N >> 3;
+  const float* pr = part + (size_t)row * N;
+  float v[NORM_MAX_CHUNKS][8];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float a[8];
+      *(f32x4*)a = *(const f32x4*)(pr + c * 8);
+      *(f32x4*)(a + 4) = *(const f32x4*)(pr + c * 8 + 4);
+      for (int ks = 1; ks < ksplit; ++ks) {
+        const f32x4 lo = *(const f32x4*)(pr + ks * slice + c * 8), hi = *(const f32x4*)(pr + ks * slice + c * 8 + 4);
+        a[0] += lo[0]; a[1] += lo[1]; a[2] += lo[2]; a[3] += lo[3];
+        a[4] += hi[0]; a[5] += hi[1]; a[6] += hi[2]; a[7] += hi[3];
+      }
+      if (bias) {
+        float f[8];
+        unpack8(*(const u32x4*)(bias + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += f[e];
+      }
+      if (R) {
+        float f[8];
+        unpack8(*(const u32x4*)(R + (size_t)row * ldr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += f[e];
+      }
+      const u32x4 packed = pack8(a);
+      *(u32x4*)(xo + (size_t)row * ldxo + c * 8) = packed;
+      unpack8(packed, v[i]);                    // the norm sees the rounded values
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s += v[i][e];
+        ss += v[i][e] * v[i][e];
+      }
+    }
+  }
+  if (!y) return;
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const float inv_n = 1.0f / (float)N;
+  float mean = 0.f, rstd;
+  if (LAYERNORM) {
+    mean = s * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mean;
+          d2 += d * d;
+        }
+      }
+    }
+    d2 = wave_sum(d2);
+    rstd = rsqrtf(d2 * inv_n + eps);
+  } else {
+    rstd = rsqrtf(ss * inv_n + eps);
+  }
+  bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float wv[8], o[8];
+      unpack8(*(const u32x4*)(w + c * 8), wv);
+      if (LAYERNORM) {
+        float bv[8];
+        unpack8(*(const u32x4*)(b + c * 8), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[i][e] * rstd)) * wv[e];
+      }
+      *(u32x4*)(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
+// part [ksplit][M][N] f32 (vis_gemm_bf16_splitk_part) -> x [M][ldx] bf16 = sum + bias + R, and (y != NULL)
+// y [M][ldy] = RMSNorm (norm_b == NULL) or LayerNorm of x.
+extern "C" int vis_splitk_finalize_norm(const void* part, int ksplit, const void* bias, const void* R, void* x,
+                                        const void* norm_w, const void* norm_b, void* y, int M, int N, int ldr, int ldx,
+                                        int ldy, float eps, hipStream_t stream) {
+  if (!part || !x || M <= 0 || N <= 0 || ksplit < 1 || ksplit > 8) return VIS_ERR_ARG;
+  if (N % 8 != 0 || N > 64 * 8 * NORM_MAX_CHUNKS || ldx % 8 != 0 || (R && ldr % 8 != 0)) return VIS_ERR_ARG;
+  if (y && (!norm_w || ldy % 8 != 0)) return VIS_ERR_ARG;
+  if (((uintptr_t)part | (uintptr_t)bias | (uintptr_t)R | (uintptr_t)x | (uintptr_t)norm_w | (uintptr_t)norm_b |
+       (uintptr_t)y) & 15)
+    return VIS_ERR_ARG;
+  const dim3 grid((M + 3) / 4), block(256);
+  const size_t slice = (size_t)M * N;
+  vis_clear_error();
+  if (norm_b)
+    hipLaunchKernelGGL(finalize_norm_rows_kernel<true>, grid, block, 0, stream, (const float*)part, ksplit, slice,
+                       (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)x, ldx, (const bf16_t*)norm_w,
+                       (const bf16_t*)norm_b, (bf16_t*)y, ldy, M, N, eps);
+  else
+    hipLaunchKernelGGL(finalize_norm_rows_kernel<false>, grid, block, 0, stream, (const float*)part, ksplit, slice,
+                       (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)x, ldx, (const bf16_t*)norm_w,
+                       (const bf16_t*)nullptr, (bf16_t*)y, ldy, M, N, eps);
+  return vis_check_launch();
+}
+
 static int norm_launch(bool ln, const void* x, const void* w, const void* b, void* y, int rows, int N,
                        int ldx, int ldy, float eps, hipStream_t stream) {
   if (!x || !w || !y || rows <= 0 || N <= 0) return VIS_ERR_ARG;

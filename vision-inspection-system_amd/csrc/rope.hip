@@ -17,7 +17,11 @@
 //             KV-cache layer here so prefill writes the cache in place)
 //          V  [Hkv][k_tokens][HD] at row k_pos0+s (optional row-major copy: KV cache)
 //          Vt [Hkv][HD][vt_ld]   (optional; keys contiguous - the PV operand
-//             layout of the prefill attention kernel; pad columns zeroed)
+//             layout of the prefill attention kernel; pad columns zeroed).
+//             Column order inside every aligned group of 32 keys: key 16 a + 4 h + r (a = 0..1, h = 0..3,
+//             r = 0..3) sits at column 8 h + 4 a + r - the k-slot order the attention kernel's P fragment
+//             has (two S^T accumulator blocks packed in-lane), so that a lane's 8 V values are ONE aligned
+//             16-byte chunk (a single ds_read_b128) instead of two 8-byte pieces 32 bytes apart.
 // HBM-bound: every qkv element is read once and written once (V twice).
 #include "common.hip.h"
 
@@ -94,10 +98,11 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p) {
         if (p.v) *(u32x4*)(p.v + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD + c * 8) = raw;
       }
       if (p.vt) {
+        const int tp = (t & 32) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);   // key -> V^T column
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          tile[(c * 8 + 2 * e) * VT_LD + t] = (bf16_t)(raw[e] & 0xffffu);
-          tile[(c * 8 + 2 * e + 1) * VT_LD + t] = (bf16_t)(raw[e] >> 16);
+          tile[(c * 8 + 2 * e) * VT_LD + tp] = (bf16_t)(raw[e] & 0xffffu);
+          tile[(c * 8 + 2 * e + 1) * VT_LD + tp] = (bf16_t)(raw[e] >> 16);
         }
       }
     }

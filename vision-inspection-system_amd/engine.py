@@ -212,9 +212,6 @@ class Qwen2VLEngine:
                 self.vq8.append({n: q8pad(getattr(b, n)) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w")})
         self.slot_prompt_len = [0] * Bm
         self._prefill_streams: List[torch.cuda.Stream] = []
-        self._vit_side_streams: List[torch.cuda.Stream] = []
-        self.vit_streams = int(os.environ.get("VIS_VIT_STREAMS", "1"))   # 2: row-split ViT on two streams (opt-in; measured slower)
-        self.vit_split_min_rows = 2048
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.min_shared_prefix = 256     # shorter common prefixes are not worth a separate pass
         self.temperature, self.seed = 0.0, 0
@@ -225,55 +222,6 @@ class Qwen2VLEngine:
         self.last_first_logits: Optional[torch.Tensor] = None
 
     # ------------------------------------------------------------------ vision tower
-    def _vit_blocks_two_streams(self, x, y, qkv, att, hmid, cos, sin, N: int, ld: int) -> None:
-        """The ViT blocks of ONE image as two row-halves on two HIP streams.  The GEMM grids of this tower are
-        ragged (M = 4900: 2.29 / 0.76 / 1.56 / 0.78 rounds of the chip for qkv / proj / fc1 / fc2), and within a layer
-        every kernel depends on the previous one, so a single stream idles through every partial last round
-        (~0.62 PFLOP/s over the tower's GEMMs against ~1.1 for full rounds).  Rows only interact in attention:
-        each half runs its own LN -> qkv -> rope/split -> attention -> proj -> LN -> fc1 -> fc2 chain, the only
-        cross-stream dependency per layer is "the other half's K/V^T of this layer are written" (one event), and
-        K / V^T are double-buffered over layers so the next layer's writes cannot overtake a reader.
-        MEASURED (MI355X, 1024^2 image): 53.9 ms prefill against 52.7 ms single-stream - the two halves run in
-        lockstep (same kernel at the same time, and the per-layer event re-aligns them), so their ragged rounds
-        coincide instead of filling each other; kept as an opt-in (VIS_VIT_STREAMS=2) and as a record.  Across
-        DIFFERENT images the same idea works (prefill_many: -9 %), because the chains drift apart."""
-        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
-        E, Hh, D = cfg.v_embed, cfg.v_heads, cfg.v_head_dim
-        Na = (N // 2) // 128 * 128
-        halves = [(0, Na), (Na, N)]
-        cur = torch.cuda.current_stream(dev)
-        if not self._vit_side_streams:
-            self._vit_side_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
-        S = self._vit_side_streams
-        k2 = torch.empty((2, Hh, N, D), dtype=bf, device=dev)
-        vt2 = torch.empty((2, Hh, D, ld), dtype=bf, device=dev)
-        qh = [torch.empty((Hh, r1 - r0, D), dtype=bf, device=dev) for r0, r1 in halves]
-        work = [torch.tensor([(q0, min(128, r1 - r0 - q0), 0, N) for q0 in range(0, r1 - r0, 128)], dtype=torch.int32,
-                             device=dev).reshape(-1, 4).contiguous() for r0, r1 in halves]
-        scale = D ** -0.5
-        for st in S:
-            st.wait_stream(cur)
-        for li, b in enumerate(w.vit):
-            kb, vb = k2[li & 1], vt2[li & 1]
-            ready = [torch.cuda.Event(), torch.cuda.Event()]
-            for h, (r0, r1) in enumerate(halves):
-                with torch.cuda.stream(S[h]):
-                    hip.layernorm(x[r0:r1], b.ln1_w, b.ln1_b, 1e-6, out=y[r0:r1])
-                    hip.gemm(y[r0:r1], b.qkv_w, bias=b.qkv_b, out=qkv[r0:r1])
-                    hip.qkv_rope_split(qkv[r0:r1], cos[r0:r1], sin[r0:r1], qh[h], kb, None, vb, Hh, Hh, D, k_pos0=r0,
-                                       vt_col0=r0)
-                    ready[h].record(S[h])
-            for h, (r0, r1) in enumerate(halves):
-                with torch.cuda.stream(S[h]):
-                    S[h].wait_event(ready[1 - h])
-                    hip.attn_prefill(qh[h], kb, vb, att[r0:r1], work[h], False, scale)
-                    hip.gemm(att[r0:r1], b.proj_w, bias=b.proj_b, residual=x[r0:r1], out=x[r0:r1])
-                    hip.layernorm(x[r0:r1], b.ln2_w, b.ln2_b, 1e-6, out=y[r0:r1])
-                    hip.gemm(y[r0:r1], b.fc1_w, bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid[r0:r1])
-                    hip.gemm(hmid[r0:r1], b.fc2_w, bias=b.fc2_b, residual=x[r0:r1], out=x[r0:r1])
-        for st in S:
-            cur.wait_stream(st)
-
     def vision_forward(self, frames: Sequence[torch.Tensor], split_rows: bool = True) -> torch.Tensor:
         """frames: uint8 device tensors [H, W, 3] (H, W multiples of 28) -> [n_image_tokens, hidden] bf16."""
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
@@ -321,6 +269,7 @@ class Qwen2VLEngine:
         att = (torch.zeros if padded else torch.empty)((N, E), dtype=bf, device=dev)     # pad rows are never written
         hmid = torch.empty((N, cfg.v_mlp), dtype=bf, device=dev)
         scale = D ** -0.5
+        merger_ln_done = False
         if self.vq8:
             # fp8 configuration: the four block projections on the fp8 MFMA, LayerNorm fused into the activation quantiser
             xq = torch.zeros((N, self.vepad), dtype=torch.uint8, device=dev)      # pad columns stay 0
@@ -337,19 +286,34 @@ class Qwen2VLEngine:
                 hip.gemm_fp8(xq, sx, *q8["fc1_w"], bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid)
                 hip.quant_rows_fp8(hmid, hq, sx)
                 hip.gemm_fp8(hq, sx, *q8["fc2_w"], bias=b.fc2_b, residual=x, out=x)
-        elif split_rows and len(frames) == 1 and N >= self.vit_split_min_rows and self.vit_streams == 2:
-            self._vit_blocks_two_streams(x, y, qkv, att, hmid, cos, sin, N, ld)
         else:
-            for b in w.vit:
-                hip.layernorm(x, b.ln1_w, b.ln1_b, 1e-6, out=y)
+            # fc2 (K = 5120, only 100 tiles of 256 x 256 at M = 4900) runs as two K-slices (200 workgroups) whose
+            # finalisation - sum + bias + residual - is fused with the NEXT LayerNorm (the next block's norm1, or the
+            # merger's ln_q after the last block): the row owner exists there, so the norm costs no pass of its own.
+            # The choice depends on the layer shape only, never on the row count (an image's features must not depend
+            # on what shares the batch).  VIS_VIT_FC2_SPLITK=0: plain fc2 GEMM + separate LayerNorm (A/B).
+            splitk = cfg.v_mlp >= 1024 and os.environ.get("VIS_VIT_FC2_SPLITK", "1") != "0"
+            swork = torch.empty(2 * N * E, dtype=torch.float32, device=dev) if splitk else None
+            nb = len(w.vit)
+            hip.layernorm(x, w.vit[0].ln1_w, w.vit[0].ln1_b, 1e-6, out=y)
+            for bi, b in enumerate(w.vit):
                 hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
                 hip.attn_prefill(q, k, vt, att, work, False, scale)
                 hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
                 hip.layernorm(x, b.ln2_w, b.ln2_b, 1e-6, out=y)
                 hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid)
-                hip.gemm(hmid, b.fc2_w, bias=b.fc2_b, residual=x, out=x)
-        hip.layernorm(x, w.merger_ln_w, w.merger_ln_b, 1e-6, out=y)
+                nw, nbias = (w.vit[bi + 1].ln1_w, w.vit[bi + 1].ln1_b) if bi + 1 < nb else (w.merger_ln_w, w.merger_ln_b)
+                if splitk:
+                    hip.gemm_splitk_part(hmid, b.fc2_w, swork, 2)
+                    hip.splitk_finalize_norm(swork, 2, x, bias=b.fc2_b, residual=x, norm_w=nw, norm_b=nbias, y_out=y,
+                                             eps=1e-6)
+                else:
+                    hip.gemm(hmid, b.fc2_w, bias=b.fc2_b, residual=x, out=x)
+                    hip.layernorm(x, nw, nbias, 1e-6, out=y)
+            merger_ln_done = True
+        if not merger_ln_done:
+            hip.layernorm(x, w.merger_ln_w, w.merger_ln_b, 1e-6, out=y)
         m = cfg.merge ** 2
         z = hip.gemm(y.view(N // m, E * m), w.merger_fc0_w, bias=w.merger_fc0_b, act=hip.ACT_GELU_ERF)
         out = hip.gemm(z, w.merger_fc2_w, bias=w.merger_fc2_b)
@@ -424,12 +388,18 @@ class Qwen2VLEngine:
             if taps is not None:
                 taps["image_embeds"] = img
         cos, sin = cos_t[P:S], sin_t[P:S]
-        if P:
+        # causal pass over rows P..S-1: 128-row query blocks paired latest-with-earliest, one pair per workgroup
+        # (hip.attn_prefill_pairs); VIS_ATTN_PAIRS=0 keeps one block per workgroup (A/B: same results, bit for bit)
+        pairs = os.environ.get("VIS_ATTN_PAIRS", "1") != "0"
+        if pairs:
+            work = hip.make_attn_pairs(P, S, dev)
+        elif P:
             items = [(q0, min(128, S - q0), 0, S) for q0 in range(P, S, 128)]
             items.sort(key=lambda it: -(it[0] + it[1]))
             work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
         else:
             work = hip.make_attn_work([(0, S)], True, dev)
+        self._causal_pairs = pairs
         ld = _round_up(S, 64)
         nq = (Hq + 2 * Hkv) * D
         y = torch.empty((n, H), dtype=bf, device=dev)
@@ -455,19 +425,27 @@ class Qwen2VLEngine:
         if self.prefill_dtype == "fp8":
             self._llm_layers_fp8(x, qkv, q, vt_all, att, act, cos, sin, kcache, vcache, work, n, taps, P)
         else:
+            hip.rmsnorm(x, w.llm[0].ln1_w, cfg.rms_eps, out=y)
             for li, lw in enumerate(w.llm):
                 vt = vt_all[li if per_layer_vt else 0]
-                hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=P, vt_col0=P)
-                hip.attn_prefill(q, kcache[li], vt, att, work, True, scale, q_row0=P)
+                if pairs:
+                    hip.attn_prefill_pairs(q, kcache[li], vt, att, work, scale, q_row0=P)
+                else:
+                    hip.attn_prefill(q, kcache[li], vt, att, work, True, scale, q_row0=P)
                 hip.gemm(att, lw.o_w, residual=x, out=x)
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
+                nxt = w.llm[li + 1].ln1_w if li + 1 < L else None      # the next layer's input norm rides on the finalisation
                 if splitk_work is not None:      # long K, too few 256x256 tiles for the chip: two K-slices per tile
-                    hip.gemm_splitk(act, lw.down_w, splitk_work, 2, residual=x, out=x)
+                    hip.gemm_splitk_part(act, lw.down_w, splitk_work, 2)
+                    hip.splitk_finalize_norm(splitk_work, 2, x, residual=x, norm_w=nxt, y_out=y if nxt is not None else None,
+                                             eps=cfg.rms_eps)
                 else:
                     hip.gemm(act, lw.down_w, residual=x, out=x)
+                    if nxt is not None:
+                        hip.rmsnorm(x, nxt, cfg.rms_eps, out=y)
                 if taps is not None and li == 0:
                     taps["layer0"] = x.clone()
         if collect_prefix:
@@ -506,7 +484,10 @@ class Qwen2VLEngine:
             hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln1_w, eps=cfg.rms_eps)
             hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=lw.qkv_b, out=qkv)
             hip.qkv_rope_split(qkv, cos, sin, q, kcache[li], vcache[li], vt, Hq, Hkv, D, k_pos0=P, vt_col0=P)
-            hip.attn_prefill(q, kcache[li], vt, att, work, True, scale, q_row0=P)
+            if self._causal_pairs:
+                hip.attn_prefill_pairs(q, kcache[li], vt, att, work, scale, q_row0=P)
+            else:
+                hip.attn_prefill(q, kcache[li], vt, att, work, True, scale, q_row0=P)
             hip.quant_rows_fp8(att, aq, sx)
             hip.gemm_fp8(aq, sx, *q8["o_w"], residual=x, out=x)
             hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln2_w, eps=cfg.rms_eps)

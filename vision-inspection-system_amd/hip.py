@@ -24,6 +24,8 @@ _SIGS = {
     "vis_abi_version": "",
     "vis_gemm_bf16": "ppppp" + "iiiiiiii" + "p",
     "vis_gemm_bf16_splitk": "pppppp" + "iiiiiiiii" + "p",
+    "vis_gemm_bf16_splitk_part": "ppp" + "iiiiii" + "p",
+    "vis_splitk_finalize_norm": "p" + "i" + "pppppp" + "iiiii" + "f" + "p",
     "vis_gemm_fp8": "pppppppp" + "iiiiiiiii" + "p",
     "vis_quant_rows_fp8": "ppppp" + "iiii" + "f" + "p",
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
@@ -31,6 +33,7 @@ _SIGS = {
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_attn_prefill_rows": "ppppp" + "iiiiiiiii" + "f" + "i" + "p",
+    "vis_attn_prefill_pairs": "ppppp" + "iiiiiiii" + "f" + "i" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_gemv_fp8w": "ppppppp" + "iiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
@@ -149,6 +152,38 @@ def gemm_splitk(a: torch.Tensor, w: torch.Tensor, work: torch.Tensor, ksplit: in
                                      residual.stride(0) if residual is not None else 0, act, ksplit, _stream())
     _check(rc, "vis_gemm_bf16_splitk")
     return out
+
+
+def gemm_splitk_part(a: torch.Tensor, w: torch.Tensor, work: torch.Tensor, ksplit: int = 2) -> torch.Tensor:
+    """The K-sliced tiles of gemm_splitk alone: work[:ksplit*M*N] (f32) = partial sums of a @ w.T per K slice."""
+    _bf16(a, "gemm a"); _bf16(w, "gemm w")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K or a.stride(1) != 1 or w.stride(1) != 1:
+        raise HipLibraryError("gemm_splitk_part: bad operands")
+    if work.dtype != torch.float32 or work.numel() < ksplit * M * N:
+        raise HipLibraryError("gemm_splitk_part: workspace too small")
+    rc = load().vis_gemm_bf16_splitk_part(_ptr(a), _ptr(w), _ptr(work), M, N, K, a.stride(0), w.stride(0), ksplit, _stream())
+    _check(rc, "vis_gemm_bf16_splitk_part")
+    return work
+
+
+def splitk_finalize_norm(work: torch.Tensor, ksplit: int, x_out: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                         residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+                         norm_b: Optional[torch.Tensor] = None, y_out: Optional[torch.Tensor] = None,
+                         eps: float = 1e-6) -> None:
+    """x_out = bf16(sum of the K-slice partials + bias + residual); y_out (optional) = RMSNorm (norm_b None) or LayerNorm
+    of x_out - one row pass instead of finalise + norm.  residual may alias x_out."""
+    M, N = x_out.shape
+    if work.dtype != torch.float32 or work.numel() < ksplit * M * N or x_out.stride(1) != 1:
+        raise HipLibraryError("splitk_finalize_norm: bad operands")
+    if y_out is not None and (norm_w is None or y_out.shape != x_out.shape or y_out.stride(1) != 1):
+        raise HipLibraryError("splitk_finalize_norm: bad norm operands")
+    rc = load().vis_splitk_finalize_norm(_ptr(work), ksplit, _ptr(bias), _ptr(residual), _ptr(x_out), _ptr(norm_w),
+                                         _ptr(norm_b), _ptr(y_out), M, N,
+                                         residual.stride(0) if residual is not None else 0, x_out.stride(0),
+                                         y_out.stride(0) if y_out is not None else 0, float(eps), _stream())
+    _check(rc, "vis_splitk_finalize_norm")
 
 
 def quant_rows_fp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scale: Optional[torch.Tensor] = None,
@@ -322,6 +357,16 @@ def make_attn_work(segments, causal: bool, device, block_q: int = 128, heads: in
     return torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
 
 
+def vt_key_order(n_cols: int, device=None) -> torch.Tensor:
+    """key_of_col [n_cols] (n_cols % 32 == 0): the key stored at every V^T column (ABI version 2: inside each aligned
+    group of 32 keys, key 16a + 4h + r sits at column 8h + 4a + r).  ``vt = v_transposed[..., vt_key_order(ld)]`` turns
+    a plainly transposed V into the layout vis_attn_prefill reads (vis_qkv_rope_split writes it directly)."""
+    if n_cols % 32:
+        raise HipLibraryError("vt_key_order: column count must be a multiple of 32")
+    c = torch.arange(n_cols, device=device)
+    return (c & ~31) | (((c >> 2) & 1) << 4) | (((c >> 3) & 3) << 2) | (c & 3)
+
+
 def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
                  causal: bool, scale: float, q_row0: int = 0) -> torch.Tensor:
     """q [Hq,S,HD], k [Hkv,T,HD], vt [Hkv,HD,ld] -> out [S, Hq*HD].  q_row0 > 0: q / out hold rows q_row0.. of a longer
@@ -338,6 +383,41 @@ def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.
     rc = load().vis_attn_prefill_rows(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
                                       S, T, vt.shape[2], out.stride(0), 1 if causal else 0, scale, int(q_row0), _stream())
     _check(rc, "vis_attn_prefill_rows")
+    return out
+
+
+def make_attn_pairs(q_start: int, q_end: int, device, block_q: int = 128) -> torch.Tensor:
+    """Work list of attn_prefill_pairs for the causal pass over query rows [q_start, q_end) of one sequence (keys from
+    0): the 128-row blocks are paired latest-with-earliest, so every workgroup - and every wave in it - covers the
+    same number of (16-row block x 64-key tile) units.  Items {qB0, qBn, qA0, qAn}; an odd middle block has qAn = 0."""
+    blocks = [(q0, min(block_q, q_end - q0)) for q0 in range(q_start, q_end, block_q)]
+    items = []
+    i, j = 0, len(blocks) - 1
+    while i < j:
+        items.append((blocks[j][0], blocks[j][1], blocks[i][0], blocks[i][1]))
+        i += 1
+        j -= 1
+    if i == j:
+        items.append((blocks[i][0], blocks[i][1], 0, 0))
+    return torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+
+
+def attn_prefill_pairs(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
+                       scale: float, q_row0: int = 0) -> torch.Tensor:
+    """Causal head_dim-128 prefill attention with paired query blocks (work from make_attn_pairs); same tensors and
+    results as attn_prefill(..., causal=True)."""
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
+    Hq, S, HD = q.shape
+    Hkv, T, _ = k.shape
+    if not (q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()):
+        raise HipLibraryError("attn_prefill_pairs: contiguous tensors required")
+    if HD != 128 or vt.shape[0] != Hkv or vt.shape[1] != HD or out.shape[0] != S or out.stride(1) != 1:
+        raise HipLibraryError("attn_prefill_pairs: bad shapes")
+    if work.dtype != torch.int32 or work.dim() != 2 or work.shape[1] != 4 or not work.is_contiguous():
+        raise HipLibraryError("attn_prefill_pairs: work must be int32 [n,4]")
+    rc = load().vis_attn_prefill_pairs(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
+                                       S, T, vt.shape[2], out.stride(0), scale, int(q_row0), _stream())
+    _check(rc, "vis_attn_prefill_pairs")
     return out
 
 

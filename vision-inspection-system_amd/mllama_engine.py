@@ -243,7 +243,7 @@ class MllamaEngine:
         x = torch.empty((S, H), dtype=bf, device=dev)
         hip.gather_rows(w.embed, torch.from_numpy(ids_np.astype(np.int32)).to(dev), x)
         cos, sin = self.cos_t[:S], self.sin_t[:S]
-        work = hip.make_attn_work([(0, S)], True, dev)
+        work = hip.make_attn_pairs(0, S, dev)        # causal self-attention: paired query blocks (hip.attn_prefill_pairs)
         ld = _round_up(S, 64)
         nq = (Hq + 2 * Hkv) * D
         y = torch.empty((S, H), dtype=bf, device=dev)
@@ -280,7 +280,7 @@ class MllamaEngine:
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, self.kcache[si], self.vcache[si], vt, Hq, Hkv, D, k_pos0=0)
-                hip.attn_prefill(q, self.kcache[si], vt, att, work, True, scale)
+                hip.attn_prefill_pairs(q, self.kcache[si], vt, att, work, scale)
                 hip.gemm(att, lw.o_w, residual=x, out=x)
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
