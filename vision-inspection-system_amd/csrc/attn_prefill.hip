@@ -148,11 +148,15 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
   int k_goff[K_ITERS], k_loff[K_ITERS], k_row[K_ITERS], v_goff[V_ITERS], v_loff[V_ITERS];
   u32x4 kreg[DMA ? 1 : K_ITERS], vreg[DMA ? 1 : V_ITERS];
   if constexpr (DMA) {
-    // LDS slot p = i * 256 + tid (16 bytes each, lane-linear per wave instruction).  K slot p holds chunk
-    // c ^ ((row >> 3) & 1) of row p / 10: rows r and r + 8 then land on different bank quads (dense 160-byte rows
+    // LDS slot p = i * 256 + tid (16 bytes each, lane-linear per wave instruction).  K slot p = (row p / 10, chunk c):
+    // chunks 0..7 (the ds_read_b128 fragments) are stored in place - with 160-byte rows the b128 lane groups
+    // {0-3, 12-15, 20-27} ... already hit 16 distinct 16-byte bank slots (rows 0-3 / 12-15 take the even slots with
+    // chunk c0, rows 4-11 the odd ones with c0 + 1); r02 PMC showed the former XOR on these chunks CAUSED 2-way
+    // conflicts (SQ_LDS_BANK_CONFLICT 1.6 x SQ_ACTIVE_INST_LDS).  Chunks 8, 9 (the 8-byte tail reads, two 32-lane
+    // groups) keep c ^ ((row >> 3) & 1): rows r and r + 8 then land on different bank quads (dense 160-byte rows
     // alone would collide two-way); V^T slot p holds chunk c ^ ((d >> 1) & 7) of row d = p / 8, as before.
-    // The source offsets are RECOMPUTED per tile (a dozen integer ops per DMA): kept as loop-invariant arrays they
-    // were spilled at 168 VGPRs, and every scratch reload forced an s_waitcnt vmcnt(0) between two DMAs.
+    // The per-lane source offsets (dk_off / dv_off below) are loop constants; they fit the 168-VGPR budget since the
+    // denominators left the MFMA pipe (MFMA_SUM == false for this head_dim).
 #pragma unroll
     for (int i = 0; i < K_ITERS; ++i) { k_row[i] = 0; k_goff[i] = 0; k_loff[i] = 0; }
 #pragma unroll
@@ -175,32 +179,48 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
     }
   }
   const int dma_base = __builtin_amdgcn_readfirstlane(tid >> 6) * 1024;
+  uint32_t dk_off[3], dv_off[3];
+  if constexpr (DMA) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int ps = i * 256 + tid;
+      const int r0 = (ps * 6554) >> 16;                 // ps / 10 for ps < 768
+      const int c = ps - r0 * 10, row = min(r0, 63);
+      dk_off[i] = (uint32_t)row * (HD * 2) + ((c < 8 ? c : (c ^ ((row >> 3) & 1))) << 4);
+      const int d = min(ps >> 3, HD - 1), cv = ps & 7;
+      dv_off[i] = (uint32_t)d * (uint32_t)(p.vt_ld * 2) + ((cv ^ ((d >> 1) & 7)) << 4);
+    }
+  }
   // global -> LDS of one 64-key tile (DMA), or global -> registers (the head_dim 128 path stores them later)
   auto load_tile = [&](int kt, int buf) {
     if constexpr (DMA) {
       char* base = lds + buf * BUF + dma_base;
-      int t = tid;
-      asm volatile("" : "+v"(t));   // opaque: the offsets below are recomputed here, not hoisted out of the loop
-      const char* kbase = (const char*)Kh;
+      // per-lane byte offsets inside a tile are loop constants (dk_off / dv_off, 6 VGPRs); only the wave-uniform tile
+      // base moves.  The ragged last tile of a head (rows past k_tokens) recomputes clamped K addresses instead.
       const char* vbase = (const char*)(Vh + kt);
+      if (kt + 64 <= p.k_tokens) {
+        const char* kbase = (const char*)Kh + (size_t)kt * (HD * 2);
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int ps = i * 256 + t;
-        const int r0 = (ps * 6554) >> 16;                 // ps / 10 for ps < 768
-        const int c = ps - r0 * 10, row = min(r0, 63);
-        const int key = min(kt + row, p.k_tokens - 1);
-        const uint32_t off = (uint32_t)key * (HD * 2) + ((c ^ ((row >> 3) & 1)) << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + off),
-                                         (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+        for (int i = 0; i < 3; ++i)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + dk_off[i]),
+                                           (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+      } else {
+        const char* kbase = (const char*)Kh;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          const int ps = i * 256 + tid;
+          const int r0 = (ps * 6554) >> 16;                 // ps / 10 for ps < 768
+          const int c = ps - r0 * 10, row = min(r0, 63);
+          const int key = min(kt + row, p.k_tokens - 1);
+          const uint32_t off = (uint32_t)key * (HD * 2) + ((c < 8 ? c : (c ^ ((row >> 3) & 1))) << 4);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + off),
+                                           (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
+        }
       }
 #pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int ps = i * 256 + t;
-        const int d = min(ps >> 3, HD - 1), cv = ps & 7;
-        const uint32_t off = (uint32_t)d * (uint32_t)(p.vt_ld * 2) + ((cv ^ ((d >> 1) & 7)) << 4);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + off),
+      for (int i = 0; i < 3; ++i)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + dv_off[i]),
                                          (__attribute__((address_space(3))) void*)(base + K_BYTES + i * 4096), 16, 0, 0);
-      }
     } else {
 #pragma unroll
       for (int i = 0; i < K_ITERS; ++i) {
@@ -225,12 +245,18 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
   // constant: B-operand lanes of column 0 hold 1.0), so the row sums come out of the MFMA pipe in the same
   // layout and with the same rescaling as O instead of costing one VALU add per score.  The denominator
   // therefore sums the bf16-rounded probabilities - exactly the weights P*V uses.
-  f32x4 oacc[2][ND + 1];
+  // head_dim 80 (VGPR-bound at three workgroups per CU) keeps the denominators as two f32 lane sums instead: that frees
+  // the ones fragment and the extra accumulator block (12 VGPRs), which is what lets the LDS-DMA source offsets stay in
+  // registers for the whole kernel (no per-tile address arithmetic, no scratch).
+  constexpr bool MFMA_SUM = (HD == 128);
+  constexpr int NACC = ND + (MFMA_SUM ? 1 : 0);
+  f32x4 oacc[2][NACC];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-    for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nb = 0; nb < NACC; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float mrow[2] = {ATT_NEG, ATT_NEG};
+  float lsum[2] = {0.f, 0.f};      // !MFMA_SUM: sum over this lane's keys (4 h-rows are added at the end)
   const uint32_t one2 = (l15 == 0) ? 0x3f803f80u : 0u;
   const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
 
@@ -263,7 +289,7 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
         for (int kbk = 0; kbk < 4; ++kbk) {
           const int row = kbk * 16 + l15;
           const int c = ds * 4 + h;
-          const int pc = (HD == 128) ? (c ^ l15) : (c ^ ((l15 >> 3) & 1));
+          const int pc = (HD == 128) ? (c ^ l15) : c;   // d = 80: dense 160-byte rows need no swizzle for b128 (see below)
           kf[kbk] = *(const bf16x8*)(kb + row * KROW + pc * 16);
         }
 #pragma unroll
@@ -337,6 +363,11 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
             const float e = att_exp2(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
             pv[kbk][r] = e;
           }
+        if constexpr (!MFMA_SUM) {
+          float t0 = (pv[0][0] + pv[0][1]) + (pv[0][2] + pv[0][3]), t1 = (pv[1][0] + pv[1][1]) + (pv[1][2] + pv[1][3]);
+          float t2 = (pv[2][0] + pv[2][1]) + (pv[2][2] + pv[2][3]), t3 = (pv[3][0] + pv[3][1]) + (pv[3][2] + pv[3][3]);
+          lsum[qb] = lsum[qb] * alpha[qb] + ((t0 + t1) + (t2 + t3));
+        }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u32x4 pk;
@@ -358,7 +389,7 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
           for (int r = 0; r < 4; ++r) {
             const float a = __shfl(alpha[qb], 4 * h + r, 64);
 #pragma unroll
-            for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb][r] *= a;
+            for (int nb = 0; nb < NACC; ++nb) oacc[qb][nb][r] *= a;
           }
       }
 
@@ -377,11 +408,13 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
           }
         }
       }
+      if constexpr (MFMA_SUM) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int qb = 0; qb < NQ; ++qb)
-          oacc[qb][ND] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], ones_frag, oacc[qb][ND], 0, 0, 0);
+          for (int qb = 0; qb < NQ; ++qb)
+            oacc[qb][ND] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[ks][qb], ones_frag, oacc[qb][ND], 0, 0, 0);
+      }
     };
     if (active) {
       if (HD != 80 || nqb == 2) tile_body(std::integral_constant<int, 2>{});
@@ -398,9 +431,12 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     if (qb >= nqb) break;
+    float ltot = 0.f;
+    if constexpr (!MFMA_SUM) ltot = hsum4(lsum[qb]);          // query l15's denominator, on all four of its lanes
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float l = __shfl(oacc[qb][ND][r], 16 * h, 64);  // column 0 of the ones block: row 4h+r's sum
+      // MFMA_SUM: column 0 of the ones block holds row 4h+r's sum; otherwise fetch query (4h + r)'s total from lane 4h+r
+      const float l = MFMA_SUM ? __shfl(oacc[qb][MFMA_SUM ? ND : 0][r], 16 * h, 64) : __shfl(ltot, 4 * h + r, 64);
       const float a = (l > 0.f) ? 1.0f / l : 0.f;
       const int row = qb * 16 + 4 * h + r;
 #pragma unroll
