@@ -39,44 +39,51 @@ struct RopeArgs {
   int vt_ld;     // row stride of Vt (multiple of 64, >= round_up(S, 64))
 };
 
+// Work decomposition (r02): the cos / sin rows are f32 and four times the bytes of the bf16 data they rotate, and the
+// first version (one workgroup per (64 tokens, head)) re-read them for every head: 2.9 TB/s of useful traffic.  Now
+//  * "rope" workgroups own 16 tokens and ALL q / k heads: a thread holds the cos / sin values of one (token, 8-dim
+//    pair-chunk) in registers and walks the heads (in HG interleaved groups), so a table row is read once per token;
+//  * "V" workgroups own (64 tokens, one kv head): row-major copy into the cache and the transposed tile through LDS
+//    (64 tokens = one 128-byte run of V^T columns).
+// Both kinds live in ONE launch: blocks [0, n_rope) are rope blocks, the rest V blocks.
 template <int HD>
-__global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p) {
+__global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p, int n_rope) {
   constexpr int HALF = HD / 2;
   constexpr int PC = HD / 16;  // pair-chunks per (token, head): 8 dims + their rotate_half partners
   constexpr int CH = HD / 8;   // 16-byte chunks per (token, head)
   constexpr int VT_LD = 64 + 8;
+  constexpr int HG = 256 / (16 * PC);   // head groups per workgroup: 2 (head_dim 128) / 3 (head_dim 80)
   __shared__ __attribute__((aligned(16))) bf16_t tile[HD * VT_LD];
   const int tid = threadIdx.x;
-  const int s0 = blockIdx.x * 64;
-  const int head = blockIdx.y;
-  const int ntok = min(64, p.S - s0);
 
-  if (head < p.Hq + p.Hkv) {
-    const bool is_q = head < p.Hq;
-    const int hh = is_q ? head : head - p.Hq;
-    for (int it = tid; it < 64 * PC; it += 256) {
-      const int t = it / PC, pc = it - t * PC;
-      if (t >= ntok) continue;
-      const int s = s0 + t;
-      const int d0 = pc * 8;
-      const bf16_t* src = p.qkv + (size_t)s * p.ld_qkv + head * HD;
-      float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
-      unpack8(*(const u32x4*)(src + d0), a);
-      unpack8(*(const u32x4*)(src + HALF + d0), b);
-      if (p.cosv) {
-        const float* cr = p.cosv + (size_t)s * HD;
-        const float* sr = p.sinv + (size_t)s * HD;
+  if ((int)blockIdx.x < n_rope) {
+    const int slot = tid % (16 * PC), hg = tid / (16 * PC);
+    const int t = slot / PC, pc = slot - t * PC;
+    const int s = blockIdx.x * 16 + t;
+    if (hg >= HG || s >= p.S) return;
+    const int d0 = pc * 8;
+    float ca[8], sa[8], cb[8], sb[8];
+    if (p.cosv) {
+      const float* cr = p.cosv + (size_t)s * HD;
+      const float* sr = p.sinv + (size_t)s * HD;
 #pragma unroll
-        for (int e = 0; e < 8; e += 4) {
-          *(f32x4*)(ca + e) = *(const f32x4*)(cr + d0 + e);
-          *(f32x4*)(sa + e) = *(const f32x4*)(sr + d0 + e);
-          *(f32x4*)(cb + e) = *(const f32x4*)(cr + HALF + d0 + e);
-          *(f32x4*)(sb + e) = *(const f32x4*)(sr + HALF + d0 + e);
-        }
-      } else {  // no rotary embedding (mllama vision tower, cross-attention q / k): pure head split
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 1.f; sa[e] = 0.f; sb[e] = 0.f; }
+      for (int e = 0; e < 8; e += 4) {
+        *(f32x4*)(ca + e) = *(const f32x4*)(cr + d0 + e);
+        *(f32x4*)(sa + e) = *(const f32x4*)(sr + d0 + e);
+        *(f32x4*)(cb + e) = *(const f32x4*)(cr + HALF + d0 + e);
+        *(f32x4*)(sb + e) = *(const f32x4*)(sr + HALF + d0 + e);
       }
+    } else {  // no rotary embedding (mllama vision tower, cross-attention q / k): pure head split
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 1.f; sa[e] = 0.f; sb[e] = 0.f; }
+    }
+    const bf16_t* row = p.qkv + (size_t)s * p.ld_qkv;
+    for (int head = hg; head < p.Hq + p.Hkv; head += HG) {
+      const bool is_q = head < p.Hq;
+      const int hh = is_q ? head : head - p.Hq;
+      float a[8], b[8], oa[8], ob[8];
+      unpack8(*(const u32x4*)(row + head * HD + d0), a);
+      unpack8(*(const u32x4*)(row + head * HD + HALF + d0), b);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         oa[e] = a[e] * ca[e] - b[e] * sa[e];  // first half: rotate_half gives -x2
@@ -87,32 +94,39 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p) {
       *(u32x4*)(dst + d0) = pack8(oa);
       *(u32x4*)(dst + HALF + d0) = pack8(ob);
     }
-  } else {
-    const int hh = head - p.Hq - p.Hkv;
-    for (int it = tid; it < 64 * CH; it += 256) {
-      const int t = it / CH, c = it - t * CH;
-      u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
-      if (t < ntok) {
-        const int s = s0 + t;
-        raw = *(const u32x4*)(p.qkv + (size_t)s * p.ld_qkv + head * HD + c * 8);
-        if (p.v) *(u32x4*)(p.v + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD + c * 8) = raw;
-      }
-      if (p.vt) {
-        const int tp = (t & 32) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);   // key -> V^T column
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          tile[(c * 8 + 2 * e) * VT_LD + tp] = (bf16_t)(raw[e] & 0xffffu);
-          tile[(c * 8 + 2 * e + 1) * VT_LD + tp] = (bf16_t)(raw[e] >> 16);
-        }
-      }
+    return;
+  }
+
+  // ---- V block: (64 tokens, kv head hh)
+  const int vb = blockIdx.x - n_rope;
+  const int nblk = (p.S + 63) / 64;
+  const int hh = vb / nblk;
+  const int s0 = (vb - hh * nblk) * 64;
+  const int head = p.Hq + p.Hkv + hh;
+  const int ntok = min(64, p.S - s0);
+  for (int it = tid; it < 64 * CH; it += 256) {
+    const int t = it / CH, c = it - t * CH;
+    u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
+    if (t < ntok) {
+      const int s = s0 + t;
+      raw = *(const u32x4*)(p.qkv + (size_t)s * p.ld_qkv + head * HD + c * 8);
+      if (p.v) *(u32x4*)(p.v + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD + c * 8) = raw;
     }
     if (p.vt) {
-      __syncthreads();
-      for (int it = tid; it < HD * 8; it += 256) {
-        const int d = it >> 3, c = it & 7;
-        const u32x4 o = *(const u32x4*)(tile + d * VT_LD + c * 8);
-        *(u32x4*)(p.vt + ((size_t)hh * HD + d) * p.vt_ld + s0 + c * 8) = o;
+      const int tp = (t & 32) | (((t >> 2) & 3) << 3) | (((t >> 4) & 1) << 2) | (t & 3);   // key -> V^T column
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tile[(c * 8 + 2 * e) * VT_LD + tp] = (bf16_t)(raw[e] & 0xffffu);
+        tile[(c * 8 + 2 * e + 1) * VT_LD + tp] = (bf16_t)(raw[e] >> 16);
       }
+    }
+  }
+  if (p.vt) {
+    __syncthreads();
+    for (int it = tid; it < HD * 8; it += 256) {
+      const int d = it >> 3, c = it & 7;
+      const u32x4 o = *(const u32x4*)(tile + d * VT_LD + c * 8);
+      *(u32x4*)(p.vt + ((size_t)hh * HD + d) * p.vt_ld + s0 + c * 8) = o;
     }
   }
 }
@@ -136,12 +150,14 @@ extern "C" int vis_qkv_rope_split(const void* qkv, const void* cosv, const void*
   p.q = (bf16_t*)q; p.k = (bf16_t*)k; p.v = (bf16_t*)v; p.vt = (bf16_t*)vt;
   p.S = S; p.ld_qkv = ld_qkv; p.Hq = Hq; p.Hkv = Hkv;
   p.k_tokens = k_tokens; p.k_pos0 = k_pos0; p.vt_ld = vt_ld;
-  const dim3 grid((S + 63) / 64, Hq + 2 * Hkv), block(256);
+  const int n_rope = (S + 15) / 16;                                   // rope blocks: 16 tokens x all q / k heads
+  const int n_v = (v || vt) ? ((S + 63) / 64) * Hkv : 0;              // V blocks: (64 tokens, kv head)
+  const dim3 grid(n_rope + n_v), block(256);
   vis_clear_error();
   if (HD == 128)
-    hipLaunchKernelGGL(qkv_rope_split_kernel<128>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(qkv_rope_split_kernel<128>, grid, block, 0, stream, p, n_rope);
   else
-    hipLaunchKernelGGL(qkv_rope_split_kernel<80>, grid, block, 0, stream, p);
+    hipLaunchKernelGGL(qkv_rope_split_kernel<80>, grid, block, 0, stream, p, n_rope);
   return vis_check_launch();
 }
 

@@ -216,6 +216,9 @@ class Qwen2VLEngine:
         self.min_shared_prefix = 256     # shorter common prefixes are not worth a separate pass
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._rope_cache: Dict[tuple, tuple] = {}
+        self._pairs_cache: Dict[tuple, torch.Tensor] = {}
+        self._vis_work_cache: Dict[tuple, torch.Tensor] = {}
         self.prompt_len = 0
         self._decoded = 0
         self.decode_limit = 0
@@ -259,7 +262,11 @@ class Qwen2VLEngine:
                 self._vis_rope_cache.pop(next(iter(self._vis_rope_cache)))
         cos, sin = self._vis_rope_cache[key]
         segs = [(r0, r0 + c) for r0, c in zip(starts, counts)]
-        work = hip.make_attn_work(segs, False, dev, heads=Hh)
+        work = self._vis_work_cache.get(tuple(segs))
+        if work is None:
+            if len(self._vis_work_cache) >= 16:
+                self._vis_work_cache.clear()
+            work = self._vis_work_cache[tuple(segs)] = hip.make_attn_work(segs, False, dev, heads=Hh)
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
@@ -351,14 +358,28 @@ class Qwen2VLEngine:
         if ids_np.min() < 0 or ids_np.max() >= cfg.vocab:
             raise ValueError("token id out of range")
         grids = [(1, f.shape[0] // cfg.patch, f.shape[1] // cfg.patch) for f in frames]
-        pos3, next_pos = rope_index(cfg, ids_np, grids)
-        cos_np, sin_np = mrope_cos_sin(cfg, pos3)
         # decode rows: slot S + t carries rope position next_pos + t on all three axes
         n_dec = self.max_ctx - S if max_new_tokens is None else min(self.max_ctx - S, max_new_tokens + 1)
-        dpos = np.broadcast_to((next_pos + np.arange(n_dec))[None, :], (3, n_dec))
-        dcos, dsin = mrope_cos_sin(cfg, dpos)
-        cos_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([cos_np, dcos])), non_blocking=True)
-        sin_t[:S + n_dec].copy_(torch.from_numpy(np.concatenate([sin_np, dsin])), non_blocking=True)
+        # The M-RoPE tables (and the image-token scatter index) depend only on WHERE the image tokens sit, not on the
+        # text: the images of a batch inspection - and every request with the same prompt template and frame size -
+        # share them, so they are built once (host trigonometry + H2D) and kept on the device.
+        is_img = ids_np == cfg.image_token_id
+        key = (S, n_dec, tuple(grids), bool(is_img[0]), np.flatnonzero(np.diff(is_img.view(np.int8))).tobytes())
+        hit = self._rope_cache.get(key)
+        if hit is None:
+            pos3, next_pos = rope_index(cfg, ids_np, grids)
+            cos_np, sin_np = mrope_cos_sin(cfg, pos3)
+            dpos = np.broadcast_to((next_pos + np.arange(n_dec))[None, :], (3, n_dec))
+            dcos, dsin = mrope_cos_sin(cfg, dpos)
+            img_idx = np.nonzero(is_img)[0].astype(np.int32)
+            hit = (torch.from_numpy(np.concatenate([cos_np, dcos])).to(dev), torch.from_numpy(np.concatenate([sin_np, dsin])).to(dev),
+                   torch.from_numpy(img_idx).to(dev))
+            if len(self._rope_cache) >= 16:
+                self._rope_cache.pop(next(iter(self._rope_cache)))
+            self._rope_cache[key] = hit
+        cos_t[:S + n_dec].copy_(hit[0], non_blocking=True)
+        sin_t[:S + n_dec].copy_(hit[1], non_blocking=True)
+        img_idx_dev = hit[2]
         if slot == 0:
             self.decode_limit = S + n_dec
         if ids_dev is None:
@@ -381,10 +402,9 @@ class Qwen2VLEngine:
             # image_embeds: the merged ViT output of these frames computed elsewhere (prefill_many batches the tower
             # over several requests' images)
             img = image_embeds if image_embeds is not None else self.vision_forward(frames, split_rows=split_vit)
-            idx = np.nonzero(ids_np == cfg.image_token_id)[0].astype(np.int32) - P
-            if idx.shape[0] != img.shape[0]:
-                raise ValueError(f"image tokens ({idx.shape[0]}) and image features ({img.shape[0]}) do not match")
-            hip.scatter_rows(img, torch.from_numpy(idx).to(dev), x)
+            if img_idx_dev.shape[0] != img.shape[0]:
+                raise ValueError(f"image tokens ({img_idx_dev.shape[0]}) and image features ({img.shape[0]}) do not match")
+            hip.scatter_rows(img, (img_idx_dev - P) if P else img_idx_dev, x)
             if taps is not None:
                 taps["image_embeds"] = img
         cos, sin = cos_t[P:S], sin_t[P:S]
@@ -392,7 +412,11 @@ class Qwen2VLEngine:
         # (hip.attn_prefill_pairs); VIS_ATTN_PAIRS=0 keeps one block per workgroup (A/B: same results, bit for bit)
         pairs = os.environ.get("VIS_ATTN_PAIRS", "1") != "0"
         if pairs:
-            work = hip.make_attn_pairs(P, S, dev)
+            work = self._pairs_cache.get((P, S))
+            if work is None:
+                if len(self._pairs_cache) >= 64:
+                    self._pairs_cache.clear()
+                work = self._pairs_cache[(P, S)] = hip.make_attn_pairs(P, S, dev)
         elif P:
             items = [(q0, min(128, S - q0), 0, S) for q0 in range(P, S, 128)]
             items.sort(key=lambda it: -(it[0] + it[1]))
