@@ -232,6 +232,11 @@ int vis_add_rows_bf16(void* x, const void* table, const void* idx, int n, int D,
 int vis_decode_cross_attn(const void* q, const void* q_norm_w, const void* k, const void* v, const void* nkeys_m1,
                           void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int key_tokens,
                           int nsplit, float scale, float eps, vis_stream_t stream);
+/* Batch form: sequence b uses q + b * q_bs, k / v + b * kv_bs (element strides) and nkeys_m1[b]; out [batch][Hq*128]. */
+int vis_decode_cross_attn_batch(const void* q, const void* q_norm_w, const void* k, const void* v,
+                                const void* nkeys_m1, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
+                                int key_tokens, int nsplit, float scale, float eps, int batch, long long q_bs,
+                                long long kv_bs, vis_stream_t stream);
 
 /* Row f4: pixel statistics of the image-quality pre-check (src/safety/image_quality.py:42-56,:118-127): exact integer
  * sums over the RGB frame - stats[0] = sum gray, stats[1] = sum Laplacian, stats[2] = sum Laplacian^2 (int64[3]) with

@@ -106,3 +106,34 @@ def test_graph_replay_equals_eager_and_text_only(setup, device):
     assert _check_tokens(toks, ref_toks, ref_logits) >= 4
     with pytest.raises(ValueError):
         eng.prefill(ids, None)                        # image token without a frame
+
+
+def test_batched_decode_matches_single_and_is_batch_invariant(device):
+    """verify_many path: several images share ONE decode loop (stream-K batched projections, batched
+    self- and cross-attention).  A request's tokens do not depend on its slot, on the batch size or on what shares the
+    batch (exact); graph replay == eager; against the single-sequence GEMV path the first token (same prompt pass) is
+    exact and the rest agree up to genuine near-ties of the oracle (different f32 summation order)."""
+    from oracle import mllama_ref as R
+    from test_oracle_mllama import ref_cfg
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    from vision_inspection_system_amd.mllama_weights import MllamaConfig, pack_device_weights, synth_state_dict
+    cfg = MllamaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = MllamaEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=5)
+    g = np.load(os.path.join(HERE, "golden", "mllama_tiny.npz"))
+    reqs = [(g[f"{c}_ids"].tolist(), torch.from_numpy(g[f"{c}_image"]).to(device)) for c in "abc"]
+    singles = [eng.generate(ids, fr, max_new_tokens=10, stop_on_eos=False) for ids, fr in reqs]
+    eager = eng.generate_batch(reqs + [reqs[0], reqs[2]], max_new_tokens=10, stop_on_eos=False, use_graph=False)
+    graph = eng.generate_batch(reqs + [reqs[0], reqs[2]], max_new_tokens=10, stop_on_eos=False, use_graph=True)
+    assert eager == graph and [len(t) for t in graph] == [10] * 5
+    assert graph[0] == graph[3] and graph[2] == graph[4]                     # same request, different slots
+    other = eng.generate_batch([reqs[2], reqs[0]], max_new_tokens=10, stop_on_eos=False)
+    assert other == [graph[2], graph[0]]                                     # other batch size / order / neighbours
+    for b, (ids, fr) in enumerate(reqs):
+        assert graph[b][0] == singles[b][0]
+        ref_toks, ref_logits = R.generate(ref_cfg(cfg), sd, ids, fr.cpu().numpy(), 10)
+        _check_tokens(graph[b], ref_toks, ref_logits)
+        _check_tokens(singles[b], ref_toks, ref_logits)
+    # a text-only request cannot join a batch (the batched step always runs the cross layers)
+    with pytest.raises(ValueError):
+        eng.generate_batch([reqs[0], ([1, 5, 6, 7], None)], max_new_tokens=4)

@@ -13,10 +13,11 @@ ap.add_argument("--prompt-tokens", type=int, default=700)
 ap.add_argument("--new-tokens", type=int, default=128)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--model", default="11b", choices=["11b", "tiny"])
+ap.add_argument("--batch", type=int, default=1, help="> 1: that many images per step, per-image prompt pass + ONE shared decode loop")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = MllamaConfig.mllama_11b() if a.model == "11b" else MllamaConfig.tiny()
-eng = MllamaEngine(cfg, random_device_weights(cfg, dev, 0), dev, max_ctx=2048 if a.model == "11b" else 1024)
+eng = MllamaEngine(cfg, random_device_weights(cfg, dev, 0), dev, max_ctx=2048 if a.model == "11b" else 1024, max_batch=a.batch)
 rng = np.random.default_rng(0)
 side = 1024 if a.model == "11b" else 100
 frame = torch.from_numpy(rng.integers(0, 256, (side, side, 3), dtype=np.uint8)).to(dev)
@@ -25,9 +26,17 @@ res = []
 for it in range(a.steps + 1):
     s, m, e = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     s.record()
-    eng.prefill(ids, frame)
-    m.record()
-    eng.decode(a.new_tokens - 1, use_graph=True)
+    if a.batch > 1:
+        for b in range(a.batch):
+            eng.prefill(ids, frame, slot=b)
+        m.record()
+        g = eng._ensure_graph_batched(a.batch)
+        for _ in range(a.new_tokens - 1):
+            g.replay()
+    else:
+        eng.prefill(ids, frame)
+        m.record()
+        eng.decode(a.new_tokens - 1, use_graph=True)
     e.record()
     torch.cuda.synchronize()
     if it:
@@ -36,5 +45,5 @@ pre = float(np.mean([r[0] for r in res])); dec = float(np.mean([r[1] for r in re
 wbytes = sum(t.numel() * 2 for lw in eng.w.layers for t in (lw.qkv_w, lw.o_w, lw.gateup_w, lw.down_w) if t is not None) + eng.w.lm_head.numel() * 2
 print(json.dumps({"model": cfg.name, "prompt_tokens": len(ids), "vision_tokens": eng.TP, "new_tokens": a.new_tokens,
                   "prefill_ms": pre, "decode_ms": dec, "ms_per_token": dec / (a.new_tokens - 1),
-                  "images_per_s": 1000.0 / (pre + dec),
+                  "batch": a.batch, "images_per_s": 1000.0 * a.batch / (pre + dec), "prefill_ms_per_image": pre / a.batch,
                   "decode_weight_GBps": wbytes / (dec / (a.new_tokens - 1) * 1e-3) / 1e9}))

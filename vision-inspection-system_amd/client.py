@@ -98,7 +98,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
             return _ENGINES[key]
         max_ctx = int(os.environ.get("VIS_MAX_CTX", "4096"))
         max_batch = max(1, min(64, int(os.environ.get("VIS_MAX_BATCH", "64"))))
-        mllama = _load_mllama(model_id, device, max_ctx)
+        mllama = _load_mllama(model_id, device, max_ctx, max_batch)
         if mllama is not None:
             _ENGINES[key] = mllama
             return mllama
@@ -133,7 +133,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
         return lm
 
 
-def _load_mllama(model_id: str, device, max_ctx: int) -> Optional[LoadedModel]:
+def _load_mllama(model_id: str, device, max_ctx: int, max_batch: int = 1) -> Optional[LoadedModel]:
     """mllama family (synthetic:mllama-tiny[:seed], synthetic:mllama-11b, or a local directory whose config.json
     says model_type "mllama"); None when ``model_id`` is not an mllama model."""
     import json
@@ -153,7 +153,7 @@ def _load_mllama(model_id: str, device, max_ctx: int) -> Optional[LoadedModel]:
         else:
             raise ValueError(f"unknown synthetic model {parts[1]!r}")
         tok = LlamaByteTokenizer(cfg.vocab, cfg.image_token_id, cfg.eos_ids)
-        return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx), tok, cfg, model_id, "mllama")
+        return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch), tok, cfg, model_id, "mllama")
     path = resolve_model_dir(model_id)
     if path is None or not os.path.exists(os.path.join(path, "config.json")):
         return None
@@ -163,7 +163,7 @@ def _load_mllama(model_id: str, device, max_ctx: int) -> Optional[LoadedModel]:
     cfg = MW.config_from_hf_dir(path)
     w = MW.load_safetensors_dir(cfg, path, device)
     tok = LlamaHFTokenizer(path, cfg.image_token_id, cfg.eos_ids)
-    return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx), tok, cfg, model_id, "mllama")
+    return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch), tok, cfg, model_id, "mllama")
 
 
 def drop_models() -> None:
@@ -259,7 +259,7 @@ class LocalVLMClient:
         temp = float(temperature) if temperature else 0.0
         out: List[ChatCompletion] = []
         if lm.family == "mllama":
-            return [self._complete_mllama(lm, m, temp, max_new) for m in batch_of_messages]
+            return self._complete_mllama_many(lm, batch_of_messages, temp, max_new)
         prepared = [self._prepare(lm, m) for m in batch_of_messages]
         with eng.lock:
             for i in range(0, len(prepared), eng.max_batch):
@@ -276,11 +276,10 @@ class LocalVLMClient:
         return out
 
 
-    def _complete_mllama(self, lm, messages, temp: float, max_new: int) -> ChatCompletion:
-        """One request through the mllama engine: the JPEG is decoded on the host, the tile canvas is chosen on the
-        host, bilinear resample / normalise / patchify and everything after run on the GPU."""
+    def _prepare_mllama(self, lm, messages):
+        """messages -> (token ids, decoded uint8 RGB frame or None).  The JPEG is decoded on the host, the tile canvas is
+        chosen on the host; bilinear resample / normalise / patchify and everything after run on the GPU."""
         import numpy as np
-        import torch
         from .image_processing import decode_data_uri
         from .tokenizer import build_llama_chat_ids
         frames = []
@@ -293,14 +292,34 @@ class LocalVLMClient:
                         frames.append(np.array(decode_data_uri(url), dtype=np.uint8))
         if len(frames) > 1:
             raise ValueError("the mllama backend takes one image per request (what the reference sends)")
-        ids = build_llama_chat_ids(lm.tokenizer, messages, len(frames))
-        eng = lm.engine
+        return build_llama_chat_ids(lm.tokenizer, messages, len(frames)), (frames[0] if frames else None)
+
+    def _complete_mllama_many(self, lm, batch_of_messages, temp: float, max_new: int) -> List[ChatCompletion]:
+        """Requests with an image share ONE decode loop in groups of the engine's max_batch (MllamaEngine.generate_batch:
+        per-request prompt pass, weights streamed once per generated token for the whole group); text-only requests
+        (the agents' health check) take the single-sequence path."""
+        import torch
+        eng, tok = lm.engine, lm.tokenizer
+        prepared = [self._prepare_mllama(lm, m) for m in batch_of_messages]
+        toks_out: List[Optional[List[int]]] = [None] * len(prepared)
+        ignore_eos = os.environ.get("VIS_IGNORE_EOS") == "1"
         with eng.lock:
-            frame = torch.from_numpy(frames[0]).to(eng.device) if frames else None
-            toks = eng.generate(ids, frame, max_new_tokens=max_new, temperature=temp, seed=self.seed)
-        return ChatCompletion([_Choice(_Message(lm.tokenizer.decode(toks)))], model=lm.model_id,
-                              usage={"prompt_tokens": len(ids), "completion_tokens": len(toks),
-                                     "total_tokens": len(ids) + len(toks)})
+            with_img = [i for i, (_, f) in enumerate(prepared) if f is not None]
+            for g0 in range(0, len(with_img), eng.max_batch):
+                grp = with_img[g0:g0 + eng.max_batch]
+                reqs = [(prepared[i][0], torch.from_numpy(prepared[i][1]).to(eng.device)) for i in grp]
+                outs = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed,
+                                          stop_on_eos=not ignore_eos)
+                for i, t in zip(grp, outs):
+                    toks_out[i] = t
+            for i, (ids, f) in enumerate(prepared):
+                if f is None:
+                    toks_out[i] = eng.generate(ids, None, max_new_tokens=max_new, temperature=temp, seed=self.seed,
+                                               stop_on_eos=not ignore_eos)
+        return [ChatCompletion([_Choice(_Message(tok.decode(t)))], model=lm.model_id,
+                               usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
+                                      "total_tokens": len(ids) + len(t)})
+                for (ids, _), t in zip(prepared, toks_out)]
 
 
 _MOCK_REPLY: List[Optional[Any]] = [None]

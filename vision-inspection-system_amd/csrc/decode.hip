@@ -774,14 +774,16 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
 // Cross-attention of one new token over a static key/value set (mllama cross layers, decode): q [Hq*128] straight
 // from the q projection (q_norm applied inside), keys/values [Hkv][key_tokens][128] written once per request by
 // the prefill; *nkeys_m1 (device int) = number of valid keys - 1.  Same split/combine machinery as vis_decode_attn.
-extern "C" int vis_decode_cross_attn(const void* q, const void* q_norm_w, const void* k, const void* v,
-                                     const void* nkeys_m1, void* part_o, void* part_ml, void* out, int Hq, int Hkv,
-                                     int HD, int key_tokens, int nsplit, float scale, float eps, hipStream_t stream) {
+static int decode_cross_attn_impl(const void* q, const void* q_norm_w, const void* k, const void* v,
+                                  const void* nkeys_m1, void* part_o, void* part_ml, void* out, int Hq, int Hkv,
+                                  int HD, int key_tokens, int nsplit, float scale, float eps, int batch, long long q_bs,
+                                  long long kv_bs, hipStream_t stream) {
   if (!q || !q_norm_w || !k || !v || !nkeys_m1 || !part_o || !part_ml || !out) return VIS_ERR_ARG;
   if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
   const int G = Hq / Hkv;
   if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;
   if (nsplit <= 0 || nsplit > 256 || key_tokens <= 0 || (long long)nsplit * DA_MAXKEYS < key_tokens) return VIS_ERR_ARG;
+  if (batch <= 0 || batch > 64 || (batch > 1 && (q_bs <= 0 || kv_bs <= 0)) || (q_bs % 8) || (kv_bs % 8)) return VIS_ERR_ARG;
   if (((uintptr_t)k | (uintptr_t)v) & 15) return VIS_ERR_ARG;
   DecAttnArgs p;
   p.qkv = (const bf16_t*)q; p.cos_t = nullptr; p.sin_t = nullptr;
@@ -789,9 +791,26 @@ extern "C" int vis_decode_cross_attn(const void* q, const void* q_norm_w, const 
   p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
   p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = key_tokens; p.nsplit = nsplit;
   p.scale_log2 = scale * 1.4426950408889634f;
-  p.qkv_bs = 0; p.cache_bs = 0; p.tab_bs = 0;
+  p.qkv_bs = q_bs; p.cache_bs = kv_bs; p.tab_bs = 0;
   p.q_norm_w = (const bf16_t*)q_norm_w; p.q_eps = eps;
-  return decode_attn_launch(p, out, 1, stream);
+  return decode_attn_launch(p, out, batch, stream);
+}
+
+extern "C" int vis_decode_cross_attn(const void* q, const void* q_norm_w, const void* k, const void* v,
+                                     const void* nkeys_m1, void* part_o, void* part_ml, void* out, int Hq, int Hkv,
+                                     int HD, int key_tokens, int nsplit, float scale, float eps, hipStream_t stream) {
+  return decode_cross_attn_impl(q, q_norm_w, k, v, nkeys_m1, part_o, part_ml, out, Hq, Hkv, HD, key_tokens, nsplit, scale,
+                                eps, 1, 0, 0, stream);
+}
+
+// Batch form (mllama batched decode): sequence b reads q + b * q_bs, its own static keys / values k, v + b * kv_bs
+// (element strides) and nkeys_m1[b]; out [batch][Hq * 128]; workspaces sized batch x the single-sequence ones.
+extern "C" int vis_decode_cross_attn_batch(const void* q, const void* q_norm_w, const void* k, const void* v,
+                                           const void* nkeys_m1, void* part_o, void* part_ml, void* out, int Hq,
+                                           int Hkv, int HD, int key_tokens, int nsplit, float scale, float eps,
+                                           int batch, long long q_bs, long long kv_bs, hipStream_t stream) {
+  return decode_cross_attn_impl(q, q_norm_w, k, v, nkeys_m1, part_o, part_ml, out, Hq, Hkv, HD, key_tokens, nsplit, scale,
+                                eps, batch, q_bs, kv_bs, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -49,6 +49,7 @@ _SIGS = {
     "vis_patchify_tiles_u8": "pp" + "iiiiii" + "pp" + "p",
     "vis_add_rows_bf16": "ppp" + "iiii" + "p",
     "vis_decode_cross_attn": "pppppppp" + "iiiii" + "ff" + "p",
+    "vis_decode_cross_attn_batch": "pppppppp" + "iiiii" + "ff" + "ill" + "p",
     "vis_image_stats_u8": "p" + "ii" + "p" + "p",
     "vis_gather_rows": "ppp" + "iii" + "p",
     "vis_scatter_rows": "ppp" + "iii" + "p",
@@ -699,6 +700,27 @@ def decode_cross_attn(q: torch.Tensor, q_norm_w: torch.Tensor, k: torch.Tensor, 
                                       _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, k.shape[1], nsplit, scale, eps,
                                       _stream())
     _check(rc, "vis_decode_cross_attn")
+
+
+def decode_cross_attn_batch(q: torch.Tensor, q_norm_w: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                            nkeys_m1: torch.Tensor, part_o: torch.Tensor, part_ml: torch.Tensor, out: torch.Tensor,
+                            n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float, eps: float) -> None:
+    """Batch of B new tokens, each over ITS OWN static keys/values: q [B, Hq*128], k / v [B, Hkv, T, 128] (any batch
+    stride), nkeys_m1 [B] int32, out [B, Hq*128]."""
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(v, "v")
+    B = q.shape[0]
+    if k.dim() != 4 or k.shape != v.shape or k.shape[0] != B or k.shape[1] != n_kv or k.shape[3] != head_dim \
+            or not (k[0].is_contiguous() and v[0].is_contiguous()) or k.stride(0) != v.stride(0):
+        raise HipLibraryError("decode_cross_attn_batch: bad k/v")
+    if q.shape[1] != n_q * head_dim or q.stride(1) != 1 or out.shape != (B, n_q * head_dim) or not out.is_contiguous() \
+            or nkeys_m1.dtype != torch.int32 or nkeys_m1.numel() != B:
+        raise HipLibraryError("decode_cross_attn_batch: bad q/out/nkeys")
+    if part_o.numel() < B * n_q * nsplit * head_dim or part_ml.numel() < B * n_q * nsplit * 2:
+        raise HipLibraryError("decode_cross_attn_batch: workspace too small")
+    rc = load().vis_decode_cross_attn_batch(_ptr(q), _ptr(q_norm_w), _ptr(k), _ptr(v), _ptr(nkeys_m1), _ptr(part_o),
+                                            _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, k.shape[2], nsplit, scale, eps,
+                                            B, q.stride(0), k.stride(0), _stream())
+    _check(rc, "vis_decode_cross_attn_batch")
 
 
 def patchify(img_u8: torch.Tensor, out: torch.Tensor, row0: int, mean, std) -> None:

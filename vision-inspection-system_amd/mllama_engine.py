@@ -12,7 +12,13 @@ see only real keys.  Attention is permutation-equivariant, so the tower runs on 
 which makes both key sets contiguous ranges - two groups of plain work items for vis_attn_prefill - and leaves
 the first max_tiles*1601 rows in exactly the order the cross-attention layers consume.
 
-Scope: one image per prompt (what the reference sends), single sequence per engine (no batched decode yet).
+Scope: one image per prompt (what the reference sends).  Up to ``max_batch`` requests are in flight at once: every
+request ("slot") owns its self-attention KV cache, its cross-attention keys/values and its position counter; prompt
+passes run per request, then ONE decode loop serves all of them - every projection weight is streamed once per step
+for the whole batch (gemm_decode_stream_kernel + skinny_finalize, the kernels of the Qwen2-VL batched decode), the
+self-attention takes the sequence index on its grid and the cross-attention reads each sequence's own static keys
+(vis_decode_cross_attn_batch).  Reference: VLMAuditorAgent.verify is called once per image of a batch
+(src/agents/vlm_auditor.py:166-234, src/orchestration/graph.py:308-357).
 """
 from __future__ import annotations
 
@@ -88,7 +94,7 @@ def llama3_rope_tables(cfg: MllamaConfig, n: int) -> Tuple[np.ndarray, np.ndarra
 class MllamaEngine:
     """One mllama replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
 
-    def __init__(self, cfg: MllamaConfig, weights: MllamaDeviceWeights, device, max_ctx: int = 4096):
+    def __init__(self, cfg: MllamaConfig, weights: MllamaDeviceWeights, device, max_ctx: int = 4096, max_batch: int = 1):
         cfg.validate_for_kernels()
         hip.load()
         if not torch.cuda.is_available():
@@ -104,20 +110,27 @@ class MllamaEngine:
         self.Tk = _round_up(self.TP, 64)
         self.nsplit = max(1, -(-self.max_ctx // hip.DECODE_KEYS_PER_SPLIT))
         self.xsplit = -(-self.Tk // hip.DECODE_KEYS_PER_SPLIT)
-        self.kcache = torch.zeros((self.n_self, Hkv, self.max_ctx, D), dtype=bf, device=dev)
-        self.vcache = torch.zeros((self.n_self, Hkv, self.max_ctx, D), dtype=bf, device=dev)
-        self.xk = torch.zeros((self.n_cross, Hkv, self.Tk, D), dtype=bf, device=dev)
-        self.xv = torch.zeros((self.n_cross, Hkv, self.Tk, D), dtype=bf, device=dev)
+        if not 1 <= max_batch <= 64:
+            raise ValueError("max_batch must be in 1..64")
+        Bm = self.max_batch = max_batch
+        # per-request ("slot") state; slot 0 doubles as the single-sequence engine
+        self.kcache_b = torch.zeros((Bm, self.n_self, Hkv, self.max_ctx, D), dtype=bf, device=dev)
+        self.vcache_b = torch.zeros((Bm, self.n_self, Hkv, self.max_ctx, D), dtype=bf, device=dev)
+        self.xk_b = torch.zeros((Bm, self.n_cross, Hkv, self.Tk, D), dtype=bf, device=dev)
+        self.xv_b = torch.zeros((Bm, self.n_cross, Hkv, self.Tk, D), dtype=bf, device=dev)
         cos, sin = llama3_rope_tables(cfg, self.max_ctx)
-        self.cos_t = torch.from_numpy(cos).to(dev)
+        self.cos_t = torch.from_numpy(cos).to(dev)          # plain positions: one table for every sequence
         self.sin_t = torch.from_numpy(sin).to(dev)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.cur_token = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.nkeys_m1 = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.tokens = torch.zeros(self.max_ctx, dtype=torch.int32, device=dev)
-        self.ws_val = torch.empty(256, dtype=torch.float32, device=dev)
-        self.ws_idx = torch.empty(256, dtype=torch.int32, device=dev)
-        self.logits = torch.empty(cfg.vocab, dtype=torch.float32, device=dev)
+        self.step_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
+        self.cur_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
+        self.nkeys_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
+        self.tokens_b = torch.zeros((Bm, self.max_ctx), dtype=torch.int32, device=dev)
+        self.ws_val = torch.empty(256 * Bm, dtype=torch.float32, device=dev)
+        self.ws_idx = torch.empty(256 * Bm, dtype=torch.int32, device=dev)
+        self.logits_b = torch.empty((Bm, cfg.vocab), dtype=torch.float32, device=dev)
+        self.kcache, self.vcache, self.xk, self.xv = self.kcache_b[0], self.vcache_b[0], self.xk_b[0], self.xv_b[0]
+        self.step, self.cur_token, self.nkeys_m1 = self.step_b[0:1], self.cur_b[0:1], self.nkeys_b[0:1]
+        self.tokens, self.logits = self.tokens_b[0], self.logits_b[0]
         nq = (Hq + 2 * Hkv) * D
         self.d_x = torch.empty((1, H), dtype=bf, device=dev)
         self.d_x2 = torch.empty((1, H), dtype=bf, device=dev)
@@ -125,10 +138,22 @@ class MllamaEngine:
         self.d_attn = torch.empty(Hq * D, dtype=bf, device=dev)
         self.d_act = torch.empty(cfg.intermediate, dtype=bf, device=dev)
         ns = max(self.nsplit, self.xsplit)
-        self.part_o = torch.empty(Hq * ns * D, dtype=torch.float32, device=dev)
-        self.part_ml = torch.empty(Hq * ns * 2, dtype=torch.float32, device=dev)
+        self.part_o = torch.empty(Bm * Hq * ns * D, dtype=torch.float32, device=dev)
+        self.part_ml = torch.empty(Bm * Hq * ns * 2, dtype=torch.float32, device=dev)
+        if Bm > 1:      # batched-decode activations and the stream-K partial workspace
+            self.b_x = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_x2 = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_xn = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_qkv = torch.empty((Bm, nq), dtype=bf, device=dev)
+            self.b_attn = torch.empty((Bm, Hq * D), dtype=bf, device=dev)
+            self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
+            self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
+                                      device=dev)
+        self.slot_prompt_len = [0] * Bm
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
+        self._graphs_b: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.temperature, self.seed = 0.0, 0
         self.prompt_len = 0
         self._decoded = 0
@@ -209,9 +234,14 @@ class MllamaEngine:
 
     # ------------------------------------------------------------------ prefill
     def prefill(self, input_ids: Sequence[int], frame: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
-                temperature: float = 0.0, seed: int = 0) -> None:
+                temperature: float = 0.0, seed: int = 0, slot: int = 0) -> None:
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        if not 0 <= slot < self.max_batch:
+            raise ValueError("slot out of range")
         self.temperature, self.seed = float(temperature), int(seed)
+        kcache, vcache, xk, xv = self.kcache_b[slot], self.vcache_b[slot], self.xk_b[slot], self.xv_b[slot]
+        step, cur_token, nkeys_m1 = self.step_b[slot:slot + 1], self.cur_b[slot:slot + 1], self.nkeys_b[slot:slot + 1]
+        tokens, logits = self.tokens_b[slot], self.logits_b[slot]
         S = len(input_ids)
         if S < 1 or S + 1 > self.max_ctx:
             raise ValueError(f"prompt of {S} tokens does not fit the context of {self.max_ctx}")
@@ -225,13 +255,15 @@ class MllamaEngine:
             raise ValueError("image token and image frame must come together")
         H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
         P, TP = cfg.tile_tokens, self.TP
-        self.has_image = frame is not None
-        nm = int(locs[0]) if self.has_image else 0
+        has_image = frame is not None
+        if slot == 0:
+            self.has_image = has_image
+        nm = int(locs[0]) if has_image else 0
         cross = None
-        if self.has_image:
+        if has_image:
             cross, n_tiles = self.vision_forward(frame, taps)
             nR = n_tiles * P
-            self.nkeys_m1.fill_(nR - 1)
+            nkeys_m1.fill_(nR - 1)
             if taps is not None:
                 taps["cross_states"] = cross
             xitems = [(q0, min(128, nm - q0), 0, TP) for q0 in range(0, nm, 128)] + \
@@ -256,18 +288,18 @@ class MllamaEngine:
         si = ci = 0
         for li, lw in enumerate(w.layers):
             if lw.cross:
-                if not self.has_image:
+                if not has_image:
                     ci += 1
                     continue                      # text-only prompt: cross layers are skipped (TF:...:1128-1138)
                 hip.gemm(cross, lw.kv_w, out=kvbuf)
                 for h in range(Hkv):              # k_norm per kv head (rows of 128, strided view)
                     hip.rmsnorm(kvbuf[:, h * D:(h + 1) * D], lw.k_norm, cfg.rms_eps, out=kvbuf[:, h * D:(h + 1) * D])
-                hip.qkv_rope_split(kvbuf, None, None, None, self.xk[ci], self.xv[ci], xvt, 0, Hkv, D, k_pos0=0)
+                hip.qkv_rope_split(kvbuf, None, None, None, xk[ci], xv[ci], xvt, 0, Hkv, D, k_pos0=0)
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, out=q2)
                 hip.rmsnorm(q2.view(S * Hq, D), lw.q_norm, cfg.rms_eps, out=q2.view(S * Hq, D))
                 hip.qkv_rope_split(q2, None, None, q, None, None, None, Hq, 0, D)
-                hip.attn_prefill(q, self.xk[ci], xvt, att, xwork, False, scale)
+                hip.attn_prefill(q, xk[ci], xvt, att, xwork, False, scale)
                 hip.gemm(att, lw.o_w, residual=x, out=x)
                 keep = x[:nm].clone() if nm > 0 else None
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
@@ -279,8 +311,8 @@ class MllamaEngine:
             else:
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, out=qkv)
-                hip.qkv_rope_split(qkv, cos, sin, q, self.kcache[si], self.vcache[si], vt, Hq, Hkv, D, k_pos0=0)
-                hip.attn_prefill_pairs(q, self.kcache[si], vt, att, work, scale)
+                hip.qkv_rope_split(qkv, cos, sin, q, kcache[si], vcache[si], vt, Hq, Hkv, D, k_pos0=0)
+                hip.attn_prefill_pairs(q, kcache[si], vt, att, work, scale)
                 hip.gemm(att, lw.o_w, residual=x, out=x)
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
@@ -288,14 +320,16 @@ class MllamaEngine:
                 si += 1
             if taps is not None:
                 taps[f"layer{li}"] = x.clone()
-        hip.gemv(x[S - 1], w.lm_head, self.logits, norm_w=w.norm_w, eps=cfg.rms_eps)
+        hip.gemv(x[S - 1], w.lm_head, logits, norm_w=w.norm_w, eps=cfg.rms_eps)
         if taps is not None:
-            taps["first_logits"] = self.logits.clone()
-        self.step.fill_(S - 1)
-        hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step, self.temperature,
-                   self.seed)
-        self.prompt_len, self._decoded = S, 0
-        self.decode_limit = self.max_ctx
+            taps["first_logits"] = logits.clone()
+        step.fill_(S - 1)
+        hip.argmax(logits, self.ws_val[256 * slot:256 * (slot + 1)], self.ws_idx[256 * slot:256 * (slot + 1)], tokens,
+                   cur_token, step, self.temperature, self.seed + 0x9E3779B9 * slot)
+        self.slot_prompt_len[slot] = S
+        if slot == 0:
+            self.prompt_len, self._decoded = S, 0
+            self.decode_limit = self.max_ctx
 
     # ------------------------------------------------------------------ decode
     def _decode_step(self) -> None:
@@ -356,6 +390,109 @@ class MllamaEngine:
             for _ in range(n_steps):
                 self._decode_step()
         self._decoded += n_steps
+
+    # ---- batched decode: B in-flight requests (slots 0..B-1, all with an image) share every weight read of a step
+    def _decode_step_batched(self, B: int) -> None:
+        """Every projection = gemm_decode (weights streamed once for all B sequences, stream-K f32 partials) +
+        skinny_finalize (row-wise: sum, residual / SwiGLU, and the RMSNorm of the NEXT projection); self-attention and
+        cross-attention take the sequence index on the grid."""
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
+        scale, eps = D ** -0.5, cfg.rms_eps
+        x, x2, xn, xn2 = self.b_x[:B], self.b_x2[:B], self.b_xn[:B], self.b_xn2[:B]
+        qkv, att, act, part = self.b_qkv[:B], self.b_attn[:B], self.b_act[:B], self.b_part
+        nq = qkv.shape[1]
+        cosb = self.cos_t.unsqueeze(0).expand(B, -1, -1)          # batch stride 0: the rope table is shared
+        sinb = self.sin_t.unsqueeze(0).expand(B, -1, -1)
+        hip.gather_rows(w.embed, self.cur_b[:B], x)
+        hip.rmsnorm(x, w.layers[0].ln1_w, eps, out=xn)
+        n_layers = len(w.layers)
+        si = ci = 0
+        for li, lw in enumerate(w.layers):
+            if lw.cross:
+                q = qkv[:, :Hq * D]
+                ks = hip.decode_gemm(xn, lw.qkv_w, part=part)
+                hip.skinny_finalize(part, ks, q, Hq * D, eps=eps)
+                hip.decode_cross_attn_batch(q, lw.q_norm, self.xk_b[:B, ci], self.xv_b[:B, ci], self.nkeys_b[:B],
+                                            self.part_o, self.part_ml, att, Hq, Hkv, D, self.xsplit, scale, eps)
+                ci += 1
+            else:
+                ks = hip.decode_gemm(xn, lw.qkv_w, part=part)
+                hip.skinny_finalize(part, ks, qkv, nq, eps=eps)
+                hip.decode_attn(qkv, cosb, sinb, self.kcache_b[:B, si], self.vcache_b[:B, si], self.step_b[:B],
+                                self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                si += 1
+            ks = hip.decode_gemm(att, lw.o_w, part=part)
+            hip.skinny_finalize(part, ks, x2, H, residual=x, norm_w=lw.ln2_w, yn=xn2, eps=eps)
+            ks = hip.decode_gemm(xn2, lw.gateup_w, part=part)
+            hip.skinny_finalize(part, ks, act, 2 * cfg.intermediate, swiglu=True, eps=eps)
+            ks = hip.decode_gemm(act, lw.down_w, part=part)
+            next_norm = w.layers[li + 1].ln1_w if li + 1 < n_layers else w.norm_w
+            hip.skinny_finalize(part, ks, x, H, residual=x2, norm_w=next_norm, yn=xn, eps=eps)
+        hip.decode_gemm(xn, w.lm_head, out=self.logits_b[:B])
+        hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
+                   self.temperature, self.seed)
+
+    def _ensure_graph_batched(self, B: int) -> torch.cuda.CUDAGraph:
+        key = (self.temperature, self.seed, B)
+        if key in self._graphs_b:
+            return self._graphs_b[key]
+        snap = (self.step_b.clone(), self.cur_b.clone())
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._decode_step_batched(B)             # warm-up outside capture
+        torch.cuda.current_stream().wait_stream(s)
+        self.step_b.copy_(snap[0]); self.cur_b.copy_(snap[1])
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._decode_step_batched(B)
+        self.step_b.copy_(snap[0]); self.cur_b.copy_(snap[1])
+        if len(self._graphs_b) >= 4:
+            self._graphs_b.pop(next(iter(self._graphs_b)))
+        self._graphs_b[key] = g
+        return g
+
+    def generate_batch(self, requests: Sequence[Tuple[Sequence[int], torch.Tensor]], max_new_tokens: int = 128,
+                       temperature: float = 0.0, seed: int = 0, stop_on_eos: bool = True, use_graph: bool = True,
+                       chunk: int = 16) -> List[List[int]]:
+        """requests: [(input_ids, frame)] for up to max_batch images (every request carries an image: the batched step
+        always runs the cross-attention layers).  Prompt passes run per request; the decode steps are shared."""
+        B = len(requests)
+        if not 1 <= B <= self.max_batch:
+            raise ValueError(f"batch of {B} does not fit max_batch={self.max_batch}")
+        if B == 1 or any(fr is None for _, fr in requests):
+            if B > 1:
+                raise ValueError("generate_batch needs an image in every request (text-only prompts go through generate)")
+            ids, fr = requests[0]
+            return [self.generate(ids, fr, max_new_tokens, temperature, seed, stop_on_eos, use_graph)]
+        longest = max(len(r[0]) for r in requests)
+        max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - longest - 1))
+        for b, (ids, fr) in enumerate(requests):
+            self.prefill(ids, fr, temperature=temperature, seed=seed, slot=b)
+        eos = set(self.cfg.eos_ids)
+        starts = [self.slot_prompt_len[b] - 1 for b in range(B)]
+
+        def collect(n):
+            t = self.tokens_b[:B].cpu()
+            return [t[b, starts[b]:starts[b] + n].tolist() for b in range(B)]
+
+        done = 1
+        g = self._ensure_graph_batched(B) if use_graph else None
+        while done < max_new_tokens:
+            if stop_on_eos and all(any(t in eos for t in seq) for seq in collect(done)):
+                break
+            n = min(chunk if stop_on_eos else max_new_tokens, max_new_tokens - done)
+            for _ in range(n):
+                if g is not None:
+                    g.replay()
+                else:
+                    self._decode_step_batched(B)
+            done += n
+        outs = collect(done)
+        if stop_on_eos:
+            outs = [seq[:next((i + 1 for i, t in enumerate(seq) if t in eos), len(seq))] for seq in outs]
+        return outs
 
     def generated(self, n: int) -> List[int]:
         s = self.prompt_len - 1          # the token generated at step i is stored at index (its position - 1)
