@@ -113,8 +113,16 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
             elif kind in ("7b", "qwen2-vl-7b"):
                 cfg = Qwen2VLConfig.qwen2_vl_7b()
                 w = W.random_device_weights(cfg, device, seed)
+            elif kind in ("tiny25", "qwen2.5-vl-tiny"):
+                cfg = Qwen2VLConfig.tiny_2_5()
+                w = W.pack_device_weights(cfg, W.synth_state_dict(cfg, seed), device)
+                max_ctx = min(max_ctx, 1024)
+            elif kind in ("7b25", "qwen2.5-vl-7b"):
+                cfg = Qwen2VLConfig.qwen2_5_vl_7b()
+                w = W.random_device_weights(cfg, device, seed)
             else:
-                raise ValueError(f"unknown synthetic model {kind!r} (use synthetic:tiny or synthetic:7b)")
+                raise ValueError(f"unknown synthetic model {kind!r} (use synthetic:tiny, synthetic:7b, synthetic:tiny25 "
+                                 f"or synthetic:qwen2.5-vl-7b)")
             tok = ByteTokenizer(cfg.vocab, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
         else:
             path = resolve_model_dir(model_id)
@@ -122,7 +130,7 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
                 raise FileNotFoundError(
                     f"model {model_id!r} is not a local directory and VIS_MODEL_ROOT has no copy of it; the "
                     f"'{LOCAL_PROVIDER}' provider only loads local files (config.json, *.safetensors, tokenizer.json)")
-            local_model_type(path)          # refuses anything but qwen2_vl (mllama was handled above)
+            local_model_type(path)          # refuses anything but qwen2_vl / qwen2_5_vl (mllama was handled above)
             cfg = Qwen2VLConfig.from_hf_dir(path)
             w = W.load_safetensors_dir(cfg, path, device)
             tok = HFTokenizer(path, cfg.image_token_id, cfg.vision_start_id, cfg.vision_end_id, cfg.eos_ids)
@@ -183,7 +191,7 @@ def unregister_model(model_id: str, device: str) -> None:
         _ENGINES.pop((model_id, str(device)), None)
 
 
-SUPPORTED_MODEL_TYPES = ("qwen2_vl", "mllama")
+SUPPORTED_MODEL_TYPES = ("qwen2_vl", "qwen2_5_vl", "mllama")
 
 
 def local_model_type(path: str) -> str:

@@ -45,6 +45,12 @@ class Qwen2VLConfig:
     merge: int = 2
     min_pixels: int = 56 * 56
     max_pixels: int = 28 * 28 * 1280
+    # vision tower family: "qwen2_vl" (LayerNorm, fc1/QuickGELU/fc2, full attention per image) or "qwen2_5_vl" (the
+    # reference's code default, utils/config.py:42-45: RMSNorm, SwiGLU MLP with biases of width v_mlp, attention inside
+    # v_window-pixel windows except in the v_fullatt blocks; TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:294-472)
+    vision_arch: str = "qwen2_vl"
+    v_window: int = 112
+    v_fullatt: Tuple[int, ...] = (7, 15, 23, 31)
     # special tokens
     image_token_id: int = 151655
     vision_start_id: int = 151652
@@ -63,6 +69,13 @@ class Qwen2VLConfig:
     def patch_dim(self) -> int:
         return 3 * self.temporal * self.patch * self.patch
 
+    @property
+    def v_mlp_pad(self) -> int:
+        """MLP width as the kernels see it: Qwen2.5-VL's 3420 is zero-padded to a multiple of 64 (GEMM K-step of the down
+        projection; also a multiple of 16 for the gate/up interleave).  Exact: padded gate/up rows are zero, so are
+        their SwiGLU outputs and the padded down-projection columns."""
+        return (self.v_mlp + 63) // 64 * 64 if self.vision_arch == "qwen2_5_vl" else self.v_mlp
+
     def validate_for_kernels(self) -> None:
         """The gfx950 kernels are specialised; refuse shapes they do not cover."""
         problems = []
@@ -72,8 +85,12 @@ class Qwen2VLConfig:
             problems.append(f"ViT head_dim must be 80, got {self.v_head_dim}")
         if self.heads % self.kv_heads or self.heads // self.kv_heads not in (1, 2, 4, 7, 8):
             problems.append("heads/kv_heads must be one of 1, 2, 4, 7, 8 (instantiated GQA group sizes)")
+        if self.vision_arch not in ("qwen2_vl", "qwen2_5_vl"):
+            problems.append(f"unknown vision_arch {self.vision_arch!r}")
+        if self.vision_arch == "qwen2_5_vl" and (self.v_window % (self.patch * self.merge) or self.v_window <= 0):
+            problems.append("v_window must be a positive multiple of patch * merge")
         for nm, v in (("hidden", self.hidden), ("intermediate", self.intermediate), ("v_embed", self.v_embed),
-                      ("v_mlp", self.v_mlp), ("merger", self.v_embed * self.merge ** 2)):
+                      ("v_mlp", self.v_mlp_pad), ("merger", self.v_embed * self.merge ** 2)):
             if v % 64:
                 problems.append(f"{nm}={v} must be a multiple of 64 (GEMM K-step)")
         if self.intermediate % 16 or self.vocab % 4:
@@ -90,6 +107,19 @@ class Qwen2VLConfig:
         return cls()
 
     @classmethod
+    def qwen2_5_vl_7b(cls) -> "Qwen2VLConfig":
+        """Qwen2.5-VL-7B-Instruct: the text decoder has the Qwen2-VL-7B shapes; the tower is the windowed one."""
+        return cls(name="qwen2.5-vl-7b", vision_arch="qwen2_5_vl", v_mlp=3420, v_window=112, v_fullatt=(7, 15, 23, 31))
+
+    @classmethod
+    def tiny_2_5(cls) -> "Qwen2VLConfig":
+        """Kernel-compatible miniature of the Qwen2.5-VL tower: 3 blocks (block 1 full attention), 56-pixel windows
+        (2 x 2 merged tokens = 16 patches), SwiGLU width 428 (padded to 448 like 3420 -> 3456)."""
+        return cls(name="qwen2.5-vl-tiny", hidden=256, layers=2, heads=2, kv_heads=1, intermediate=704, vocab=512,
+                   v_depth=3, v_embed=320, v_heads=4, v_mlp=428, image_token_id=500, vision_start_id=501,
+                   vision_end_id=502, eos_ids=(503,), vision_arch="qwen2_5_vl", v_window=56, v_fullatt=(1,))
+
+    @classmethod
     def tiny(cls) -> "Qwen2VLConfig":
         """Smallest shape every kernel specialisation accepts (parity tests, smoke)."""
         return cls(name="qwen2-vl-tiny", hidden=256, layers=2, heads=2, kv_heads=1, intermediate=704, vocab=512,
@@ -98,11 +128,20 @@ class Qwen2VLConfig:
 
     @classmethod
     def from_hf_dir(cls, path: str) -> "Qwen2VLConfig":
-        """Read a local HuggingFace ``config.json`` (Qwen2-VL layout, flat or nested text_config)."""
+        """Read a local HuggingFace ``config.json`` (Qwen2-VL or Qwen2.5-VL layout, flat or nested text_config)."""
         with open(os.path.join(path, "config.json")) as f:
             c = json.load(f)
         t = c.get("text_config", c)
         v = c.get("vision_config", {})
+        arch = "qwen2_5_vl" if c.get("model_type") == "qwen2_5_vl" else "qwen2_vl"
+        if arch == "qwen2_5_vl":        # TF:models/qwen2_5_vl/configuration_qwen2_5_vl.py: own key names
+            v = dict(v)
+            v.setdefault("embed_dim", v.get("hidden_size", 1280))
+            vis_extra = dict(vision_arch=arch, v_mlp=int(v.get("intermediate_size", 3420)),
+                             v_window=int(v.get("window_size", 112)),
+                             v_fullatt=tuple(v.get("fullatt_block_indexes", (7, 15, 23, 31))))
+        else:
+            vis_extra = dict(v_mlp=int(v.get("embed_dim", 1280) * v.get("mlp_ratio", 4)))
         rope = t.get("rope_scaling") or t.get("rope_parameters") or c.get("rope_scaling") or {}
         eos = c.get("eos_token_id", t.get("eos_token_id", 151645))
         eos_ids = tuple(eos) if isinstance(eos, (list, tuple)) else (int(eos),)
@@ -115,7 +154,7 @@ class Qwen2VLConfig:
             rms_eps=t.get("rms_norm_eps", 1e-6), rope_theta=t.get("rope_theta", rope.get("rope_theta", 1e6)),
             mrope_section=tuple(rope.get("mrope_section", (16, 24, 24))),
             v_depth=v.get("depth", 32), v_embed=v.get("embed_dim", 1280), v_heads=v.get("num_heads", 16),
-            v_mlp=int(v.get("embed_dim", 1280) * v.get("mlp_ratio", 4)), patch=v.get("patch_size", 14),
+            patch=v.get("patch_size", 14), **vis_extra,
             temporal=v.get("temporal_patch_size", 2), merge=v.get("spatial_merge_size", 2),
             image_token_id=c.get("image_token_id", 151655), vision_start_id=c.get("vision_start_token_id", 151652),
             vision_end_id=c.get("vision_end_token_id", 151653), eos_ids=eos_ids)

@@ -86,10 +86,17 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& p, f32x4 (&acc)[
         const int n = nbase + j * 16 + 4 * h;  // gate row index in the interleaved weight
         if (j >= ntiles || n >= p.N) continue;
         const int oc = (nbase >> 1) + (j >> 1) * 16 + 4 * h;
-        float v[4];
+        float v[4], bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {   // interleaved like the weight rows: gate biases at n .. n+3, up biases 16 further
+          const u32x2 b0 = *(const u32x2*)(p.bias + n), b1 = *(const u32x2*)(p.bias + n + 16);
+          bg[0] = __uint_as_float(b0[0] << 16); bg[1] = __uint_as_float(b0[0] & 0xffff0000u);
+          bg[2] = __uint_as_float(b0[1] << 16); bg[3] = __uint_as_float(b0[1] & 0xffff0000u);
+          bu[0] = __uint_as_float(b1[0] << 16); bu[1] = __uint_as_float(b1[0] & 0xffff0000u);
+          bu[2] = __uint_as_float(b1[1] << 16); bu[3] = __uint_as_float(b1[1] & 0xffff0000u);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float g = acc[i][j][r], u = acc[i][j + 1][r];
+          const float g = acc[i][j][r] + bg[r], u = acc[i][j + 1][r] + bu[r];
           v[r] = silu_fast(g) * u;
         }
         u32x2 o;
@@ -156,9 +163,17 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4 (&ac
       const int row = i * 16 + l15;
 #pragma unroll
       for (int j = 0; j < NT; j += 2) {
-        float v[4];
+        float v[4], bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
+        const int n = nbase + j * 16 + 4 * h;
+        if (p.bias && n < p.N) {   // interleaved like the weight rows: gate biases at n .. n+3, up biases 16 further
+          const u32x2 b0 = *(const u32x2*)(p.bias + n), b1 = *(const u32x2*)(p.bias + n + 16);
+          bg[0] = __uint_as_float(b0[0] << 16); bg[1] = __uint_as_float(b0[0] & 0xffff0000u);
+          bg[2] = __uint_as_float(b0[1] << 16); bg[3] = __uint_as_float(b0[1] & 0xffff0000u);
+          bu[0] = __uint_as_float(b1[0] << 16); bu[1] = __uint_as_float(b1[0] & 0xffff0000u);
+          bu[2] = __uint_as_float(b1[1] << 16); bu[3] = __uint_as_float(b1[1] & 0xffff0000u);
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[i][j][r]) * acc[i][j + 1][r];
+        for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[i][j][r] + bg[r]) * (acc[i][j + 1][r] + bu[r]);
         u32x2 o;
         o[0] = pack2bf(v[0], v[1]);
         o[1] = pack2bf(v[2], v[3]);
@@ -1414,7 +1429,7 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   if (K % GEMM_BK != 0 || N % 4 != 0) return VIS_ERR_ARG;
   if (lda % 8 != 0 || ldw % 8 != 0 || ldc % 4 != 0 || (R && ldr % 4 != 0)) return VIS_ERR_ARG;
   if (act < ACT_NONE || act > ACT_SWIGLU) return VIS_ERR_ARG;
-  if (act == ACT_SWIGLU && (N % 32 != 0 || bias || R)) return VIS_ERR_ARG;
+  if (act == ACT_SWIGLU && (N % 32 != 0 || R)) return VIS_ERR_ARG;   // bias (if any) is interleaved like the weight rows
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 7) return VIS_ERR_ARG;
   if (((uintptr_t)A | (uintptr_t)W) & 15) return VIS_ERR_ARG;
   GemmArgs p;

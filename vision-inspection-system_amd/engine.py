@@ -57,6 +57,28 @@ def vision_cos_sin(cfg: Qwen2VLConfig, grids) -> Tuple[np.ndarray, np.ndarray]:
     return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
 
 
+def vision_window_order(cfg: Qwen2VLConfig, grid: Tuple[int, int, int]) -> Tuple[np.ndarray, List[int]]:
+    """Qwen2.5-VL window layout of ONE image (TF vision_utils.get_vision_window_index): the permutation of its 2x2 merge
+    units into window order and the cumulative window boundaries in patch rows.  Windows are v_window pixels square
+    (v_window / merge / patch merged tokens per side); the right / bottom windows of a grid are ragged."""
+    t, h, w = grid
+    win = cfg.v_window // cfg.merge // cfg.patch
+    unit = cfg.merge ** 2
+    lh, lw = h // cfg.merge, w // cfg.merge
+    idx = np.arange(t * lh * lw).reshape(t, lh, lw)
+    ph, pw = win - lh % win, win - lw % win               # the reference pads a whole window when already divisible
+    nh, nw = (lh + ph) // win, (lw + pw) // win
+    pad = np.pad(idx, ((0, 0), (0, ph), (0, pw)), constant_values=-100)
+    pad = pad.reshape(t, nh, win, nw, win).transpose(0, 1, 3, 2, 4).reshape(t, nh * nw, win * win)
+    seqlens = (pad != -100).sum(axis=2).reshape(-1)
+    flat = pad.reshape(-1)
+    cu = [0]
+    for n in seqlens.tolist():
+        if n:                                             # all-padding windows vanish (unique_consecutive)
+            cu.append(cu[-1] + n * unit)
+    return flat[flat != -100].astype(np.int64), cu
+
+
 def rope_index(cfg: Qwen2VLConfig, input_ids: Sequence[int], grids) -> Tuple[np.ndarray, int]:
     """M-RoPE position ids [3, S] of one sequence and the next text position
     (TF modeling_qwen2_vl.py:914-1016: text runs count up on all 3 axes, an image block uses
@@ -261,6 +283,8 @@ class Qwen2VLEngine:
             if len(self._vis_rope_cache) > 16:
                 self._vis_rope_cache.pop(next(iter(self._vis_rope_cache)))
         cos, sin = self._vis_rope_cache[key]
+        if cfg.vision_arch == "qwen2_5_vl":
+            return self._vision_forward_windowed(x, grids, starts, counts, N, padded, cos, sin)
         segs = [(r0, r0 + c) for r0, c in zip(starts, counts)]
         work = self._vis_work_cache.get(tuple(segs))
         if work is None:
@@ -324,6 +348,76 @@ class Qwen2VLEngine:
         m = cfg.merge ** 2
         z = hip.gemm(y.view(N // m, E * m), w.merger_fc0_w, bias=w.merger_fc0_b, act=hip.ACT_GELU_ERF)
         out = hip.gemm(z, w.merger_fc2_w, bias=w.merger_fc2_b)
+        if padded:
+            out = torch.cat([out[r0 // m:(r0 + c) // m] for r0, c in zip(starts, counts)])
+        return out
+
+    def _vision_forward_windowed(self, x, grids, starts, counts, N: int, padded: bool, cos, sin) -> torch.Tensor:
+        """Qwen2.5-VL tower (TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:408-472) on the patch-embedded rows ``x``: the
+        2x2 merge units of every image are permuted into window order (one row gather; the rope rows move with them),
+        blocks = RMSNorm -> qkv -> 2-D rope -> attention over the WINDOWS (work items of <= 64 rows) or, in the
+        v_fullatt blocks, over the whole image -> proj(+res) -> RMSNorm -> gate/up GEMM with bias + SwiGLU epilogue ->
+        down projection as two K-slices finalised together with the next RMSNorm; merger (RMSNorm, GELU MLP); the merged
+        rows are gathered back into the original order.  Same kernels as the Qwen2-VL tower."""
+        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        E, Hh, D = cfg.v_embed, cfg.v_heads, cfg.v_head_dim
+        m = cfg.merge ** 2
+        key = ("win", tuple(grids))
+        lay = self._vis_work_cache.get(key)
+        if lay is None:
+            row_idx = np.arange(N, dtype=np.int32)                 # pad rows (if any) stay where they are
+            rev = np.arange(N // m, dtype=np.int32)
+            win_segs, full_segs = [], []
+            for g, r0, c in zip(grids, starts, counts):
+                widx, cu = vision_window_order(cfg, g)
+                rows = (widx[:, None] * m + np.arange(m)[None, :]).reshape(-1)
+                row_idx[r0:r0 + c] = r0 + rows
+                rev[r0 // m:(r0 + c) // m] = r0 // m + np.argsort(widx)
+                win_segs += [(r0 + a, r0 + b) for a, b in zip(cu[:-1], cu[1:])]
+                full_segs.append((r0, r0 + c))
+            c_np, s_np = vision_cos_sin(cfg, grids)                 # rope rows follow their patches: permuted on the host
+            cp, sp = np.zeros((N, c_np.shape[1]), np.float32), np.zeros((N, s_np.shape[1]), np.float32)
+            o = 0
+            for r0, c in zip(starts, counts):
+                cp[r0:r0 + c], sp[r0:r0 + c] = c_np[o:o + c], s_np[o:o + c]
+                o += c
+            if len(self._vis_work_cache) >= 16:
+                self._vis_work_cache.clear()
+            lay = self._vis_work_cache[key] = (
+                torch.from_numpy(row_idx).to(dev), torch.from_numpy(rev).to(dev),
+                hip.make_attn_work(win_segs, False, dev, heads=Hh), hip.make_attn_work(full_segs, False, dev, heads=Hh),
+                torch.from_numpy(cp[row_idx]).to(dev), torch.from_numpy(sp[row_idx]).to(dev))
+        row_idx, rev, work_win, work_full, cw, sw = lay
+        xw = torch.empty_like(x)
+        hip.gather_rows(x, row_idx, xw)
+        x = xw
+        ld = _round_up(N, 64)
+        pad = cfg.v_mlp_pad
+        y = torch.empty((N, E), dtype=bf, device=dev)
+        qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
+        q = torch.empty((Hh, N, D), dtype=bf, device=dev)
+        k = torch.empty((Hh, N, D), dtype=bf, device=dev)
+        vt = torch.empty((Hh, D, ld), dtype=bf, device=dev)
+        att = (torch.zeros if padded else torch.empty)((N, E), dtype=bf, device=dev)
+        hmid = torch.empty((N, pad), dtype=bf, device=dev)
+        swork = torch.empty(2 * N * E, dtype=torch.float32, device=dev)
+        scale = D ** -0.5
+        nb = len(w.vit)
+        hip.rmsnorm(x, w.vit[0].ln1_w, 1e-6, out=y)
+        for bi, b in enumerate(w.vit):
+            hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
+            hip.qkv_rope_split(qkv, cw, sw, q, k, None, vt, Hh, Hh, D)
+            hip.attn_prefill(q, k, vt, att, work_full if bi in cfg.v_fullatt else work_win, False, scale)
+            hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
+            hip.rmsnorm(x, b.ln2_w, 1e-6, out=y)
+            hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_SWIGLU, out=hmid)
+            nw = w.vit[bi + 1].ln1_w if bi + 1 < nb else w.merger_ln_w
+            hip.gemm_splitk_part(hmid, b.fc2_w, swork, 2)
+            hip.splitk_finalize_norm(swork, 2, x, bias=b.fc2_b, residual=x, norm_w=nw, y_out=y, eps=1e-6)
+        z = hip.gemm(y.view(N // m, E * m), w.merger_fc0_w, bias=w.merger_fc0_b, act=hip.ACT_GELU_ERF)
+        out_w = hip.gemm(z, w.merger_fc2_w, bias=w.merger_fc2_b)
+        out = torch.empty_like(out_w)
+        hip.gather_rows(out_w, rev, out)
         if padded:
             out = torch.cat([out[r0 // m:(r0 + c) // m] for r0, c in zip(starts, counts)])
         return out

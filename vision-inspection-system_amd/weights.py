@@ -53,16 +53,25 @@ def tensor_shapes(cfg: Qwen2VLConfig) -> Dict[str, tuple]:
     E, H = cfg.v_embed, cfg.hidden
     D = cfg.head_dim
     s: Dict[str, tuple] = {"visual.patch_embed.proj.weight": (E, 3, cfg.temporal, cfg.patch, cfg.patch)}
+    v25 = cfg.vision_arch == "qwen2_5_vl"
     for i in range(cfg.v_depth):
         p = f"visual.blocks.{i}."
-        s[p + "norm1.weight"] = (E,); s[p + "norm1.bias"] = (E,)
-        s[p + "norm2.weight"] = (E,); s[p + "norm2.bias"] = (E,)
+        s[p + "norm1.weight"] = (E,)
+        s[p + "norm2.weight"] = (E,)
         s[p + "attn.qkv.weight"] = (3 * E, E); s[p + "attn.qkv.bias"] = (3 * E,)
         s[p + "attn.proj.weight"] = (E, E); s[p + "attn.proj.bias"] = (E,)
-        s[p + "mlp.fc1.weight"] = (cfg.v_mlp, E); s[p + "mlp.fc1.bias"] = (cfg.v_mlp,)
-        s[p + "mlp.fc2.weight"] = (E, cfg.v_mlp); s[p + "mlp.fc2.bias"] = (E,)
+        if v25:     # RMSNorm (no bias), SwiGLU MLP with biases (TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:85-97,:294-323)
+            for nm in ("gate_proj", "up_proj"):
+                s[p + f"mlp.{nm}.weight"] = (cfg.v_mlp, E); s[p + f"mlp.{nm}.bias"] = (cfg.v_mlp,)
+            s[p + "mlp.down_proj.weight"] = (E, cfg.v_mlp); s[p + "mlp.down_proj.bias"] = (E,)
+        else:
+            s[p + "norm1.bias"] = (E,); s[p + "norm2.bias"] = (E,)
+            s[p + "mlp.fc1.weight"] = (cfg.v_mlp, E); s[p + "mlp.fc1.bias"] = (cfg.v_mlp,)
+            s[p + "mlp.fc2.weight"] = (E, cfg.v_mlp); s[p + "mlp.fc2.bias"] = (E,)
     M = E * cfg.merge ** 2
-    s["visual.merger.ln_q.weight"] = (E,); s["visual.merger.ln_q.bias"] = (E,)
+    s["visual.merger.ln_q.weight"] = (E,)
+    if not v25:
+        s["visual.merger.ln_q.bias"] = (E,)
     s["visual.merger.mlp.0.weight"] = (M, M); s["visual.merger.mlp.0.bias"] = (M,)
     s["visual.merger.mlp.2.weight"] = (H, M); s["visual.merger.mlp.2.bias"] = (H,)
     s["model.embed_tokens.weight"] = (cfg.vocab, H)
@@ -131,7 +140,10 @@ def synth_state_dict(cfg: Qwen2VLConfig, seed: int = 0, rng: str = "hash", devic
 # ----------------------------------------------------------------------------- device layouts
 @dataclass
 class VitBlockWeights:
-    ln1_w: torch.Tensor; ln1_b: torch.Tensor; ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    """Qwen2-VL: LayerNorm weights + biases, fc1 / fc2.  Qwen2.5-VL: ln*_b are None (RMSNorm); fc1_w / fc1_b hold the
+    gate / up projections interleaved in 16-row groups (SwiGLU in the GEMM epilogue) and fc2_w the down projection, all
+    zero-padded from v_mlp to cfg.v_mlp_pad."""
+    ln1_w: torch.Tensor; ln1_b: Optional[torch.Tensor]; ln2_w: torch.Tensor; ln2_b: Optional[torch.Tensor]
     qkv_w: torch.Tensor; qkv_b: torch.Tensor; proj_w: torch.Tensor; proj_b: torch.Tensor
     fc1_w: torch.Tensor; fc1_b: torch.Tensor; fc2_w: torch.Tensor; fc2_b: torch.Tensor
 
@@ -147,7 +159,7 @@ class LlmLayerWeights:
 class DeviceWeights:
     patch_w: torch.Tensor
     vit: List[VitBlockWeights]
-    merger_ln_w: torch.Tensor; merger_ln_b: torch.Tensor
+    merger_ln_w: torch.Tensor; merger_ln_b: Optional[torch.Tensor]
     merger_fc0_w: torch.Tensor; merger_fc0_b: torch.Tensor
     merger_fc2_w: torch.Tensor; merger_fc2_b: torch.Tensor
     embed: torch.Tensor
@@ -190,8 +202,27 @@ def pack_device_weights(cfg: Qwen2VLConfig, sd: Dict[str, torch.Tensor], device)
     E = cfg.v_embed
     patch_w = pad_cols(dv("visual.patch_embed.proj.weight").reshape(E, -1), PATCH_K_PAD)
     vit = []
+    v25 = cfg.vision_arch == "qwen2_5_vl"
+    pad = cfg.v_mlp_pad
+
+    def pad_rows(t: torch.Tensor) -> torch.Tensor:     # [v_mlp, ...] -> [v_mlp_pad, ...], zero rows appended
+        if t.shape[0] == pad:
+            return t
+        out = torch.zeros((pad,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        out[:t.shape[0]] = t
+        return out
+
     for i in range(cfg.v_depth):
         p = f"visual.blocks.{i}."
+        if v25:
+            gu_w = interleave_gate_up(pad_rows(dv(p + "mlp.gate_proj.weight")), pad_rows(dv(p + "mlp.up_proj.weight")))
+            gu_b = interleave_gate_up(pad_rows(dv(p + "mlp.gate_proj.bias")).view(-1, 1),
+                                      pad_rows(dv(p + "mlp.up_proj.bias")).view(-1, 1)).view(-1).contiguous()
+            vit.append(VitBlockWeights(
+                dv(p + "norm1.weight"), None, dv(p + "norm2.weight"), None,
+                dv(p + "attn.qkv.weight"), dv(p + "attn.qkv.bias"), dv(p + "attn.proj.weight"), dv(p + "attn.proj.bias"),
+                gu_w, gu_b, pad_cols(dv(p + "mlp.down_proj.weight"), 64), dv(p + "mlp.down_proj.bias")))
+            continue
         vit.append(VitBlockWeights(
             dv(p + "norm1.weight"), dv(p + "norm1.bias"), dv(p + "norm2.weight"), dv(p + "norm2.bias"),
             dv(p + "attn.qkv.weight"), dv(p + "attn.qkv.bias"), dv(p + "attn.proj.weight"), dv(p + "attn.proj.bias"),
@@ -209,7 +240,7 @@ def pack_device_weights(cfg: Qwen2VLConfig, sd: Dict[str, torch.Tensor], device)
                                    dv(p + "mlp.down_proj.weight")))
     embed = dv("model.embed_tokens.weight")
     lm_head = dv("lm_head.weight") if "lm_head.weight" in sd else embed  # tied checkpoints
-    return DeviceWeights(patch_w, vit, dv("visual.merger.ln_q.weight"), dv("visual.merger.ln_q.bias"),
+    return DeviceWeights(patch_w, vit, dv("visual.merger.ln_q.weight"), None if v25 else dv("visual.merger.ln_q.bias"),
                          dv("visual.merger.mlp.0.weight"), dv("visual.merger.mlp.0.bias"),
                          dv("visual.merger.mlp.2.weight"), dv("visual.merger.mlp.2.bias"),
                          embed, llm, dv("model.norm.weight"), lm_head)
@@ -236,14 +267,32 @@ def random_device_weights(cfg: Qwen2VLConfig, device, seed: int = 0, std: float 
     E, H, D = cfg.v_embed, cfg.hidden, cfg.head_dim
     M = E * cfg.merge ** 2
     patch_w = pad_cols(rn(E, cfg.patch_dim), PATCH_K_PAD)
-    vit = [VitBlockWeights(ones(E), zeros(E), ones(E), zeros(E), rn(3 * E, E), rn(3 * E), rn(E, E), rn(E),
-                           rn(cfg.v_mlp, E), rn(cfg.v_mlp), rn(E, cfg.v_mlp), rn(E)) for _ in range(cfg.v_depth)]
+    if cfg.vision_arch == "qwen2_5_vl":
+        pad, I = cfg.v_mlp_pad, cfg.v_mlp
+
+        def padded(t, dim):          # zero the pad rows / columns (exactly what pack_device_weights produces)
+            if dim == 0:
+                t[I:] = 0
+            else:
+                t[:, I:] = 0
+            return t
+        vit = []
+        for _ in range(cfg.v_depth):
+            g_w, u_w = padded(rn(pad, E), 0), padded(rn(pad, E), 0)
+            g_b, u_b = padded(rn(pad), 0), padded(rn(pad), 0)
+            vit.append(VitBlockWeights(ones(E), None, ones(E), None, rn(3 * E, E), rn(3 * E), rn(E, E), rn(E),
+                                       interleave_gate_up(g_w, u_w),
+                                       interleave_gate_up(g_b.view(-1, 1), u_b.view(-1, 1)).view(-1).contiguous(),
+                                       padded(rn(E, pad), 1), rn(E)))
+    else:
+        vit = [VitBlockWeights(ones(E), zeros(E), ones(E), zeros(E), rn(3 * E, E), rn(3 * E), rn(E, E), rn(E),
+                               rn(cfg.v_mlp, E), rn(cfg.v_mlp), rn(E, cfg.v_mlp), rn(E)) for _ in range(cfg.v_depth)]
     llm = []
     for _ in range(cfg.layers):
         nq = (cfg.heads + 2 * cfg.kv_heads) * D
         llm.append(LlmLayerWeights(ones(H), ones(H), rn(nq, H), rn(nq), rn(H, cfg.heads * D),
                                    rn(2 * cfg.intermediate, H), rn(H, cfg.intermediate)))
-    return DeviceWeights(patch_w, vit, ones(E), zeros(E), rn(M, M), rn(M), rn(H, M), rn(H),
+    return DeviceWeights(patch_w, vit, ones(E), None if cfg.vision_arch == "qwen2_5_vl" else zeros(E), rn(M, M), rn(M), rn(H, M), rn(H),
                          rn(cfg.vocab, H), llm, ones(H), rn(cfg.vocab, H))
 
 
