@@ -76,9 +76,15 @@ def synthetic_prompt(cfg, n_image_tokens: int, n_text: int, seed: int = 99, orde
 
 def prefill_flops(cfg, n_patches: int, S: int) -> float:
     E, M = cfg.v_embed, cfg.v_embed * cfg.merge ** 2
-    vit_gemm = 2.0 * n_patches * (cfg.patch_dim * E + cfg.v_depth * (3 * E * E + E * E + 2 * E * cfg.v_mlp))
+    v25 = getattr(cfg, "vision_arch", "qwen2_vl") == "qwen2_5_vl"
+    mlp_mats = 3 if v25 else 2                                     # SwiGLU: gate, up, down
+    vit_gemm = 2.0 * n_patches * (cfg.patch_dim * E + cfg.v_depth * (3 * E * E + E * E + mlp_mats * E * cfg.v_mlp))
     vit_gemm += 2.0 * (n_patches // cfg.merge ** 2) * (M * M + M * cfg.hidden)
     vit_attn = cfg.v_depth * 4.0 * n_patches * n_patches * E
+    if v25:   # only the v_fullatt blocks attend over the whole image; the others inside windows of <= (v_window/patch)^2 patches
+        win = (cfg.v_window // cfg.patch) ** 2
+        n_full = len([i for i in cfg.v_fullatt if i < cfg.v_depth])
+        vit_attn = 4.0 * n_patches * E * (n_full * n_patches + (cfg.v_depth - n_full) * win)
     D = cfg.head_dim
     per_layer = cfg.hidden * (cfg.heads + 2 * cfg.kv_heads) * D + cfg.heads * D * cfg.hidden \
         + 3 * cfg.hidden * cfg.intermediate
