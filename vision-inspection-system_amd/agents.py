@@ -146,10 +146,17 @@ class VLMInspectorAgent(_BaseAgent):
             self.logger.error(f"Inspector analysis failed: {e}", exc_info=True)
             return self._failure(e)
 
-    def analyze_many(self, image_paths, contexts) -> list:
+    def analyze_many(self, image_paths, contexts, prepared=None) -> list:
         """Batch form of ``analyze`` for clients that can serve several requests with one shared decode loop
-        (LocalVLMClient.complete_many).  Failures stay per image; never raises."""
-        return _many(self, image_paths, contexts)
+        (LocalVLMClient.complete_many).  Failures stay per image; never raises.  ``prepared``: futures from
+        ``prepare_many`` (requests encoded ahead of time on the ingest pool)."""
+        return _many(self, image_paths, contexts, prepared)
+
+    def prepare_many(self, image_paths, contexts) -> list:
+        """Submit the request-side work of every image (open, thumbnail, JPEG q85, base64, prompt) to the ingest pool;
+        returns one future per image for ``analyze_many(..., prepared=)``."""
+        from . import ingest
+        return [ingest.submit(self._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
 
 
 class VLMAuditorAgent(_BaseAgent):
@@ -227,23 +234,31 @@ class VLMAuditorAgent(_BaseAgent):
             self.logger.error(f"Auditor verification failed: {e}", exc_info=True)
             return self._failure(e)
 
-    def verify_many(self, image_paths, contexts, inspector_results=None) -> list:
+    def verify_many(self, image_paths, contexts, inspector_results=None, prepared=None) -> list:
         """Batch form of ``verify`` (see VLMInspectorAgent.analyze_many)."""
-        return _many(self, image_paths, contexts)
+        return _many(self, image_paths, contexts, prepared)
+
+    def prepare_many(self, image_paths, contexts) -> list:
+        from . import ingest
+        return [ingest.submit(self._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
 
 
-def _many(agent, image_paths, contexts) -> list:
-    """Shared body of analyze_many / verify_many: encode every image (failures stay per image), one
+def _many(agent, image_paths, contexts, prepared=None) -> list:
+    """Shared body of analyze_many / verify_many: encode every image on the ingest pool (failures stay per image), one
     ``complete_many`` call when the client offers it (one shared decode loop), per-reply interpretation."""
+    from . import ingest
     results = [None] * len(image_paths)
     todo, msgs = [], []
-    for i, (path, ctx) in enumerate(zip(image_paths, contexts)):
-        try:
-            msgs.append(agent._messages(Path(path), ctx))
+    futs = prepared if prepared is not None else \
+        [ingest.submit(agent._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
+    for i, (path, fut) in enumerate(zip(image_paths, futs)):
+        ok, val = ingest.outcome(fut)
+        if ok:
+            msgs.append(val)
             todo.append(i)
-        except Exception as e:
-            agent.logger.error(f"{agent.nickname}: request for {path} failed: {e}")
-            results[i] = agent._failure(e)
+        else:
+            agent.logger.error(f"{agent.nickname}: request for {path} failed: {val}")
+            results[i] = agent._failure(val)
     if todo:
         try:
             if hasattr(agent.client, "complete_many"):

@@ -33,11 +33,12 @@ logger = logging.getLogger("vision_inspection_system_amd.batch")
 
 
 def _local_batching() -> bool:
-    """True when both agents are served by the local engine (so requests can share one decode loop)."""
+    """True when at least one agent is served by the local engine: its requests then share one decode loop
+    (``complete_many``); an agent on another provider is simply called request by request inside ``_many``."""
     from .config import LOCAL_PROVIDER, get_config
     cfg = get_config()
-    return getattr(cfg, "vlm_inspector_provider", "") == LOCAL_PROVIDER and \
-        getattr(cfg, "vlm_auditor_provider", "") == LOCAL_PROVIDER and os.environ.get("VIS_BATCH_DECODE", "1") != "0"
+    local = LOCAL_PROVIDER in (getattr(cfg, "vlm_inspector_provider", ""), getattr(cfg, "vlm_auditor_provider", ""))
+    return local and os.environ.get("VIS_BATCH_DECODE", "1") != "0"
 
 
 # ----------------------------------------------------------------------------- collective
@@ -229,7 +230,7 @@ def _finish_state(state: Dict[str, Any]) -> Dict[str, Any]:
 
 
 def run_inspections_batched(image_paths: List[str], criticality: str = "medium", domain: Optional[str] = None,
-                            user_notes: Optional[str] = None) -> List[Dict[str, Any]]:
+                            user_notes: Optional[str] = None, prepared: Optional[tuple] = None) -> List[Dict[str, Any]]:
     """Several images through Inspector -> Auditor with ONE shared decode loop per agent (local provider):
     the weights are streamed once per generated token for all images in flight.  Returns one state dict per
     image, same keys as ``run_inspection``.  An image whose batched analysis failed is retried once through the
@@ -247,14 +248,15 @@ def run_inspections_batched(image_paths: List[str], criticality: str = "medium",
                        "failure_history": [], "has_critical_failure": False, "inspector_retry_count": 0,
                        "auditor_retry_count": 0, "current_step": "pending"})
     contexts = [InspectionContext(**s["context"]) for s in states]
-    for res, st in zip(get_inspector().analyze_many(image_paths, contexts), states):
+    insp_prep, aud_prep = prepared if prepared is not None else (None, None)
+    for res, st in zip(get_inspector().analyze_many(image_paths, contexts, prepared=insp_prep), states):
         if res.analysis_failed:
             st["inspector_retry_count"] = 1      # the batched attempt was attempt 1; the node makes the final one
             run_inspector(st)
         else:
             st["current_step"] = "inspector_analysis"
             st["inspector_result"] = res.model_dump()
-    for res, st in zip(get_auditor().verify_many(image_paths, contexts), states):
+    for res, st in zip(get_auditor().verify_many(image_paths, contexts, prepared=aud_prep), states):
         if res.analysis_failed:
             st["auditor_retry_count"] = 1
             run_auditor(st)
@@ -302,9 +304,17 @@ def run_multi_image_inspection(image_paths: List[str], criticality: str = "mediu
     if _inspect is run_inspection and len(my_idx) > 1 and _local_batching():
         try:  # shared-decode fast path; any problem falls back to the per-image loop below
             group = int(os.environ.get("VIS_MAX_BATCH", "64"))
+            # request-side encode of EVERY image of this rank goes to the ingest pool now (ingest.py): groups 2.. are
+            # encoded while the GPU works on group 1.  The prompt depends on (criticality, domain, notes) only.
+            from .agents import get_auditor, get_inspector
+            ctx0 = InspectionContext(image_id="prefetch", criticality=criticality, domain=domain, user_notes=user_notes)
+            my_paths = [image_paths[i] for i in my_idx]
+            insp_f = get_inspector().prepare_many(my_paths, [ctx0] * len(my_paths))
+            aud_f = get_auditor().prepare_many(my_paths, [ctx0] * len(my_paths))
             for g0 in range(0, len(my_idx), group):
                 chunk = my_idx[g0:g0 + group]
-                outs = run_inspections_batched([image_paths[i] for i in chunk], criticality, domain, user_notes)
+                outs = run_inspections_batched([image_paths[i] for i in chunk], criticality, domain, user_notes,
+                                               prepared=(insp_f[g0:g0 + group], aud_f[g0:g0 + group]))
                 pre.update(dict(zip(chunk, outs)))
         except Exception as e:
             logger.error(f"batched inspection failed ({e}); falling back to per-image processing", exc_info=True)

@@ -174,6 +174,18 @@ def _load_mllama(model_id: str, device, max_ctx: int, max_batch: int = 1) -> Opt
     return LoadedModel(MllamaEngine(cfg, w, device, max_ctx=max_ctx, max_batch=max_batch), tok, cfg, model_id, "mllama")
 
 
+def _reply_text(model_id: str, decoded: str) -> str:
+    """Throughput runs on ``synthetic:`` (seeded random) weights generate noise, which would send every image down the
+    agents' failure + retry path (nodes.py retries with back-off) and time THAT instead of the pipeline.  For synthetic
+    models only, VIS_SYNTHETIC_REPLY substitutes a fixed reply text AFTER the full generation has run (tools/ingest_bench.py);
+    real checkpoints are never affected."""
+    if model_id.startswith("synthetic:"):
+        fixed = os.environ.get("VIS_SYNTHETIC_REPLY")
+        if fixed:
+            return fixed
+    return decoded
+
+
 def drop_models() -> None:
     with _ENGINES_LOCK:
         _ENGINES.clear()
@@ -268,17 +280,20 @@ class LocalVLMClient:
         out: List[ChatCompletion] = []
         if lm.family == "mllama":
             return self._complete_mllama_many(lm, batch_of_messages, temp, max_new)
-        prepared = [self._prepare(lm, m) for m in batch_of_messages]
+        # service-side decode (base64 + JPEG) of every request on the ingest pool: group i+1 decodes while group i is
+        # in its decode loop; a request that fails to decode fails the call like a malformed request to the service
+        from . import ingest
+        futs = [ingest.submit(self._prepare, lm, m) for m in batch_of_messages]
         with eng.lock:
-            for i in range(0, len(prepared), eng.max_batch):
-                chunk = prepared[i:i + eng.max_batch]
+            for i in range(0, len(futs), eng.max_batch):
+                chunk = [f.result() for f in futs[i:i + eng.max_batch]]
                 from . import hip
                 reqs = [(ids, [hip.resize_rgb(torch.from_numpy(f).to(eng.device), th, tw) for f, (th, tw) in frames])
                         for ids, frames in chunk]
                 toks = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed,
                                           ignore_eos=os.environ.get("VIS_IGNORE_EOS") == "1")
                 for (ids, _), t in zip(chunk, toks):
-                    out.append(ChatCompletion([_Choice(_Message(tok.decode(t)))], model=model_id,
+                    out.append(ChatCompletion([_Choice(_Message(_reply_text(model_id, tok.decode(t))))], model=model_id,
                                               usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
                                                      "total_tokens": len(ids) + len(t)}))
         return out
@@ -308,7 +323,8 @@ class LocalVLMClient:
         (the agents' health check) take the single-sequence path."""
         import torch
         eng, tok = lm.engine, lm.tokenizer
-        prepared = [self._prepare_mllama(lm, m) for m in batch_of_messages]
+        from . import ingest
+        prepared = [f.result() for f in [ingest.submit(self._prepare_mllama, lm, m) for m in batch_of_messages]]
         toks_out: List[Optional[List[int]]] = [None] * len(prepared)
         ignore_eos = os.environ.get("VIS_IGNORE_EOS") == "1"
         with eng.lock:
@@ -324,7 +340,7 @@ class LocalVLMClient:
                 if f is None:
                     toks_out[i] = eng.generate(ids, None, max_new_tokens=max_new, temperature=temp, seed=self.seed,
                                                stop_on_eos=not ignore_eos)
-        return [ChatCompletion([_Choice(_Message(tok.decode(t)))], model=lm.model_id,
+        return [ChatCompletion([_Choice(_Message(_reply_text(lm.model_id, tok.decode(t))))], model=lm.model_id,
                                usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
                                       "total_tokens": len(ids) + len(t)})
                 for (ids, _), t in zip(prepared, toks_out)]
