@@ -5,6 +5,8 @@ rounded to bf16 once, so the bound is a few bf16 ulps of the output magnitude.
 """
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -793,3 +795,71 @@ def test_splitk_finalize_fused_with_norm_is_bit_identical(hip, device, M, N, K, 
     assert torch.equal(x2, x_ref)
     ref = a.float() @ w.float().t() + res.float() + (bias.float() if ln else 0.0)
     _assert_close(x, ref, atol=3e-2, rtol=2e-2, what="split-K sum")
+
+
+@pytest.mark.parametrize("Hq,Hkv,B,T", [(28, 4, 32, 2560), (32, 8, 16, 768), (2, 1, 3, 256)])
+def test_decode_attn_streaming_form(hip, device, monkeypatch, Hq, Hkv, B, T):
+    """K11, batched streaming form (one workgroup per (kv head, sequence), whole context in one pass, online softmax,
+    no partials / combine): ragged context lengths incl. tile boundaries, against an fp32 reference and against the
+    split + combine form (same arithmetic per key, other summation order: f32-rounding-level agreement), KV append
+    included.  Cross-attention mode (static keys, fused q-norm) the same way."""
+    HD = 128
+    rng = np.random.default_rng(5)
+    ctx = [int(c) for c in rng.integers(1, T - 1, B)]
+    ctx[0], ctx[1] = 63, 64
+    if B > 2:
+        ctx[2] = T - 2
+    kc = _randn((B, Hkv, T, HD), device, 120)
+    vc = _randn((B, Hkv, T, HD), device, 121)
+    g = torch.Generator().manual_seed(122)
+    ang = torch.rand((T, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos_t = emb.cos().to(device).unsqueeze(0).expand(B, -1, -1)
+    sin_t = emb.sin().to(device).unsqueeze(0).expand(B, -1, -1)
+    qkv = _randn((B, (Hq + 2 * Hkv) * HD), device, 123)
+    step = torch.tensor(ctx, dtype=torch.int32, device=device)
+    ns = T // hip.DECODE_KEYS_PER_SPLIT
+    nmax = max(ns, -(-448 // hip.DECODE_KEYS_PER_SPLIT))
+    po = torch.empty(B * Hq * nmax * HD, dtype=torch.float32, device=device)
+    pml = torch.empty(B * Hq * nmax * 2, dtype=torch.float32, device=device)
+    outs, caches = {}, {}
+    for mode in ("2", "0"):            # 2: streaming form forced, 0: split + combine
+        monkeypatch.setenv("VIS_DECODE_ATTN_STREAM", mode)
+        k1, v1 = kc.clone(), vc.clone()
+        out = torch.full((B, Hq * HD), 7.0, dtype=torch.bfloat16, device=device)
+        hip.decode_attn(qkv, cos_t, sin_t, k1, v1, step, po, pml, out, Hq, Hkv, HD, ns, HD ** -0.5)
+        outs[mode], caches[mode] = out.float().cpu(), (k1, v1)
+    assert torch.equal(caches["2"][0], caches["0"][0]) and torch.equal(caches["2"][1], caches["0"][1])     # same append
+    assert (outs["2"] - outs["0"]).abs().max() < 2e-2
+    k1, v1 = caches["2"]
+    G = Hq // Hkv
+    for b in range(B):
+        n = ctx[b] + 1
+        x = qkv[b].float().cpu().reshape(Hq + 2 * Hkv, HD)
+        c, s_ = emb[ctx[b]].cos(), emb[ctx[b]].sin()
+        qr = (x[:Hq] * c + _rotate_half(x[:Hq]) * s_).to(torch.bfloat16).float()
+        kk, vv = k1[b, :, :n].float().cpu(), v1[b, :, :n].float().cpu()
+        ref = torch.stack([torch.softmax((kk[h // G] @ qr[h]) * HD ** -0.5, 0) @ vv[h // G] for h in range(Hq)])
+        _assert_close(outs["2"][b].reshape(Hq, HD), ref, atol=2e-2, rtol=2e-2, what=f"streaming decode attention seq {b}")
+    # cross-attention batch (mllama): static keys per sequence, per-sequence key counts, q-norm inside
+    Tk = 448
+    xk, xv = _randn((B, Hkv, Tk, HD), device, 130), _randn((B, Hkv, Tk, HD), device, 131)
+    q = _randn((B, Hq * HD), device, 132)
+    qn = _randn((HD,), device, 133)
+    nkeys = torch.tensor([int(c) for c in rng.integers(1, Tk, B)], dtype=torch.int32, device=device)
+    xs = -(-Tk // hip.DECODE_KEYS_PER_SPLIT)
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("VIS_DECODE_ATTN_STREAM", mode)
+        out = torch.empty((B, Hq * HD), dtype=torch.bfloat16, device=device)
+        hip.decode_cross_attn_batch(q, qn, xk, xv, nkeys - 1, po, pml, out, Hq, Hkv, HD, xs, HD ** -0.5, 1e-5)
+        res[mode] = out.float().cpu()
+    assert (res["2"] - res["0"]).abs().max() < 2e-2
+    for b in range(min(B, 4)):
+        n = int(nkeys[b])
+        qq = q[b].float().cpu().reshape(Hq, HD)
+        qq = (qq * torch.rsqrt(qq.pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * qn.float().cpu()
+        qq = qq.to(torch.bfloat16).float()
+        kk, vv = xk[b, :, :n].float().cpu(), xv[b, :, :n].float().cpu()
+        ref = torch.stack([torch.softmax((kk[h // G] @ qq[h]) * HD ** -0.5, 0) @ vv[h // G] for h in range(Hq)])
+        _assert_close(res["2"][b].reshape(Hq, HD), ref, atol=2e-2, rtol=2e-2, what=f"streaming cross attention seq {b}")

@@ -14,6 +14,7 @@
 // Reference semantics: TF:models/qwen2_vl/modeling_qwen2_vl.py:96-110 (norm),
 // :459-466 (MLP), :501-556 (attention), greedy = argmax over lm_head logits.
 #include "common.hip.h"
+#include <stdlib.h>
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
@@ -673,6 +674,196 @@ __global__ __launch_bounds__(256) void decode_attn_fused_kernel(DecAttnArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Batched form: ONE workgroup per (kv head, sequence) walks the whole context - no partials in HBM, no combine launch.
+// The split form above needs Hkv x splits x batch workgroups and a second launch; at 64 in-flight sequences that is
+// 16384 short workgroups per layer (each pays its own prologue: rope, q staging, one exposed load round trip) and the KV
+// cache moves at 3.2 TB/s.  Here the 8 waves of a 512-thread workgroup are INDEPENDENT streams: wave w owns the 16-key
+// steps j = w, w + 8, ... of its sequence, with its own online softmax per head and its own share of O in registers, so
+// the loop has no barrier at all (a first version with one 64-key tile per workgroup iteration and two barriers per tile
+// ran at 2.7 TB/s: four waves in lockstep cannot hide their own latencies).  Per step and wave:
+//   loads   : 16 K rows in the MFMA A layout (4 x 16 B per lane) + 16 V rows (two dims per lane), two register sets
+//             (static indexing): the next step's loads are issued before the current step is consumed;
+//   scores  : S^T[key][head] on the MFMA; the 16-key max / sum per head are in-lane + two permlane swaps (no LDS);
+//   P * V   : p[head][key] goes through a wave-private LDS strip (same-wave DS ops are ordered: no barrier) and comes
+//             back as broadcast ds_read_b128; each lane accumulates its two output dims for all G heads.
+// The eight waves' (m, l, O) are merged once at the end through LDS.  Same arithmetic per (head, key) as the split
+// kernel (bf16-rounded rotated q / k, f32 softmax in the log2 domain, f32 P*V); the summation order over keys differs, so
+// the two forms agree to f32 rounding, not bit for bit.
+template <int G>
+__global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, bf16_t* __restrict__ out) {
+  constexpr int HD = 128, HALF = 64, NW = 8;
+  __shared__ __attribute__((aligned(16))) bf16_t q_s[16][HD];   // heads >= G are zero
+  __shared__ __attribute__((aligned(16))) bf16_t knew_s[HD];
+  __shared__ __attribute__((aligned(16))) bf16_t vnew_s[HD];
+  __shared__ __attribute__((aligned(16))) float pbuf[NW][G][16];   // wave-private probabilities of the current step
+  __shared__ float pal[NW][G];                                     // wave-private rescale factors of the current step
+  __shared__ float red_o[NW][G][HD];
+  __shared__ float red_ml[NW][G][2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, h = lane >> 4;
+  const int hkv = blockIdx.x, seq = blockIdx.y;
+  p.qkv += seq * p.qkv_bs;
+  p.k_cache += seq * p.cache_bs;
+  p.v_cache += seq * p.cache_bs;
+  p.cos_t += seq * p.tab_bs;
+  p.sin_t += seq * p.tab_bs;
+  p.step_ptr += seq;
+  out += (size_t)seq * p.Hq * HD;
+  bf16_t* Kh = p.k_cache + (size_t)hkv * p.cache_tokens * HD;
+  bf16_t* Vh = p.v_cache + (size_t)hkv * p.cache_tokens * HD;
+
+  struct StepRegs { u32x4 k[4]; uint32_t v[16]; };
+  auto load_step = [&](StepRegs& r, int j) {          // keys 16 j .. 16 j + 15 (rows clamped: addresses are always valid)
+    const int k0 = j * 16;
+    const int krow = min(k0 + l15, p.cache_tokens - 1);
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) r.k[ds] = *(const u32x4*)(Kh + (size_t)krow * HD + ds * 32 + 8 * h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = min(k0 + i, p.cache_tokens - 1);
+      r.v[i] = *(const uint32_t*)(Vh + (size_t)row * HD + 2 * lane);
+    }
+  };
+  StepRegs r0, r1;
+  load_step(r0, wave);                   // issued before the position has even arrived (fixed rows)
+
+  const int slot = min(*p.step_ptr, p.cache_tokens - 1);
+  const int ctx = slot + 1;
+  const int nsteps = (ctx + 15) >> 4;
+  const bool cross = p.q_norm_w != nullptr;  // workgroup-uniform
+  if (!cross) {
+    const float* cr = p.cos_t + (size_t)slot * HD;
+    const float* sr = p.sin_t + (size_t)slot * HD;
+    for (int it = tid; it < (G + 1) * HALF; it += 512) {
+      const int g = it / HALF, d = it - g * HALF;
+      const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
+      const float a = bf2f(p.qkv[head * HD + d]), b = bf2f(p.qkv[head * HD + HALF + d]);
+      const bf16_t oa = f2bf(a * cr[d] - b * sr[d]);
+      const bf16_t ob = f2bf(b * cr[HALF + d] + a * sr[HALF + d]);
+      bf16_t* dst = (g < G) ? q_s[g] : knew_s;
+      dst[d] = oa;
+      dst[HALF + d] = ob;
+    }
+    for (int it = tid; it < (16 - G) * HD; it += 512) q_s[G + it / HD][it % HD] = 0;
+    if (tid < HD) vnew_s[tid] = p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid];
+    __syncthreads();
+    if (tid < HD) {  // KV-cache append: this workgroup is the only reader and writer of the row in this launch
+      Kh[(size_t)slot * HD + tid] = knew_s[tid];
+      Vh[(size_t)slot * HD + tid] = vnew_s[tid];
+    }
+  } else {
+    for (int g = wave; g < G; g += NW) {
+      const bf16_t* qh = p.qkv + (size_t)(hkv * G + g) * HD;
+      const float a = bf2f(qh[lane]), b = bf2f(qh[lane + 64]);
+      const float ss = wave_sum(a * a + b * b);
+      const float rstd = rsqrtf(ss * (1.0f / HD) + p.q_eps);
+      q_s[g][lane] = f2bf(bf2f(f2bf(a * rstd)) * bf2f(p.q_norm_w[lane]));
+      q_s[g][lane + 64] = f2bf(bf2f(f2bf(b * rstd)) * bf2f(p.q_norm_w[lane + 64]));
+    }
+    for (int it = tid; it < (16 - G) * HD; it += 512) q_s[G + it / HD][it % HD] = 0;
+    if (tid < HD) { knew_s[tid] = 0; vnew_s[tid] = 0; }
+    __syncthreads();
+  }
+  const int new_row = cross ? -1 : slot;   // the cache row whose value may still be only in knew_s / vnew_s
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(&q_s[l15][ds * 32 + 8 * h]);
+  const uint32_t vnew = *(const uint32_t*)(&vnew_s[2 * lane]);
+  float acc0[G], acc1[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
+  float m_run = -1.0e30f, l_run = 0.f;     // of head l15 (identical in the four lanes l15, l15 + 16, + 32, + 48)
+
+  auto step = [&](StepRegs& r, int j) {
+    const int k0 = j * 16;
+    // ---- scores: acc[e] = S^T[key = k0 + 4 h + e][head = l15]
+    const bool is_new = (k0 + l15 == new_row);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      u32x4 kv = r.k[ds];
+      const u32x4 nv = *(const u32x4*)(&knew_s[ds * 32 + 8 * h]);
+      if (is_new) kv = nv;
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, kv), qf[ds], acc, 0, 0, 0);
+    }
+    float sv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sv[e] = (k0 + 4 * h + e < ctx) ? acc[e] * p.scale_log2 : -1.0e30f;
+    const float mx = hmax4(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
+    const float m_new = fmaxf(m_run, mx);
+    const float al = exp2f(m_run - m_new);
+    m_run = m_new;
+    float pe[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pe[e] = exp2f(sv[e] - m_new);
+    l_run = l_run * al + hsum4((pe[0] + pe[1]) + (pe[2] + pe[3]));
+    if (l15 < G) {
+      *(f32x4*)(&pbuf[wave][l15][4 * h]) = (f32x4){pe[0], pe[1], pe[2], pe[3]};
+      if (h == 0) pal[wave][l15] = al;
+    }
+    // ---- O[g][d] = O[g][d] * alpha[g] + sum_key p[g][key] V[key][d]; lane owns d = 2 lane, 2 lane + 1
+    float v0[16], v1[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const uint32_t raw = (k0 + i == new_row) ? vnew : r.v[i];
+      v0[i] = __uint_as_float(raw << 16);
+      v1[i] = __uint_as_float(raw & 0xffff0000u);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const float ag = pal[wave][g];
+      float a0 = acc0[g] * ag, a1 = acc1[g] * ag;
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 pw = *(const f32x4*)(&pbuf[wave][g][4 * q4]);      // broadcast read: keys k0 + 4 q4 .. + 3
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          a0 += pw[e] * v0[4 * q4 + e];      // keys past the context carry p = 0 (masked scores)
+          a1 += pw[e] * v1[4 * q4 + e];
+        }
+      }
+      acc0[g] = a0;
+      acc1[g] = a1;
+      __builtin_amdgcn_sched_barrier(0);   // one head at a time: hoisting all heads' p reads costs 100+ VGPRs (spills)
+    }
+  };
+
+  // wave w: steps w, w + 8, w + 16, ...; two register sets alternate (static indexing): the loads of the next step are
+  // in flight while the current one is consumed, and two waves share each SIMD
+  for (int j = wave; j < nsteps; j += 2 * NW) {
+    if (j + NW < nsteps) load_step(r1, j + NW);
+    step(r0, j);
+    if (j + NW < nsteps) {
+      if (j + 2 * NW < nsteps) load_step(r0, j + 2 * NW);
+      step(r1, j + NW);
+    }
+  }
+
+  // ---- merge the eight waves
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    red_o[wave][g][2 * lane] = acc0[g];
+    red_o[wave][g][2 * lane + 1] = acc1[g];
+  }
+  if (h == 0 && l15 < G) { red_ml[wave][l15][0] = m_run; red_ml[wave][l15][1] = l_run; }
+  __syncthreads();
+  for (int i = tid; i < G * HD; i += 512) {
+    const int g = i / HD, d = i - g * HD;
+    float M = red_ml[0][g][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, red_ml[w][g][0]);
+    float o = 0.f, l = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float wt = exp2f(red_ml[w][g][0] - M);
+      o += wt * red_o[w][g][d];
+      l += wt * red_ml[w][g][1];
+    }
+    out[(size_t)(hkv * G + g) * HD + d] = f2bf(l > 0.f ? o / l : 0.f);
+  }
+}
+
 // merge the per-split partials of one query head (only the splits that ran): 256 threads = 128 dims x 2
 // split-halves; the first partial loads are issued before the position is known
 #define CB_PRE 32   // partial rows preloaded per thread: covers 64 splits = 4096 cached keys
@@ -733,6 +924,22 @@ __global__ __launch_bounds__(256) void decode_attn_combine_kernel(const float* _
 static int decode_attn_launch(const DecAttnArgs& p, void* out, int batch, hipStream_t stream) {
   const int G = p.Hq / p.Hkv;
   vis_clear_error();
+  // Enough (kv head, sequence) pairs to fill the chip on their own: the streaming form - one workgroup per pair, the
+  // whole context in one pass, no partials, no combine.  VIS_DECODE_ATTN_STREAM=0 keeps the split form (A/B).
+  // (read per launch - not cached - so that a test can compare both forms in one process; graph capture bakes it in)
+  const char* se = getenv("VIS_DECODE_ATTN_STREAM");
+  const int stream_env = se ? atoi(se) : 1;
+  if (stream_env == 2 || (stream_env && p.Hkv * batch >= 128)) {   // 2: force (tests at small batch)
+    const dim3 grid(p.Hkv, batch), block(512);
+    switch (G) {
+      case 1: hipLaunchKernelGGL(decode_attn_stream_kernel<1>, grid, block, 0, stream, p, (bf16_t*)out); break;
+      case 2: hipLaunchKernelGGL(decode_attn_stream_kernel<2>, grid, block, 0, stream, p, (bf16_t*)out); break;
+      case 4: hipLaunchKernelGGL(decode_attn_stream_kernel<4>, grid, block, 0, stream, p, (bf16_t*)out); break;
+      case 7: hipLaunchKernelGGL(decode_attn_stream_kernel<7>, grid, block, 0, stream, p, (bf16_t*)out); break;
+      default: hipLaunchKernelGGL(decode_attn_stream_kernel<8>, grid, block, 0, stream, p, (bf16_t*)out); break;
+    }
+    return vis_check_launch();
+  }
   const dim3 grid(p.Hkv, p.nsplit, batch), block(256);
   switch (G) {
     case 1: hipLaunchKernelGGL(decode_attn_fused_kernel<1>, grid, block, 0, stream, p); break;
