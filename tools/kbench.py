@@ -130,7 +130,7 @@ def main():
     t = timeit(lambda: b.copy_(a))
     res["torch_copy_1GiB"] = {"ms": t * 1e3, "GBs": 2 * a.numel() * 4 / t / 1e9}
 
-    for k_, v in res.items():
+    for k_, v in res.items():  # noqa
         print(f"{k_:24s} " + "  ".join(f"{kk}={vv:9.3f}" for kk, vv in v.items()))
     if args.out:
         with open(args.out, "w") as f:
