@@ -48,6 +48,7 @@ struct GemmArgs {
   float* part;
   int ksplit, out_f32;
   int wide;   // host-checked alignment preconditions of gemm_epilogue_wide hold
+  int nt;     // wide epilogue: non-temporal C stores (the output does not displace the operand tiles other workgroups re-read from L2)
 };
 
 // exact-erf GELU (merger only: 1225 x 5120 elements per image).  Deliberately NOT inlined: erff expands to ~60
@@ -152,66 +153,84 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& p, f32x4 (&acc)[
 // (slot maps chosen so that the ds_write_b64 / b128 lane groups and the ds_read_b128 lane groups hit distinct banks).
 // DS operations of one wave execute in order, so no barrier is needed between a wave's writes and its own reads.
 // Preconditions (checked on the host, p.wide): N % 8 == 0, ldc % 8 == 0, ldr % 8 == 0, C / R 16-byte aligned.
+// the C stores of the wide epilogue (timing probes swap the policy: tools/probes/gemm_probe.sh)
+#if defined(GEMM_PROBE) && GEMM_PROBE == 3
+#define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#elif defined(GEMM_PROBE) && GEMM_PROBE == 4
+#define EPI_STORE(ptr, val) do { if (p.M < 0) *(ptr) = (val); } while (0)
+#else
+#define EPI_STORE(ptr, val) do { if (p.nt) __builtin_nontemporal_store((val), (ptr)); else *(ptr) = (val); } while (0)
+#endif
 template <int ACT, int MI, int NT>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4 (&acc)[MI][NT], int mbase, int nbase,
                                                    int lane, char* st) {
   const int l15 = lane & 15, h = lane >> 4;
+  // Bias of the lane's four consecutive columns in each 16-column block: ONE 8-byte load per block, all NT issued
+  // together before anything else (r02 timeline probe: a load + wait inside every (row block, column block) step
+  // was 32 dependent L2 round trips = 4 us of a 7 us epilogue).  Columns beyond N are never stored: the address is
+  // clamped, the value unused.  Without a bias the adds are skipped by a uniform branch around the whole loop nest.
+  f32x4 bia[NT];
+  const bool has_b = p.bias != nullptr;
+  if (has_b) {
+    u32x2 raw[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) raw[j] = *(const u32x2*)(p.bias + min(nbase + j * 16 + 4 * h, p.N - 4));
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bia[j][0] = __uint_as_float(raw[j][0] << 16); bia[j][1] = __uint_as_float(raw[j][0] & 0xffff0000u);
+      bia[j][2] = __uint_as_float(raw[j][1] << 16); bia[j][3] = __uint_as_float(raw[j][1] & 0xffff0000u);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bia[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   if constexpr (ACT == ACT_SWIGLU) {
     static_assert(NT % 2 == 0, "gate/up pairs");
+    // staging: 64-byte rows (the 8 NT output columns), chunk c of row r at slot c ^ ((r >> 2) & 3); row = i * 16 + l15
+    int woff[NT / 2];
+#pragma unroll
+    for (int j = 0; j < NT; j += 2)
+      woff[j >> 1] = l15 * 64 + ((((j >> 1) * 2 + (h >> 1)) ^ ((l15 >> 2) & 3)) << 4) + (h & 1) * 8;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-      const int row = i * 16 + l15;
 #pragma unroll
-      for (int j = 0; j < NT; j += 2) {
-        float v[4], bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
-        const int n = nbase + j * 16 + 4 * h;
-        if (p.bias && n < p.N) {   // interleaved like the weight rows: gate biases at n .. n+3, up biases 16 further
-          const u32x2 b0 = *(const u32x2*)(p.bias + n), b1 = *(const u32x2*)(p.bias + n + 16);
-          bg[0] = __uint_as_float(b0[0] << 16); bg[1] = __uint_as_float(b0[0] & 0xffff0000u);
-          bg[2] = __uint_as_float(b0[1] << 16); bg[3] = __uint_as_float(b0[1] & 0xffff0000u);
-          bu[0] = __uint_as_float(b1[0] << 16); bu[1] = __uint_as_float(b1[0] & 0xffff0000u);
-          bu[2] = __uint_as_float(b1[1] << 16); bu[3] = __uint_as_float(b1[1] & 0xffff0000u);
-        }
+      for (int j = 0; j < NT; j += 2) {   // interleaved like the weight rows: gate block j, up block j + 1
+        float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = silu_fast(acc[i][j][r] + bg[r]) * (acc[i][j + 1][r] + bu[r]);
+        for (int r = 0; r < 4; ++r)
+          v[r] = has_b ? silu_fast(acc[i][j][r] + bia[j][r]) * (acc[i][j + 1][r] + bia[j + 1][r])
+                       : silu_fast(acc[i][j][r]) * acc[i][j + 1][r];
         u32x2 o;
         o[0] = pack2bf(v[0], v[1]);
         o[1] = pack2bf(v[2], v[3]);
-        const int c = (j >> 1) * 2 + (h >> 1);                       // 16-byte chunk of the 64-byte staging row
-        *(u32x2*)(st + row * 64 + ((c ^ ((row >> 2) & 3)) << 4) + (h & 1) * 8) = o;
+        *(u32x2*)(st + i * 1024 + woff[j >> 1]) = o;
       }
     }
-    const int ocol0 = (nbase >> 1);
-    const int cvalid = NT;                                           // NT/2 pairs x 16 columns = 2 NT / 2 chunks
-#pragma unroll 2
+    const int rr = lane >> 2, c = lane & 3;                          // 16 rows x 4 chunks per pass
+    const int oc = (nbase >> 1) + c * 8;
+    const int roff = rr * 64 + ((c ^ ((rr >> 2) & 3)) << 4);         // (it * 16 + rr) >> 2 & 3 == (rr >> 2) & 3
+    const int rows_ok = (c < NT && oc * 2 < p.N) ? p.M - mbase - rr : 0;   // row it * 16 + rr is valid iff it * 16 < rows_ok
+    bf16_t* cp = p.C + (size_t)(mbase + rr) * p.ldc + oc;
+    const size_t cstep = (size_t)16 * p.ldc;
+#pragma unroll
     for (int it = 0; it < MI; ++it) {
-      const int row = it * 16 + (lane >> 2), c = lane & 3;
-      const int m = mbase + row, oc = ocol0 + c * 8;
-      if (c < cvalid && m < p.M && oc * 2 < p.N) {
-        const u32x4 o = *(const u32x4*)(st + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
-        *(u32x4*)(p.C + (size_t)m * p.ldc + oc) = o;
-      }
+      const u32x4 o = *(const u32x4*)(st + it * 1024 + roff);
+      if (it * 16 < rows_ok) EPI_STORE((u32x4*)(cp + it * cstep), o);
     }
     return;
   } else {
     const bool has_r = p.R != nullptr;
     if (!has_r) {
+      // staging: 128-byte rows, chunk c of row r at slot c ^ ((r >> 1) & 7); row = i * 16 + l15 -> (r >> 1) & 7 = l15 >> 1
+      int woff[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) woff[j] = l15 * 128 + (((j * 2 + (h >> 1)) ^ ((l15 >> 1) & 7)) << 4) + (h & 1) * 8;
 #pragma unroll
       for (int i = 0; i < MI; ++i) {
-        const int row = i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const int n = nbase + j * 16 + 4 * h;
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-          if (p.bias && n < p.N) {
-            const u32x2 b = *(const u32x2*)(p.bias + n);
-            v[0] += __uint_as_float(b[0] << 16);
-            v[1] += __uint_as_float(b[0] & 0xffff0000u);
-            v[2] += __uint_as_float(b[1] << 16);
-            v[3] += __uint_as_float(b[1] & 0xffff0000u);
-          }
+          f32x4 v = acc[i][j];
+          if (has_b) v += bia[j];
           if constexpr (ACT != ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], ACT);
@@ -219,58 +238,61 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& p, f32x4 (&ac
           u32x2 o;
           o[0] = pack2bf(v[0], v[1]);
           o[1] = pack2bf(v[2], v[3]);
-          const int c = j * 2 + (h >> 1);
-          *(u32x2*)(st + row * 128 + ((c ^ ((row >> 1) & 7)) << 4) + (h & 1) * 8) = o;
+          *(u32x2*)(st + i * 2048 + woff[j]) = o;
         }
       }
-#pragma unroll 2
+      const int rr = lane >> 3, c = lane & 7;                        // 8 rows x 8 chunks per pass
+      const int n = nbase + c * 8;
+      // row it * 8 + rr: ((row >> 1) & 7) = (it * 4 + (rr >> 1)) & 7 -> two slot patterns (it even / odd)
+      const int roff0 = rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4), roff1 = rr * 128 + ((c ^ ((4 + (rr >> 1)) & 7)) << 4);
+      const int rows_ok = (c < 2 * NT && n < p.N) ? p.M - mbase - rr : 0;
+      bf16_t* cp = p.C + (size_t)(mbase + rr) * p.ldc + n;
+      const size_t cstep = (size_t)8 * p.ldc;
+#pragma unroll
       for (int it = 0; it < 2 * MI; ++it) {
-        const int row = it * 8 + (lane >> 3), c = lane & 7;
-        const int m = mbase + row, n = nbase + c * 8;
-        if (c < 2 * NT && m < p.M && n < p.N) {
-          const u32x4 o = *(const u32x4*)(st + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
-          *(u32x4*)(p.C + (size_t)m * p.ldc + n) = o;
-        }
+        const u32x4 o = *(const u32x4*)(st + it * 1024 + ((it & 1) ? roff1 : roff0));
+        if (it * 8 < rows_ok) EPI_STORE((u32x4*)(cp + it * cstep), o);
       }
       return;
     }
-    // residual: f32 staging, 64 rows at a time
+    // residual: f32 staging, 64 rows at a time (256-byte rows, chunk c at slot c ^ (r & 15)); the residual rows of a
+    // half are requested (8 x 16 bytes per lane) BEFORE the half's accumulators are staged, so their latency is paid once
+    const int rr = lane >> 3, g = lane & 7;
+    const int n = nbase + g * 8;
+    const int rows_ok = (g < 2 * NT && n < p.N) ? p.M - mbase - rr : 0;
+    int woff[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) woff[j] = l15 * 256 + (((j * 4 + h) ^ l15) << 4);
 #pragma unroll
     for (int hm = 0; hm < MI / 4; ++hm) {
+      u32x4 res[8];
+      const bf16_t* rp = p.R + (size_t)(mbase + hm * 64 + rr) * p.ldr + n;
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        res[it] = (hm * 64 + it * 8 < rows_ok) ? *(const u32x4*)(rp + (size_t)it * 8 * p.ldr) : (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int row = i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const int n = nbase + j * 16 + 4 * h;
           f32x4 v = acc[hm * 4 + i][j];
-          if (p.bias && n < p.N) {
-            const u32x2 b = *(const u32x2*)(p.bias + n);
-            v[0] += __uint_as_float(b[0] << 16);
-            v[1] += __uint_as_float(b[0] & 0xffff0000u);
-            v[2] += __uint_as_float(b[1] << 16);
-            v[3] += __uint_as_float(b[1] & 0xffff0000u);
-          }
+          if (has_b) v += bia[j];
           if constexpr (ACT != ACT_NONE) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], ACT);
           }
-          const int c = j * 4 + h;                                    // 16-byte chunk (4 floats) of the 256-byte row
-          *(f32x4*)(st + row * 256 + ((c ^ (row & 15)) << 4)) = v;
+          *(f32x4*)(st + i * 4096 + woff[j]) = v;
         }
       }
-#pragma unroll 2
+      bf16_t* cp = p.C + (size_t)(mbase + hm * 64 + rr) * p.ldc + n;
+#pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int row = it * 8 + (lane >> 3), g = lane & 7;
-        const int m = mbase + hm * 64 + row, n = nbase + g * 8;
-        if (g < 2 * NT && m < p.M && n < p.N) {
-          const f32x4 a = *(const f32x4*)(st + row * 256 + (((2 * g) ^ (row & 15)) << 4));
-          const f32x4 b = *(const f32x4*)(st + row * 256 + (((2 * g + 1) ^ (row & 15)) << 4));
-          float f[8];
-          unpack8(*(const u32x4*)(p.R + (size_t)m * p.ldr + n), f);
-          float v[8] = {a[0] + f[0], a[1] + f[1], a[2] + f[2], a[3] + f[3], b[0] + f[4], b[1] + f[5], b[2] + f[6], b[3] + f[7]};
-          *(u32x4*)(p.C + (size_t)m * p.ldc + n) = pack8(v);
-        }
+        const int row = it * 8 + rr;
+        const f32x4 a = *(const f32x4*)(st + row * 256 + (((2 * g) ^ (row & 15)) << 4));
+        const f32x4 b = *(const f32x4*)(st + row * 256 + (((2 * g + 1) ^ (row & 15)) << 4));
+        float f[8];
+        unpack8(res[it], f);
+        float v[8] = {a[0] + f[0], a[1] + f[1], a[2] + f[2], a[3] + f[3], b[0] + f[4], b[1] + f[5], b[2] + f[6], b[3] + f[7]};
+        if (hm * 64 + it * 8 < rows_ok) EPI_STORE((u32x4*)(cp + (size_t)it * 8 * p.ldc), pack8(v));
       }
     }
   }
@@ -744,8 +766,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256xN_kernel(GemmArgs p) {
 #define G5_B1 2
 #define G5_A1 3
 
+// Timeline probe (tools/probes/gemm_probe.sh builds this file with -DGEMM_PROBE; never in the product build): per workgroup
+// the 100 MHz clock at entry / main-loop start / main-loop end / stores issued / stores landed, and where it ran.
+#ifdef GEMM_PROBE
+__device__ unsigned long long g_gemm_probe[4096 * 8];
+#define GP_STAMP(i) do { if (threadIdx.x == 0) g_gemm_probe[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GP_WHERE() do { if (threadIdx.x == 0) { g_gemm_probe[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4); \
+                                              g_gemm_probe[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+extern "C" int vis_gemm_probe_read(void* dst, int n_u64) {
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_gemm_probe), (size_t)n_u64 * 8) == hipSuccess ? 0 : 2;
+}
+#else
+#define GP_STAMP(i) do { } while (0)
+#define GP_WHERE() do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char lds5[];
+  GP_STAMP(0); GP_WHERE();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -877,6 +915,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p
   G5_BAR();
   if (wr == 1) G5_BAR();   // stagger: group 1 runs one barrier behind group 0
 
+  GP_STAMP(1);
   int t = 0;
   for (; t + 1 < nk; t += 2) {
     G5_TILE(0, t, 1, G5_A1, t + 1, 0, G5_B0, t + 2, 0, G5_A0, t + 2, 0, G5_B1, t + 2);
@@ -885,6 +924,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p
   if (t < nk) G5_TILE(0, t, 1, G5_A1, t + 1, 0, G5_B0, t + 2, 0, G5_A0, t + 2, 0, G5_B1, t + 2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // redundant trailing stages
   if (wr == 0) G5_BAR();   // pay the stagger back: every wave has now executed the same number of barriers
+  GP_STAMP(2);
 #undef G5_TILE
 #undef G5_MFMA
 #undef G5_BAR
@@ -909,7 +949,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p
     // fragments a slower wave has yet to read: one more barrier for everyone, then the buffers are staging space
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#if defined(GEMM_PROBE) && GEMM_PROBE == 2   // every workgroup stores to tile (0, 0): no HBM write traffic
+    gemm_epilogue_wide_dispatch<8, 4>(p, acc, wr * 128, wc * 64, lane, lds5 + wave * 16384);
+#else
     gemm_epilogue_wide_dispatch<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane, lds5 + wave * 16384);
+#endif
+    GP_STAMP(3);
+#ifdef GEMM_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP_STAMP(4);
+#endif
     return;
   }
 #pragma unroll
@@ -1445,6 +1494,8 @@ extern "C" int vis_gemm_bf16(const void* A, const void* W, const void* bias, con
   static const int wide_env = [] { const char* e = getenv("VIS_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0: direct epilogue (A/B)
   p.wide = wide_env && N % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && !(((uintptr_t)C | (uintptr_t)R) & 15) &&
            !(act == ACT_SWIGLU && N % 16 != 0);
+  static const int nt_env = [] { const char* e = getenv("VIS_GEMM_NT"); return e ? atoi(e) : 1; }();   // 0 never, 1 by size, 2 always (A/B)
+  p.nt = nt_env == 2 || (nt_env == 1 && (size_t)M * (act == ACT_SWIGLU ? N / 2 : N) * 2 >= ((size_t)64 << 20));
   vis_clear_error();
   const int st = gemm_dispatch(p, stream);
   return st != VIS_OK ? st : vis_check_launch();
@@ -1472,7 +1523,7 @@ static int gemm_splitk_launch(const void* A, const void* W, const void* bias, co
   GemmArgs p;
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R; p.C = (bf16_t*)C;
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
-  p.part = (float*)work; p.ksplit = ksplit; p.out_f32 = 0; p.wide = 0;
+  p.part = (float*)work; p.ksplit = ksplit; p.out_f32 = 0; p.wide = 0; p.nt = 0;
   p.tiles_m = (M + GEMM4_B - 1) / GEMM4_B;
   p.tiles_n = (N + GEMM4_B - 1) / GEMM4_B;
   vis_clear_error();
