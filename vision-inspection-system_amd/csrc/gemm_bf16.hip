@@ -1391,20 +1391,29 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
   const int t2 = ((M + GEMM2_BM - 1) / GEMM2_BM) * tn1;
   const int tm4 = (M + GEMM4_B - 1) / GEMM4_B, tn4 = (N + GEMM4_B - 1) / GEMM4_B;
   const int t4 = tm4 * tn4, last = t4 % 256;
-  const bool big = forced ? (forced == 2) : (K >= 2048 && t2 >= 200 && t2 <= 256);
+  const bool big = forced == 2;   // the 3-stage 256x128 kernel: A/B only
   static const int pp_env = [] { const char* e = getenv("VIS_GEMM_PP"); return e ? atoi(e) : 1; }();   // 0: the 2-phase kernel (A/B)
   const bool use_pp = (pp_env != 0 && forced != 4) || forced == 7;
-  bool huge = forced ? (forced == 4 || forced == 7) : (!big && K >= 1024 && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128));
+  // Kernel choice by a two-line cost model fitted to cold-cache timings of the production shapes (tools/gemm_tiles_ab.py,
+  // r02): a 256x256 ping-pong tile costs ~1.41 us per 64-wide K-step + 4.3 us (prologue + epilogue), one per CU; a
+  // 128x128 tile ~1.2 us per K-step + 3 us with two per CU.  Rounds are what ragged grids pay for:
+  //   ViT qkv  4900x3840x1280: 300 tiles of 256^2 = 2 rounds (66 us) beat 1170 of 128^2 = 3 rounds (78 us);
+  //   LLM qkv  2249x4608x3584: 162 tiles of 256^2 on 63 % of the CUs (83 us) still beat 216 tiles of 256x192 (90 us);
+  //   LLM o    2249x3584x3584: 504 tiles of 128^2 = one full round of two per CU (75 us) beat 252 of 256x128 (85 us).
+  // Every kernel accumulates K in the same order, so the choice (which depends on M) never changes a result bit.
+  const int nk64 = K / GEMM_BK;
+  const int t1 = ((M + GEMM_BM - 1) / GEMM_BM) * tn1;
+  const float cost1 = (float)((t1 + 511) / 512) * (1.2f * nk64 + 3.0f);
+  const float cost4 = (float)((t4 + 255) / 256) * (1.41f * nk64 + 4.3f);
+  bool huge = forced ? (forced == 4 || forced == 7) : (K >= 256 && M > 128 && N > 128 && cost4 < cost1);
   int cols4 = tn4;  // 256-wide tile columns given to the 256x256 kernel
-  if (!forced && !big && !huge && K >= 1024 && M >= 1024 && t4 >= 768) {
-    cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only
+  if (!forced && K >= 1024 && M >= 1024 && t4 >= 768 && last != 0 && last < 128) {
+    cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only; the ragged remainder columns go through this function again
     huge = cols4 > 0;
   }
-  // 256 x 192 / 256 x 128 forms of the pipelined kernel: one (nearly) full round of 256 workgroups
-  const int t3 = tm4 * ((N + 191) / 192), t2n = tm4 * tn1;
-  const bool nt3 = forced ? (forced == 6) : (!huge && p.act != ACT_SWIGLU && K >= 1024 && M >= 1024 && t3 >= 200 && t3 <= 256 &&
-                                             !(t2n >= 200 && t2n <= 256));
-  const bool nt2 = forced ? (forced == 5) : big;   // the pipelined 256x128 form beat the 3-stage kernel by 3-5 %
+  // 256 x 192 / 256 x 128 forms of the 2-phase pipelined kernel: A/B only (r02: never the fastest on a production shape)
+  const bool nt3 = forced == 6;
+  const bool nt2 = forced == 5;
   if (nt3 || nt2) {
     static const bool attr_ok = [] {
       return hipFuncSetAttribute((const void*)gemm_bf16_256xN_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
