@@ -282,3 +282,88 @@ def test_batched_agent_calls_use_the_ingest_pool_and_keep_failures_per_image(moc
         res2 = getattr(agent, call)(paths, ctxs, prepared=futs)
         assert [r.analysis_failed for r in res2] == [False, False, True, False, False]
         assert res2[0].defects[0].type == "crack"
+
+
+def test_encode_is_shared_between_the_agents_when_the_bytes_are_the_same(tmp_path, monkeypatch):
+    """Inspector and Auditor encode the same file; for an image within the Auditor's 1024 px limit that is not in mode LA the
+    bytes are identical, so the second request takes the first one's result (image_processing encode cache).  A different
+    thumbnail decision or conversion is a different key; a rewritten file is a different key; the 10 MB refusal is the
+    caller's own (applied on the cached path too)."""
+    from vision_inspection_system_amd import image_processing as IP
+    IP.clear_encode_cache()
+    calls = []
+    real = IP._encode
+    monkeypatch.setattr(IP, "_encode", lambda *a: (calls.append(a[1:3]), real(*a))[1])
+    rng = np.random.default_rng(3)
+    small, big, la = tmp_path / "s.png", tmp_path / "b.png", tmp_path / "la.png"
+    Image.fromarray(rng.integers(0, 256, (300, 200, 3), dtype=np.uint8)).save(small)
+    Image.fromarray(rng.integers(0, 256, (1200, 300, 3), dtype=np.uint8)).save(big)
+    Image.fromarray(rng.integers(0, 256, (60, 40, 2), dtype=np.uint8), mode="LA").save(la)
+    insp = dict(max_size=2048, convert_la=True, enforce_limit=True)
+    aud = dict(max_size=1024, convert_la=False, enforce_limit=False)
+    a, b = IP.encode_image_optimized(small, **insp), IP.encode_image_optimized(small, **aud)
+    assert a == b and len(calls) == 1                       # shared
+    assert IP.encode_image_optimized(big, **insp) != IP.encode_image_optimized(big, **aud) and len(calls) == 3   # 1200 > 1024
+    IP.encode_image_optimized(la, **insp)
+    with pytest.raises(OSError):                            # PIL cannot write LA as JPEG: the Auditor's own (reference) behaviour
+        IP.encode_image_optimized(la, **aud)
+    assert len(calls) == 5
+    # same path, new content -> new key
+    import os
+    Image.fromarray(rng.integers(0, 256, (300, 200, 3), dtype=np.uint8)).save(small)
+    os.utime(small, ns=(1, 1))
+    c = IP.encode_image_optimized(small, **insp)
+    assert c != a and len(calls) == 6
+    # the size refusal is per caller, also when the bytes come from the cache
+    IP.clear_encode_cache()
+    monkeypatch.setattr(IP, "_encode", lambda *a: ("data:image/jpeg;base64,AAAA", 10_000_001))
+    assert IP.encode_image_optimized(small, **aud).endswith("AAAA")
+    with pytest.raises(ValueError, match="too large"):
+        IP.encode_image_optimized(small, **insp)
+    # switched off
+    monkeypatch.setenv("VIS_ENCODE_CACHE_MB", "0")
+    n = []
+    monkeypatch.setattr(IP, "_encode", lambda *a: (n.append(1), ("x", 1))[1])
+    IP.encode_image_optimized(small, **aud); IP.encode_image_optimized(small, **aud)
+    assert len(n) == 2
+    IP.clear_encode_cache()
+
+
+def test_streaming_client_gets_the_encode_futures_and_failures_stay_per_image(mock_cfg, tmp_path):
+    """A client that sets accepts_futures (LocalVLMClient) is handed the prepare_many futures themselves and answers a
+    failed request with the exception in its place; the agent turns exactly that one into analysis_failed."""
+    from concurrent.futures import Future
+    from vision_inspection_system_amd.agents import VLMInspectorAgent
+    from vision_inspection_system_amd.schemas import InspectionContext
+    paths = []
+    for i in range(4):
+        p = tmp_path / f"im{i}.png"
+        if i != 1:
+            Image.fromarray(np.full((40, 40, 3), 50 * i, dtype=np.uint8)).save(p)
+        paths.append(p)
+    seen = {}
+
+    class StreamingClient:
+        accepts_futures = True
+
+        def complete_many(self, model, batch, temperature=None, max_tokens=None):
+            seen["futures"] = all(isinstance(m, Future) for m in batch)
+            out = []
+            for j, m in enumerate(batch):
+                try:
+                    m.result()
+                except Exception as e:
+                    out.append(e)
+                    continue
+                if j == 3:
+                    out.append(ValueError("decode failed"))
+                    continue
+                out.append(type("R", (), {"choices": [type("C", (), {"message": type("M", (), {"content": GOOD_REPLY})()})()]})())
+            return out
+
+    agent = VLMInspectorAgent()
+    agent.client = StreamingClient()
+    res = agent.analyze_many(paths, [InspectionContext(image_id=f"i{i}", criticality="medium") for i in range(4)])
+    assert seen["futures"] is True
+    assert [r.analysis_failed for r in res] == [False, True, False, True]
+    assert "decode failed" in res[3].failure_reason

@@ -138,3 +138,44 @@ def test_batch_inspection_with_mllama_auditor(local_cfg, images):
     for v in out["image_results"].values():
         assert v["completed"] is True and v["auditor_result"] is not None and v["consensus"] is not None
         assert v["safety_verdict"]["verdict"] in ("SAFE", "UNSAFE", "REQUIRES_HUMAN_REVIEW")
+
+
+def test_batch_with_an_unreadable_image_streams_the_rest(local_cfg, images, tmp_path):
+    """run_batch_inspection hands the encode futures straight to the local client (agents.prepare_many -> complete_many):
+    a file that cannot be opened fails alone (analysis_failed -> GATE_0 -> UNSAFE), the other images are served by the
+    shared decode loop, order is kept."""
+    from vision_inspection_system_amd import nodes
+    from vision_inspection_system_amd.batch import run_batch_inspection
+    nodes._sleep = lambda s: None
+    bad = tmp_path / "broken.png"
+    bad.write_bytes(b"this is not a png")
+    paths = [images[0], str(bad), images[1], images[2]]
+    out = run_batch_inspection(paths, "medium", "general")
+    res = list(out["image_results"].values())
+    assert [v["image_path"] for v in res] == paths
+    assert res[1]["inspector_result"]["analysis_failed"] is True and res[1]["safety_verdict"]["verdict"] == "UNSAFE"
+    assert out["session_results"]["total_images"] == 4 and all(v["completed"] for v in res)
+
+
+def test_streamed_batch_replies_equal_single_requests(local_cfg, images):
+    """complete_many fed with Futures of messages (the streaming form) returns the same replies as one
+    chat.completions.create per request (first token exact; greedy continuation up to batched-vs-GEMV near-ties is
+    covered at engine level, here the reply of the same request in two places of the batch must be identical)."""
+    from vision_inspection_system_amd import ingest
+    from vision_inspection_system_amd.agents import VLMInspectorAgent
+    agent = VLMInspectorAgent()
+    paths = [images[0], images[1], images[0]]
+
+    def request(path):      # a short prompt (the tiny model's context is 1024 byte-tokens), the agent's own image encode
+        return [{"role": "user", "content": [{"type": "text", "text": "Inspect this part."},
+                                             {"type": "image_url", "image_url": {"url": agent._encode_image_optimized(path)}}]}]
+
+    futs = [ingest.submit(request, p) for p in paths]
+    replies = agent.client.complete_many(agent.model_id, futs, 0.0, agent.max_tokens)      # greedy: sampling seeds are per slot
+    eager = agent.client.complete_many(agent.model_id, [f.result() for f in futs], 0.0, agent.max_tokens)
+    texts = [r.choices[0].message.content for r in replies]
+    assert texts == [r.choices[0].message.content for r in eager]
+    assert texts[0] == texts[2] and replies[0].usage["prompt_tokens"] == eager[0].usage["prompt_tokens"]
+    bad = ingest.submit(lambda: (_ for _ in ()).throw(OSError("no such file")))
+    mixed = agent.client.complete_many(agent.model_id, [futs[0], bad, futs[1]], 0.0, agent.max_tokens)
+    assert isinstance(mixed[1], OSError) and mixed[0].choices[0].message.content == texts[0]

@@ -412,3 +412,45 @@ def test_fp8_batched_decode(device):
     eng._decode_step_batched(2)
     d = (eng.logits_b[0].float() - l_single).abs()
     assert d.mean() < 0.06 and d.max() < 0.4, (float(d.mean()), float(d.max()))
+
+
+def test_lazy_requests_stream_into_the_batch_and_failures_stay_per_request(device):
+    """The batch seam hands generate_batch callables (each waits for its image's host decode): they are resolved in
+    order, a ViT group at a time; the tokens are those of the eager call, a callable that raises leaves its exception in
+    its place and takes no slot, and nothing is resolved before the request in front of it."""
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=8)
+    g = load_golden()
+    fa = [torch.from_numpy(g["frame_a"]).to(device)]
+    fb = [torch.from_numpy(g["frame_b1"]).to(device), torch.from_numpy(g["frame_b2"]).to(device)]
+    base = [(g["ids_a"].tolist(), fa), (g["ids_b"].tolist(), fb), ([256, 72, 105, 33], []), (g["ids_a"].tolist(), fa),
+            (g["ids_b"].tolist(), fb), (g["ids_a"].tolist(), fa)]
+    eager = eng.generate_batch(base, max_new_tokens=9, ignore_eos=True)
+    order = []
+
+    def lazy(i, fail=False):
+        def resolve():
+            order.append(i)
+            if fail:
+                raise ValueError(f"image {i} is corrupt")
+            return base[i]
+        return resolve
+
+    out = eng.generate_batch([lazy(i) for i in range(6)], max_new_tokens=9, ignore_eos=True)
+    assert out == eager and order == list(range(6))
+    order.clear()
+    out = eng.generate_batch([lazy(0), lazy(1, fail=True), lazy(2), lazy(3), lazy(4, fail=True), lazy(5)], max_new_tokens=9,
+                             ignore_eos=True)
+    assert isinstance(out[1], ValueError) and isinstance(out[4], ValueError) and "image 4" in str(out[4])
+    survivors = eng.generate_batch([base[0], base[2], base[3], base[5]], max_new_tokens=9, ignore_eos=True)
+    assert [out[0], out[2], out[3], out[5]] == survivors
+    # everything fails / a single survivor / a single lazy request
+    out = eng.generate_batch([lazy(0, fail=True), lazy(1, fail=True)], max_new_tokens=4, ignore_eos=True)
+    assert all(isinstance(o, ValueError) for o in out)
+    out = eng.generate_batch([lazy(0, fail=True), lazy(1)], max_new_tokens=6, ignore_eos=True)
+    assert isinstance(out[0], ValueError) and out[1][0] == eager[1][0] and len(out[1]) == 6
+    assert eng.generate_batch([lazy(3)], max_new_tokens=5, ignore_eos=True) == [eng.generate(*base[3], max_new_tokens=5, ignore_eos=True)]

@@ -15,6 +15,7 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--auditor", default="mllama", choices=["mllama", "mock"])
 ap.add_argument("--threads", default="1,16")
 ap.add_argument("--new-tokens", type=int, default=128)
+ap.add_argument("--profile", action="store_true", help="cProfile the measured call (main thread) and print the top entries")
 a = ap.parse_args()
 os.environ["VIS_IGNORE_EOS"] = "1"
 # random weights generate noise; a fixed parseable reply (substituted after the full generation) keeps the agents on their
@@ -44,9 +45,16 @@ with tempfile.TemporaryDirectory() as d:
     for n in [int(x) for x in a.threads.split(",")]:
         os.environ["VIS_INGEST_THREADS"] = str(n)
         ingest.shutdown()
+        if a.profile:
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            pr.enable()
         t0 = time.perf_counter()
         out = run_batch_inspection(paths, "medium", "general")
         t = time.perf_counter() - t0
+        if a.profile:
+            pr.disable()
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
         done = out["session_results"]["completed_images"]
         print(json.dumps({"workload": f"run_batch_inspection, {a.images} PNG files {a.size}x{a.size}, Inspector synthetic:7b"
                                       f" + Auditor {a.auditor}, {a.new_tokens} tokens per model, 1 rank",

@@ -245,13 +245,21 @@ class VLMAuditorAgent(_BaseAgent):
 
 def _many(agent, image_paths, contexts, prepared=None) -> list:
     """Shared body of analyze_many / verify_many: encode every image on the ingest pool (failures stay per image), one
-    ``complete_many`` call when the client offers it (one shared decode loop), per-reply interpretation."""
+    ``complete_many`` call when the client offers it (one shared decode loop), per-reply interpretation.
+    A client that sets ``accepts_futures`` (LocalVLMClient) is handed the encode futures themselves and starts its
+    first prompt pass while the later images are still being encoded; it returns the exception in the place of a
+    request whose encode or decode failed."""
     from . import ingest
     results = [None] * len(image_paths)
-    todo, msgs = [], []
     futs = prepared if prepared is not None else \
         [ingest.submit(agent._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
+    streaming = getattr(agent.client, "accepts_futures", False) and hasattr(agent.client, "complete_many")
+    todo, msgs = [], []
     for i, (path, fut) in enumerate(zip(image_paths, futs)):
+        if streaming:
+            msgs.append(fut)
+            todo.append(i)
+            continue
         ok, val = ingest.outcome(fut)
         if ok:
             msgs.append(val)
@@ -263,7 +271,7 @@ def _many(agent, image_paths, contexts, prepared=None) -> list:
         try:
             if hasattr(agent.client, "complete_many"):
                 replies = agent.client.complete_many(agent.model_id, msgs, agent.temperature, agent.max_tokens)
-                texts = [r.choices[0].message.content for r in replies]
+                texts = [r if isinstance(r, Exception) else r.choices[0].message.content for r in replies]
             else:
                 texts = [agent.client.chat.completions.create(model=agent.model_id, messages=m,
                                                               temperature=agent.temperature,
@@ -275,6 +283,10 @@ def _many(agent, image_paths, contexts, prepared=None) -> list:
                 results[i] = agent._failure(e)
             return results
         for i, text in zip(todo, texts):
+            if isinstance(text, Exception):
+                agent.logger.error(f"{agent.nickname}: request for {image_paths[i]} failed: {text}")
+                results[i] = agent._failure(text)
+                continue
             try:
                 results[i] = agent._interpret(text, contexts[i])
             except Exception as e:

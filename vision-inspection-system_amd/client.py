@@ -228,6 +228,8 @@ def local_model_type(path: str) -> str:
 class LocalVLMClient:
     """``InferenceClient``-shaped facade over the MI355X engine."""
 
+    accepts_futures = True      # complete_many takes Futures of messages (agents.prepare_many) and streams them in
+
     def __init__(self, api_key: Optional[str] = None, device: Optional[str] = None, default_model: Optional[str] = None,
                  seed: int = 0, **_ignored):
         self.device = device
@@ -280,22 +282,45 @@ class LocalVLMClient:
         out: List[ChatCompletion] = []
         if lm.family == "mllama":
             return self._complete_mllama_many(lm, batch_of_messages, temp, max_new)
-        # service-side decode (base64 + JPEG) of every request on the ingest pool: group i+1 decodes while group i is
-        # in its decode loop; a request that fails to decode fails the call like a malformed request to the service
-        from . import ingest
-        futs = [ingest.submit(self._prepare, lm, m) for m in batch_of_messages]
+        # Service-side decode (base64 + JPEG) of every request on the ingest pool.  A request may arrive as a Future of
+        # its messages (the agents' prepare_many: the request-side encode is still running on the same pool); the decode
+        # task then waits for it - the pool is FIFO, so what it waits for was queued before it.  The engine receives the
+        # requests as callables and resolves them in order, so its first prompt pass starts as soon as image 0 is
+        # decoded, and group i+1 decodes while group i is in its decode loop.
+        # Eager requests (plain message lists): a request that fails to decode fails the call, like a malformed request
+        # to the service.  Future requests: the failure (encode or decode) stays that request's own - its place in the
+        # returned list holds the exception.
+        from concurrent.futures import Future
+        from . import hip, ingest
+        lazy = any(isinstance(m, Future) for m in batch_of_messages)
+
+        def prep(m):
+            return self._prepare(lm, m.result() if isinstance(m, Future) else m)
+
+        futs = [ingest.submit(prep, m) for m in batch_of_messages]
+        n_ids = {}
+
+        def resolver(j):
+            def resolve():
+                ids, frames = futs[j].result()
+                n_ids[j] = len(ids)
+                return ids, [hip.resize_rgb(torch.from_numpy(f).to(eng.device), th, tw) for f, (th, tw) in frames]
+            return resolve
+
         with eng.lock:
             for i in range(0, len(futs), eng.max_batch):
-                chunk = [f.result() for f in futs[i:i + eng.max_batch]]
-                from . import hip
-                reqs = [(ids, [hip.resize_rgb(torch.from_numpy(f).to(eng.device), th, tw) for f, (th, tw) in frames])
-                        for ids, frames in chunk]
-                toks = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed,
+                idx = range(i, min(len(futs), i + eng.max_batch))
+                toks = eng.generate_batch([resolver(j) for j in idx], max_new_tokens=max_new, temperature=temp, seed=self.seed,
                                           ignore_eos=os.environ.get("VIS_IGNORE_EOS") == "1")
-                for (ids, _), t in zip(chunk, toks):
+                for j, t in zip(idx, toks):
+                    if isinstance(t, Exception):
+                        if not lazy:
+                            raise t
+                        out.append(t)
+                        continue
                     out.append(ChatCompletion([_Choice(_Message(_reply_text(model_id, tok.decode(t))))], model=model_id,
-                                              usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
-                                                     "total_tokens": len(ids) + len(t)}))
+                                              usage={"prompt_tokens": n_ids[j], "completion_tokens": len(t),
+                                                     "total_tokens": n_ids[j] + len(t)}))
         return out
 
 
@@ -322,11 +347,41 @@ class LocalVLMClient:
         per-request prompt pass, weights streamed once per generated token for the whole group); text-only requests
         (the agents' health check) take the single-sequence path."""
         import torch
+        from concurrent.futures import Future
         eng, tok = lm.engine, lm.tokenizer
         from . import ingest
-        prepared = [f.result() for f in [ingest.submit(self._prepare_mllama, lm, m) for m in batch_of_messages]]
-        toks_out: List[Optional[List[int]]] = [None] * len(prepared)
         ignore_eos = os.environ.get("VIS_IGNORE_EOS") == "1"
+
+        def prep(m):
+            return self._prepare_mllama(lm, m.result() if isinstance(m, Future) else m)
+
+        def completion(n_ids, t):
+            return ChatCompletion([_Choice(_Message(_reply_text(lm.model_id, tok.decode(t))))], model=lm.model_id,
+                                  usage={"prompt_tokens": n_ids, "completion_tokens": len(t), "total_tokens": n_ids + len(t)})
+
+        futs = [ingest.submit(prep, m) for m in batch_of_messages]
+        if any(isinstance(m, Future) for m in batch_of_messages):
+            # the batch seam (verify_many): every request carries an image; requests are resolved in order by the engine
+            # while it already runs the earlier prompt passes; a failed request keeps its exception as its result
+            out: list = []
+            n_ids = {}
+
+            def resolver(j):
+                def resolve():
+                    ids, f = futs[j].result()
+                    n_ids[j] = len(ids)
+                    return ids, (torch.from_numpy(f).to(eng.device) if f is not None else None)
+                return resolve
+
+            with eng.lock:
+                for g0 in range(0, len(futs), eng.max_batch):
+                    idx = range(g0, min(len(futs), g0 + eng.max_batch))
+                    outs = eng.generate_batch([resolver(j) for j in idx], max_new_tokens=max_new, temperature=temp,
+                                              seed=self.seed, stop_on_eos=not ignore_eos)
+                    out.extend(t if isinstance(t, Exception) else completion(n_ids[j], t) for j, t in zip(idx, outs))
+            return out
+        prepared = [f.result() for f in futs]
+        toks_out: List[Optional[List[int]]] = [None] * len(prepared)
         with eng.lock:
             with_img = [i for i, (_, f) in enumerate(prepared) if f is not None]
             for g0 in range(0, len(with_img), eng.max_batch):
@@ -340,10 +395,7 @@ class LocalVLMClient:
                 if f is None:
                     toks_out[i] = eng.generate(ids, None, max_new_tokens=max_new, temperature=temp, seed=self.seed,
                                                stop_on_eos=not ignore_eos)
-        return [ChatCompletion([_Choice(_Message(_reply_text(lm.model_id, tok.decode(t))))], model=lm.model_id,
-                               usage={"prompt_tokens": len(ids), "completion_tokens": len(t),
-                                      "total_tokens": len(ids) + len(t)})
-                for (ids, _), t in zip(prepared, toks_out)]
+        return [completion(len(ids), t) for (ids, _), t in zip(prepared, toks_out)]
 
 
 _MOCK_REPLY: List[Optional[Any]] = [None]

@@ -941,6 +941,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p
         if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
       }
     }
+    GP_STAMP(3);
+#ifdef GEMM_PROBE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GP_STAMP(4);
+#endif
     return;
   }
   if (p.wide) {

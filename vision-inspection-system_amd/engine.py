@@ -615,65 +615,106 @@ class Qwen2VLEngine:
             if taps is not None and li == 0:
                 taps["layer0"] = x.clone()
 
-    def prefill_many(self, requests: Sequence[Tuple[Sequence[int], Sequence[torch.Tensor]]], temperature: float = 0.0,
+    def prefill_many(self, requests: Sequence, temperature: float = 0.0,
                      seed: int = 0, max_new_tokens: Optional[int] = None,
-                     ids_dev: Optional[Sequence[torch.Tensor]] = None) -> None:
-        """Prefill request b into slot b.  The prefills are independent kernel chains: they are issued round-robin
+                     ids_dev: Optional[Sequence[torch.Tensor]] = None) -> Tuple[List[Optional[int]], List[Optional[Exception]]]:
+        """Prefill the requests into consecutive slots.  The prefills are independent kernel chains: they are issued round-robin
         on a few HIP streams (VIS_PREFILL_STREAMS, default 2: 418 -> 381 ms for 8 images) so that the ragged last round of one image's GEMM /
         attention grids is filled by another image's workgroups.  Returns with the current stream ordered after
-        all of them."""
+        all of them.
+
+        A request is ``(input_ids, frames)`` or a zero-argument callable returning that pair (LAZY form, used by the
+        batch seam: the callable waits for the image's host decode and uploads it, so the GPU starts on image 0 while
+        images 1.. are still being decoded).  Lazy requests are resolved in order, a ViT group at a time; one that
+        raises gets no slot and its exception is returned instead of failing the batch.
+        Returns (slot of request b or None, exception of request b or None)."""
         B = len(requests)
+        lazy = any(callable(r) for r in requests)
+        resolved: List[Optional[tuple]] = [None] * B
+        errors: List[Optional[Exception]] = [None] * B
+        slots: List[Optional[int]] = [None] * B
+
+        def get(b):
+            if resolved[b] is None and errors[b] is None:
+                r = requests[b]
+                if callable(r):
+                    try:
+                        r = r()
+                    except Exception as e:      # noqa: BLE001 - stays this request's own failure
+                        errors[b] = e
+                        return None
+                resolved[b] = r
+            return resolved[b]
+
         n_streams = max(1, min(B, int(os.environ.get("VIS_PREFILL_STREAMS", "2"))))
+        vb = max(1, int(os.environ.get("VIS_VIT_BATCH", "4"))) if n_streams > 1 else 1
         # The text in front of the first image is the same for every image of a batch inspection (the reference's
         # INSPECTOR_PROMPT, vlm_inspector.py:452-470): its K / V / V^T are computed once and copied into every slot.
+        # Eager requests: the prefix common to ALL prompts; lazy requests: the prefix common to the first group (the
+        # others are not known yet) - a later prompt that does not start with it is simply computed in full.
+        first = [r for r in (get(b) for b in range(B if not lazy else min(B, max(vb, 2)))) if r is not None]
         shared = None
-        P = self.shared_prefix_len([r[0] for r in requests])
+        P = self.shared_prefix_len([r[0] for r in first]) if (B > 1 and len(first) > 1) else 0
         if P:
-            shared = self.prefill(list(requests[0][0][:P]), (), temperature=temperature, seed=seed, max_new_tokens=0,
+            shared = self.prefill(list(first[0][0][:P]), (), temperature=temperature, seed=seed, max_new_tokens=0,
                                   slot=0, collect_prefix=True)
+
+        def prefix_for(ids):
+            if shared is None or len(ids) <= P:
+                return None
+            return shared if np.array_equal(np.asarray(list(ids[:P]), dtype=np.int64), shared["ids"]) else None
+
+        next_slot = 0
         if n_streams == 1:
-            for b, (ids, frames) in enumerate(requests):
-                self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
-                             max_new_tokens=max_new_tokens, slot=b, prefix=shared)
-            return
+            for b in range(B):
+                r = get(b)
+                if r is None:
+                    continue
+                self.prefill(r[0], r[1], ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
+                             max_new_tokens=max_new_tokens, slot=next_slot, prefix=prefix_for(r[0]))
+                slots[b] = next_slot
+                next_slot += 1
+            return slots, errors
         cur = torch.cuda.current_stream(self.device)
         if len(self._prefill_streams) < n_streams:
             self._prefill_streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
-        # One ViT pass over the images of up to VIS_VIT_BATCH requests (default 4): at M = 4 x 4900 rows the tower's
-        # GEMM grids become whole rounds of the chip (fc1 6.02, fc2 3.0, proj 3.0, qkv 9.02 rounds instead of
-        # 1.56 / 0.78 / 0.76 / 2.29) and the varlen attention kernel takes the images as segments of one launch.
-        vb = max(1, int(os.environ.get("VIS_VIT_BATCH", "4")))
+        streams = self._prefill_streams[:n_streams]
         cfg = self.cfg
-        embeds: List[Optional[torch.Tensor]] = [None] * B
-        if vb > 1:
-            for g0 in range(0, B, vb):
-                grp = [b for b in range(g0, min(B, g0 + vb)) if len(requests[b][1])]
-                if len(grp) < 2:
-                    continue
-                frames_all = [f for b in grp for f in requests[b][1]]
-                out = self.vision_forward(frames_all, split_rows=False)
+        for g0 in range(0, B, vb):
+            grp_all = [b for b in range(g0, min(B, g0 + vb)) if get(b) is not None]
+            # One ViT pass over the images of up to VIS_VIT_BATCH requests (default 4): at M = 4 x 4900 rows the tower's
+            # GEMM grids become whole rounds of the chip (fc1 6.02, fc2 3.0, proj 3.0, qkv 9.02 rounds instead of
+            # 1.56 / 0.78 / 0.76 / 2.29) and the varlen attention kernel takes the images as segments of one launch.
+            embeds = {}
+            grp = [b for b in grp_all if len(resolved[b][1])]
+            if vb > 1 and len(grp) >= 2:
+                out = self.vision_forward([f for b in grp for f in resolved[b][1]], split_rows=False)
                 r0 = 0
                 for b in grp:
-                    n = sum((f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2 for f in requests[b][1])
+                    n = sum((f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2 for f in resolved[b][1])
                     embeds[b] = out[r0:r0 + n]
                     r0 += n
-        for st in self._prefill_streams[:n_streams]:
-            st.wait_stream(cur)
-        for b, (ids, frames) in enumerate(requests):
-            st = self._prefill_streams[b % n_streams]
-            with torch.cuda.stream(st):
-                for f in frames:
-                    f.record_stream(st)
-                if embeds[b] is not None:
-                    embeds[b].record_stream(st)
-                self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
-                             max_new_tokens=max_new_tokens, slot=b, split_vit=False, image_embeds=embeds[b], prefix=shared)
-        for st in self._prefill_streams[:n_streams]:
+            for b in grp_all:
+                ids, frames = resolved[b]
+                st = streams[next_slot % n_streams]
+                st.wait_stream(cur)              # the frames' upload / resize and the group's ViT pass ran on `cur`
+                with torch.cuda.stream(st):
+                    for f in frames:
+                        f.record_stream(st)
+                    if b in embeds:
+                        embeds[b].record_stream(st)
+                    self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
+                                 max_new_tokens=max_new_tokens, slot=next_slot, split_vit=False, image_embeds=embeds.get(b),
+                                 prefix=prefix_for(ids))
+                slots[b] = next_slot
+                next_slot += 1
+        for st in streams:
             cur.wait_stream(st)
         if shared is not None:
             for t in (shared["k"], shared["v"], shared["vt"]):
-                for st in self._prefill_streams[:n_streams]:
+                for st in streams:
                     t.record_stream(st)
+        return slots, errors
 
     def shared_prefix_len(self, id_lists: Sequence[Sequence[int]]) -> int:
         """Length (a multiple of 64, 0 = do not share) of the text-only token prefix common to all prompts of a batch."""
@@ -860,22 +901,35 @@ class Qwen2VLEngine:
         return toks
 
     # ------------------------------------------------------------------ batched generation
-    def generate_batch(self, requests: Sequence[Tuple[Sequence[int], Sequence[torch.Tensor]]],
+    def generate_batch(self, requests: Sequence,
                        max_new_tokens: int = 128, ignore_eos: bool = False, use_graph: bool = True,
-                       check_every: int = 16, temperature: float = 0.0, seed: int = 0) -> List[List[int]]:
-        """requests: [(input_ids, frames)] for up to max_batch images.  Prefill runs per image (M = S rows is
-        already MFMA-efficient); the decode steps are shared: one weight pass per step for all sequences."""
-        B = len(requests)
-        if not 1 <= B <= self.max_batch:
-            raise ValueError(f"batch of {B} does not fit max_batch={self.max_batch}")
-        if B == 1:
-            ids, frames = requests[0]
-            return [self.generate(ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)]
-        longest = max(len(r[0]) for r in requests)
+                       check_every: int = 16, temperature: float = 0.0, seed: int = 0) -> list:
+        """requests: [(input_ids, frames)] for up to max_batch images - or zero-argument callables returning that pair
+        (see prefill_many: resolved in order while the GPU already works on the earlier ones).  Prefill runs per image
+        (M = S rows is already MFMA-efficient); the decode steps are shared: one weight pass per step for all sequences.
+        Returns one token list per request; for a lazy request whose callable raised, the exception object instead."""
+        n_req = len(requests)
+        if not 1 <= n_req <= self.max_batch:
+            raise ValueError(f"batch of {n_req} does not fit max_batch={self.max_batch}")
+        if n_req == 1:
+            r = requests[0]
+            if callable(r):
+                try:
+                    r = r()
+                except Exception as e:      # noqa: BLE001
+                    return [e]
+            return [self.generate(r[0], r[1], max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)]
+        # every prompt's own limit (prompt + new tokens <= context) is applied by its prefill; the shared loop below
+        # runs to the limit of the longest one
+        slots, errors = self.prefill_many(requests, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
+        live = [b for b in range(n_req) if slots[b] is not None]
+        B = len(live)
+        if B == 0:
+            return list(errors)
+        longest = max(self.slot_prompt_len[slots[b]] for b in live)
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - longest - 1))
-        self.prefill_many(requests, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
         eos = set(self.cfg.eos_ids)
-        starts = [self.slot_prompt_len[b] - 1 for b in range(B)]
+        starts = [self.slot_prompt_len[s] - 1 for s in range(B)]
 
         def collect(n):
             t = self.tokens_b[:B].cpu()
@@ -896,4 +950,4 @@ class Qwen2VLEngine:
         outs = collect(done)
         if not ignore_eos:
             outs = [seq[:next((i for i, t in enumerate(seq) if t in eos), len(seq))] for seq in outs]
-        return outs
+        return [outs[slots[b]] if slots[b] is not None else errors[b] for b in range(n_req)]

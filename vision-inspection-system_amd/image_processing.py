@@ -11,8 +11,12 @@
 from __future__ import annotations
 
 import base64
+import collections
 import io
 import math
+import os
+import threading
+from concurrent.futures import Future
 from pathlib import Path
 from typing import Optional, Tuple, Union
 
@@ -42,17 +46,84 @@ def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56
     return h_bar, w_bar
 
 
+# Both agents encode the same file (Inspector, then Auditor: nodes.py:128,:230 of the reference), and for every image
+# that is no larger than the Auditor's 1024 px limit and is not in mode LA their bytes are identical (same thumbnail
+# decision, same conversion, same JPEG settings).  The second encode is the larger part of the host work per image at
+# batch rates (PNG inflate + JPEG q85 with optimize=True: ~0.15 s of one core for a 1024 x 1024 frame), so results are
+# shared: key = file identity + every input of the pipeline below; a concurrent second request waits for the first.
+_ENC_LOCK = threading.Lock()
+_ENC_CACHE: "collections.OrderedDict[tuple, Future]" = collections.OrderedDict()
+_ENC_BYTES = [0]
+
+
+def _encode_cache_limit() -> int:
+    return int(float(os.environ.get("VIS_ENCODE_CACHE_MB", "128")) * (1 << 20))
+
+
+def clear_encode_cache() -> None:
+    with _ENC_LOCK:
+        _ENC_CACHE.clear()
+        _ENC_BYTES[0] = 0
+
+
 def encode_image_optimized(image_path: Union[str, Path], max_size: int = 2048, convert_la: bool = True,
                            enforce_limit: bool = True, logger=None) -> str:
     """Request-side encode, byte-compatible with the reference's Inspector (``convert_la=True,
     enforce_limit=True``) and Auditor (``max_size=1024, convert_la=False, enforce_limit=False``)."""
     img = Image.open(image_path)
+    shrink = max(img.size) > max_size
+    modes = ("RGBA", "P", "LA") if convert_la else ("RGBA", "P")
+    key = fut = None
+    limit = _encode_cache_limit()
+    if limit > 0:
+        try:
+            st = os.stat(image_path)
+            key = (os.path.abspath(str(image_path)), st.st_mtime_ns, st.st_size, max_size if shrink else 0, img.mode in modes)
+        except OSError:
+            key = None
+    if key is not None:
+        with _ENC_LOCK:
+            fut = _ENC_CACHE.get(key)
+            owner = fut is None
+            if owner:
+                fut = _ENC_CACHE[key] = Future()
+            else:
+                _ENC_CACHE.move_to_end(key)
+        if not owner:
+            uri, payload_size = fut.result()          # raises what the first encode raised
+            if enforce_limit and payload_size > 10_000_000:
+                raise ValueError(f"Image too large even after optimization: {payload_size} bytes")
+            return uri
+    try:
+        uri, payload_size = _encode(img, max_size, shrink, modes, logger)
+    except BaseException as e:
+        if fut is not None:
+            with _ENC_LOCK:
+                _ENC_CACHE.pop(key, None)
+            fut.set_exception(e)
+        raise
+    if fut is not None:
+        fut.set_result((uri, payload_size))
+        with _ENC_LOCK:
+            _ENC_BYTES[0] += len(uri)
+            while _ENC_BYTES[0] > limit and _ENC_CACHE:
+                k, f = next(iter(_ENC_CACHE.items()))
+                if not f.done():
+                    break
+                _ENC_CACHE.pop(k)
+                if f.exception() is None:
+                    _ENC_BYTES[0] -= len(f.result()[0])
+    if enforce_limit and payload_size > 10_000_000:
+        raise ValueError(f"Image too large even after optimization: {payload_size} bytes")
+    return uri
+
+
+def _encode(img: Image.Image, max_size: int, shrink: bool, modes: tuple, logger) -> Tuple[str, int]:
     original_size = img.size
-    if max(img.size) > max_size:
+    if shrink:
         img.thumbnail((max_size, max_size), Image.Resampling.LANCZOS)
         if logger:
             logger.debug(f"Resized image from {original_size} to {img.size}")
-    modes = ("RGBA", "P", "LA") if convert_la else ("RGBA", "P")
     if img.mode in modes:
         img = img.convert("RGB")
     buffer = io.BytesIO()
@@ -61,9 +132,7 @@ def encode_image_optimized(image_path: Union[str, Path], max_size: int = 2048, c
         buffer = io.BytesIO()
         img.save(buffer, format="JPEG", quality=60, optimize=True)
     payload_size = buffer.tell()
-    if enforce_limit and payload_size > 10_000_000:
-        raise ValueError(f"Image too large even after optimization: {payload_size} bytes")
-    return "data:image/jpeg;base64," + base64.b64encode(buffer.getvalue()).decode()
+    return "data:image/jpeg;base64," + base64.b64encode(buffer.getvalue()).decode(), payload_size
 
 
 def decode_data_uri(url: str) -> Image.Image:

@@ -453,23 +453,43 @@ class MllamaEngine:
         self._graphs_b[key] = g
         return g
 
-    def generate_batch(self, requests: Sequence[Tuple[Sequence[int], torch.Tensor]], max_new_tokens: int = 128,
+    def generate_batch(self, requests: Sequence, max_new_tokens: int = 128,
                        temperature: float = 0.0, seed: int = 0, stop_on_eos: bool = True, use_graph: bool = True,
-                       chunk: int = 16) -> List[List[int]]:
+                       chunk: int = 16) -> list:
         """requests: [(input_ids, frame)] for up to max_batch images (every request carries an image: the batched step
-        always runs the cross-attention layers).  Prompt passes run per request; the decode steps are shared."""
-        B = len(requests)
-        if not 1 <= B <= self.max_batch:
-            raise ValueError(f"batch of {B} does not fit max_batch={self.max_batch}")
-        if B == 1 or any(fr is None for _, fr in requests):
-            if B > 1:
+        always runs the cross-attention layers).  Prompt passes run per request; the decode steps are shared.
+        A request may be a zero-argument callable returning the pair (the batch seam: it waits for the image's host
+        decode, so the prompt pass of image 0 runs while images 1.. are still being decoded); one that raises gets no
+        slot and its exception takes its place in the returned list."""
+        n_req = len(requests)
+        if not 1 <= n_req <= self.max_batch:
+            raise ValueError(f"batch of {n_req} does not fit max_batch={self.max_batch}")
+        lazy = any(callable(r) for r in requests)
+        if not lazy and (n_req == 1 or any(fr is None for _, fr in requests)):
+            if n_req > 1:
                 raise ValueError("generate_batch needs an image in every request (text-only prompts go through generate)")
             ids, fr = requests[0]
             return [self.generate(ids, fr, max_new_tokens, temperature, seed, stop_on_eos, use_graph)]
-        longest = max(len(r[0]) for r in requests)
+        slots: List[Optional[int]] = [None] * n_req
+        errors: List[Optional[Exception]] = [None] * n_req
+        B = 0
+        for b, r in enumerate(requests):
+            try:
+                ids, fr = r() if callable(r) else r
+                if fr is None:
+                    raise ValueError("generate_batch needs an image in every request")
+                self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B)
+            except Exception as e:      # noqa: BLE001 - a lazy request's failure stays its own
+                if not lazy:
+                    raise
+                errors[b] = e
+                continue
+            slots[b] = B
+            B += 1
+        if B == 0:
+            return list(errors)
+        longest = max(self.slot_prompt_len[s] for s in range(B))
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - longest - 1))
-        for b, (ids, fr) in enumerate(requests):
-            self.prefill(ids, fr, temperature=temperature, seed=seed, slot=b)
         eos = set(self.cfg.eos_ids)
         starts = [self.slot_prompt_len[b] - 1 for b in range(B)]
 
@@ -492,7 +512,7 @@ class MllamaEngine:
         outs = collect(done)
         if stop_on_eos:
             outs = [seq[:next((i + 1 for i, t in enumerate(seq) if t in eos), len(seq))] for seq in outs]
-        return outs
+        return [outs[slots[b]] if slots[b] is not None else errors[b] for b in range(n_req)]
 
     def generated(self, n: int) -> List[int]:
         s = self.prompt_len - 1          # the token generated at step i is stored at index (its position - 1)
