@@ -367,3 +367,82 @@ def test_streaming_client_gets_the_encode_futures_and_failures_stay_per_image(mo
     assert seen["futures"] is True
     assert [r.analysis_failed for r in res] == [False, True, False, True]
     assert "decode failed" in res[3].failure_reason
+
+
+def test_direct_frames_skip_the_jpeg_round_trip_only_on_request(tmp_path, monkeypatch):
+    """VIS_DIRECT_FRAMES=1 (off by default: the reference always sends JPEG q85): the local agents hand the a3-prepared
+    RGB pixels over under a process-local vis-frame: URL; the service side resolves it to exactly those pixels."""
+    from vision_inspection_system_amd import config as C, image_processing as IP
+    from vision_inspection_system_amd.agents import VLMAuditorAgent, VLMInspectorAgent
+    rng = np.random.default_rng(9)
+    p = tmp_path / "big.png"
+    Image.fromarray(rng.integers(0, 256, (1500, 700, 4), dtype=np.uint8), mode="RGBA").save(p)
+    C.set_config(C.Config(vlm_inspector_provider="mi355x", vlm_auditor_provider="mi355x", vlm_inspector_model="synthetic:tiny",
+                          vlm_auditor_model="synthetic:tiny:1"))
+    try:
+        insp, aud = VLMInspectorAgent(), VLMAuditorAgent()
+        assert insp._encode_image_optimized(p).startswith("data:image/jpeg;base64,")          # default: the reference's bytes
+        monkeypatch.setenv("VIS_DIRECT_FRAMES", "1")
+        for agent, max_size in ((insp, 2048), (aud, 1024)):
+            url = agent._encode_image_optimized(p)
+            assert url.startswith("vis-frame:")
+            ref = Image.open(p)
+            if max(ref.size) > max_size:
+                ref.thumbnail((max_size, max_size), Image.Resampling.LANCZOS)
+            assert np.array_equal(np.array(IP.decode_data_uri(url)), np.array(ref.convert("RGB")))
+        with pytest.raises(ValueError, match="unknown or expired"):
+            IP.decode_data_uri("vis-frame:999999999")
+        # a remote provider never gets a process-local handle
+        C.set_config(C.Config(vlm_inspector_provider="mock", vlm_auditor_provider="mock"))
+        assert VLMAuditorAgent()._encode_image_optimized(p).startswith("data:image/jpeg")
+    finally:
+        C.set_config(None)
+
+
+def test_ingest_pool_priorities_and_chaining(monkeypatch):
+    """ingest.then queues the dependent (decode) task only when its input is ready and ahead of the (encode) tasks still
+    waiting - no worker ever blocks on another task; failures and a shutdown travel through the chained future."""
+    import threading, time
+    from vision_inspection_system_amd import ingest
+    monkeypatch.setenv("VIS_INGEST_THREADS", "2")
+    ingest.shutdown()
+    try:
+        order, gate = [], threading.Event()
+
+        def enc(i):
+            gate.wait(5)
+            order.append(("enc", i))
+            return i
+
+        def dec(i):
+            order.append(("dec", i))
+            return i * 10
+
+        encs = [ingest.submit(enc, i) for i in range(6)]
+        decs = [ingest.then(f, dec) for f in encs]
+        gate.set()
+        assert [d.result(10) for d in decs] == [0, 10, 20, 30, 40, 50]
+        # a decode never waits behind all encodes: dec 0 runs before the last encode
+        assert order.index(("dec", 0)) < order.index(("enc", 5))
+        assert ingest.then(7, dec).result(10) == 70                       # plain value: just a task
+        bad = ingest.submit(lambda: 1 / 0)
+        ran = []
+        chained = ingest.then(bad, lambda v: ran.append(v))
+        with pytest.raises(ZeroDivisionError):
+            chained.result(10)
+        assert ran == []
+        with pytest.raises(KeyError):
+            ingest.then(ingest.submit(lambda: 3), lambda v: {}[v]).result(10)
+        # shutdown: queued work is cancelled, its dependants fail instead of hanging
+        hold = threading.Event()
+        blockers = [ingest.submit(hold.wait, 5) for _ in range(2)]
+        time.sleep(0.05)
+        queued = ingest.submit(lambda: 1)
+        dep = ingest.then(queued, lambda v: v)
+        ingest.shutdown()
+        hold.set()
+        with pytest.raises(BaseException):
+            dep.result(10)
+        assert ingest.submit(lambda: 5).result(10) == 5                   # a fresh pool is created on demand
+    finally:
+        ingest.shutdown()

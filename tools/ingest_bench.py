@@ -15,9 +15,12 @@ ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--auditor", default="mllama", choices=["mllama", "mock"])
 ap.add_argument("--threads", default="1,16")
 ap.add_argument("--new-tokens", type=int, default=128)
+ap.add_argument("--direct", action="store_true", help="VIS_DIRECT_FRAMES=1: no JPEG round trip between agent and engine")
 ap.add_argument("--profile", action="store_true", help="cProfile the measured call (main thread) and print the top entries")
 a = ap.parse_args()
 os.environ["VIS_IGNORE_EOS"] = "1"
+if a.direct:
+    os.environ["VIS_DIRECT_FRAMES"] = "1"
 # random weights generate noise; a fixed parseable reply (substituted after the full generation) keeps the agents on their
 # success path instead of the failure + retry-with-back-off path
 os.environ["VIS_SYNTHETIC_REPLY"] = ('{"object_identified": "part", "overall_condition": "good", "defects": [], '
@@ -58,4 +61,4 @@ with tempfile.TemporaryDirectory() as d:
         done = out["session_results"]["completed_images"]
         print(json.dumps({"workload": f"run_batch_inspection, {a.images} PNG files {a.size}x{a.size}, Inspector synthetic:7b"
                                       f" + Auditor {a.auditor}, {a.new_tokens} tokens per model, 1 rank",
-                          "ingest_threads": n, "images_per_s": a.images / t, "seconds": t, "completed": done}), flush=True)
+                          "ingest_threads": n, "direct_frames": bool(a.direct), "images_per_s": a.images / t, "seconds": t, "completed": done}), flush=True)

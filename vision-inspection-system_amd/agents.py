@@ -17,7 +17,7 @@ from typing import Any, Dict, Optional
 
 from .client import make_client
 from .config import LOCAL_PROVIDER, get_config
-from .image_processing import encode_image_optimized
+from .image_processing import direct_frames_enabled, encode_image_optimized, frame_url_for
 from .prompts import AUDITOR_PROMPT, INSPECTOR_PROMPT
 from .response_parsing import parse_json_robust, validate_and_fix_result
 from .schemas import InspectionContext, VLMAnalysisResult
@@ -97,6 +97,8 @@ class VLMInspectorAgent(_BaseAgent):
         self.logger.info(f"Initialized Inspector with {self.provider} model: {self.model_id}")
 
     def _encode_image_optimized(self, image_path: Path, max_size: Optional[int] = None) -> str:
+        if self.provider == LOCAL_PROVIDER and direct_frames_enabled():      # opt-in: pixels handed over in-process
+            return frame_url_for(image_path, max_size or self.max_image_size, convert_la=True, logger=self.logger)
         return encode_image_optimized(image_path, max_size or self.max_image_size, convert_la=True,
                                       enforce_limit=True, logger=self.logger)
 
@@ -192,6 +194,8 @@ class VLMAuditorAgent(_BaseAgent):
             self.model_id = "meta-llama/Llama-3.2-11B-Vision-Instruct"
 
     def _encode_image_optimized(self, image_path: Path, max_size: int = 1024) -> str:
+        if self.provider == LOCAL_PROVIDER and direct_frames_enabled():
+            return frame_url_for(image_path, max_size, convert_la=False, logger=self.logger)
         return encode_image_optimized(image_path, max_size, convert_la=False, enforce_limit=False, logger=self.logger)
 
     def _parse_json_robust(self, text: str) -> Dict[str, Any]:

@@ -283,8 +283,8 @@ class LocalVLMClient:
         if lm.family == "mllama":
             return self._complete_mllama_many(lm, batch_of_messages, temp, max_new)
         # Service-side decode (base64 + JPEG) of every request on the ingest pool.  A request may arrive as a Future of
-        # its messages (the agents' prepare_many: the request-side encode is still running on the same pool); the decode
-        # task then waits for it - the pool is FIFO, so what it waits for was queued before it.  The engine receives the
+        # its messages (the agents' prepare_many: the request-side encode is still running on the same pool); its decode
+        # is queued the moment that encode finishes, ahead of the encodes still waiting (ingest.then).  The engine receives the
         # requests as callables and resolves them in order, so its first prompt pass starts as soon as image 0 is
         # decoded, and group i+1 decodes while group i is in its decode loop.
         # Eager requests (plain message lists): a request that fails to decode fails the call, like a malformed request
@@ -294,10 +294,7 @@ class LocalVLMClient:
         from . import hip, ingest
         lazy = any(isinstance(m, Future) for m in batch_of_messages)
 
-        def prep(m):
-            return self._prepare(lm, m.result() if isinstance(m, Future) else m)
-
-        futs = [ingest.submit(prep, m) for m in batch_of_messages]
+        futs = [ingest.then(m, lambda msgs: self._prepare(lm, msgs)) for m in batch_of_messages]
         n_ids = {}
 
         def resolver(j):
@@ -352,14 +349,11 @@ class LocalVLMClient:
         from . import ingest
         ignore_eos = os.environ.get("VIS_IGNORE_EOS") == "1"
 
-        def prep(m):
-            return self._prepare_mllama(lm, m.result() if isinstance(m, Future) else m)
-
         def completion(n_ids, t):
             return ChatCompletion([_Choice(_Message(_reply_text(lm.model_id, tok.decode(t))))], model=lm.model_id,
                                   usage={"prompt_tokens": n_ids, "completion_tokens": len(t), "total_tokens": n_ids + len(t)})
 
-        futs = [ingest.submit(prep, m) for m in batch_of_messages]
+        futs = [ingest.then(m, lambda msgs: self._prepare_mllama(lm, msgs)) for m in batch_of_messages]
         if any(isinstance(m, Future) for m in batch_of_messages):
             # the batch seam (verify_many): every request carries an image; requests are resolved in order by the engine
             # while it already runs the earlier prompt passes; a failed request keeps its exception as its result

@@ -135,8 +135,44 @@ def _encode(img: Image.Image, max_size: int, shrink: bool, modes: tuple, logger)
     return "data:image/jpeg;base64," + base64.b64encode(buffer.getvalue()).decode(), payload_size
 
 
+# ---- optional: no JPEG round trip.  The reference always ships the image to the service as a JPEG-q85
+# data URI; when the "service" is the engine in this process, encode + base64 + decode (~0.2 s of one core per
+# 1024 x 1024 frame and agent) buy nothing.  With VIS_DIRECT_FRAMES=1 the agents apply the same open / thumbnail / mode
+# conversion as a3 and hand the RGB pixels over under a process-local ``vis-frame:<id>`` URL.  OFF by default: the model then
+# sees the un-quantised pixels, not the JPEG-decoded ones the reference's service sees.
+_FRAMES: "collections.OrderedDict[str, np.ndarray]" = collections.OrderedDict()
+_FRAMES_LOCK = threading.Lock()
+_FRAME_SEQ = [0]
+
+
+def direct_frames_enabled() -> bool:
+    return os.environ.get("VIS_DIRECT_FRAMES", "0") == "1"
+
+
+def frame_url_for(image_path: Union[str, Path], max_size: int = 2048, convert_la: bool = True, logger=None) -> str:
+    """a3 without the JPEG: open, thumbnail (LANCZOS) above ``max_size``, RGB; returns a ``vis-frame:`` URL that
+    ``decode_data_uri`` resolves inside this process (the newest 256 frames are kept)."""
+    img = Image.open(image_path)
+    if max(img.size) > max_size:
+        img.thumbnail((max_size, max_size), Image.Resampling.LANCZOS)
+    arr = np.array(img.convert("RGB"), dtype=np.uint8)
+    with _FRAMES_LOCK:
+        _FRAME_SEQ[0] += 1
+        url = f"vis-frame:{_FRAME_SEQ[0]}"
+        _FRAMES[url] = arr
+        while len(_FRAMES) > 256:
+            _FRAMES.popitem(last=False)
+    return url
+
+
 def decode_data_uri(url: str) -> Image.Image:
     """``data:image/...;base64,XXXX`` -> PIL RGB image.  Remote URLs are refused (no network)."""
+    if url.startswith("vis-frame:"):
+        with _FRAMES_LOCK:
+            arr = _FRAMES.get(url)
+        if arr is None:
+            raise ValueError(f"unknown or expired frame handle {url}")
+        return Image.fromarray(arr)
     if not url.startswith("data:"):
         raise ValueError("local backend accepts only data: URIs for images (no remote fetch)")
     try:

@@ -11,12 +11,66 @@ share (VIS_INGEST_THREADS, default min(16, cpu count)).
 """
 from __future__ import annotations
 
+import itertools
 import os
+import queue
 import threading
-from concurrent.futures import Future, ThreadPoolExecutor
+from concurrent.futures import Future
 from typing import Any, Callable, Iterable, List, Optional, Tuple
 
-_POOL: Optional[ThreadPoolExecutor] = None
+# Priorities (smaller runs first).  The request-side encodes of a whole batch are queued up front; the service-side decode
+# of image i must not wait behind the encodes of images i+1.. (the GPU is waiting for it), so it is queued - by `then`,
+# only once its encode has finished, never as a task that blocks a thread - with a higher priority.
+DECODE, ENCODE = 0, 1
+
+
+class _Pool:
+    """Fixed set of daemon worker threads over a priority queue (ThreadPoolExecutor is FIFO only)."""
+
+    def __init__(self, n: int):
+        self.n = n
+        self._q: "queue.PriorityQueue" = queue.PriorityQueue()
+        self._seq = itertools.count()
+        self._stop = False
+        self._threads = [threading.Thread(target=self._run, name=f"vis-ingest-{i}", daemon=True) for i in range(n)]
+        for t in self._threads:
+            t.start()
+
+    def _run(self) -> None:
+        while True:
+            _, _, item = self._q.get()
+            if item is None:
+                return
+            fut, fn, args, kwargs = item
+            if not fut.set_running_or_notify_cancel():
+                continue
+            try:
+                fut.set_result(fn(*args, **kwargs))
+            except BaseException as e:      # noqa: BLE001 - delivered through the future
+                fut.set_exception(e)
+
+    def submit(self, fn: Callable, *args, priority: int = ENCODE, **kwargs) -> Future:
+        fut: Future = Future()
+        if self._stop:
+            fut.set_exception(RuntimeError("ingest pool was shut down"))
+            return fut
+        self._q.put((priority, next(self._seq), (fut, fn, args, kwargs)))
+        return fut
+
+    def shutdown(self) -> None:
+        self._stop = True
+        while True:     # pending work is cancelled, running work finishes on its own
+            try:
+                _, _, item = self._q.get_nowait()
+            except queue.Empty:
+                break
+            if item is not None:
+                item[0].cancel()
+        for _ in self._threads:
+            self._q.put((-1, next(self._seq), None))
+
+
+_POOL: Optional[_Pool] = None
 _LOCK = threading.Lock()
 
 
@@ -25,21 +79,45 @@ def threads() -> int:
     return n if n > 0 else max(1, min(16, os.cpu_count() or 1))
 
 
-def pool() -> ThreadPoolExecutor:
+def pool() -> _Pool:
     global _POOL
     with _LOCK:
         if _POOL is None:
-            _POOL = ThreadPoolExecutor(max_workers=threads(), thread_name_prefix="vis-ingest")
+            _POOL = _Pool(threads())
         return _POOL
 
 
-def submit(fn: Callable, *args, **kwargs) -> Future:
-    return pool().submit(fn, *args, **kwargs)
+def submit(fn: Callable, *args, priority: int = ENCODE, **kwargs) -> Future:
+    return pool().submit(fn, *args, priority=priority, **kwargs)
 
 
 def submit_all(fn: Callable, items: Iterable) -> List[Future]:
-    p = pool()
-    return [p.submit(fn, *it) if isinstance(it, tuple) else p.submit(fn, it) for it in items]
+    return [submit(fn, *it) if isinstance(it, tuple) else submit(fn, it) for it in items]
+
+
+def then(first, fn: Callable, priority: int = DECODE) -> Future:
+    """Future of ``fn(value)``: queued (with ``priority``) when ``first`` - a Future, or a plain value - is available;
+    a failure of ``first`` becomes the failure of the result without ``fn`` running."""
+    if not isinstance(first, Future):
+        return submit(fn, first, priority=priority)
+    out: Future = Future()
+
+    def chain(done: Future) -> None:
+        try:
+            value = done.result()
+        except BaseException as e:      # noqa: BLE001 - also a cancelled encode
+            out.set_exception(e)
+            return
+        def deliver(f: Future) -> None:
+            try:
+                out.set_result(f.result())
+            except BaseException as e:      # noqa: BLE001 - incl. CancelledError after a shutdown
+                out.set_exception(e)
+
+        submit(fn, value, priority=priority).add_done_callback(deliver)
+
+    first.add_done_callback(chain)
+    return out
 
 
 def outcome(fut: Future) -> Tuple[bool, Any]:
@@ -54,5 +132,5 @@ def shutdown() -> None:
     global _POOL
     with _LOCK:
         if _POOL is not None:
-            _POOL.shutdown(wait=False, cancel_futures=True)
+            _POOL.shutdown()
             _POOL = None
