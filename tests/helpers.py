@@ -102,3 +102,33 @@ def teacher_forced_parity(eng, first_logits, ref_toks, ref_logits, tol, use_grap
             eng.decode(1, use_graph=use_graph)
             logits = eng.logits.float().cpu()
     return ties
+
+
+def dequantised_sd(cfg, sd):
+    """State dict whose LLM projections / lm_head are the engine's e4m3 weights, de-quantised (CPU, same quantiser)."""
+    from vision_inspection_system_amd import hip
+    from vision_inspection_system_amd.weights import interleave_gate_up
+
+    def dq(w):
+        q, s = hip.quantize_fp8_rows(w.to(torch.bfloat16))
+        return q.view(torch.float8_e4m3fn).float() * s[:, None]
+
+    dsd = dict(sd)
+    for i in range(cfg.layers):
+        p = f"model.layers.{i}."
+        qkv = dq(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0))
+        nq, nk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
+        dsd[p + "self_attn.q_proj.weight"], dsd[p + "self_attn.k_proj.weight"], dsd[p + "self_attn.v_proj.weight"] = \
+            qkv[:nq], qkv[nq:nq + nk], qkv[nq + nk:]
+        dsd[p + "self_attn.o_proj.weight"] = dq(sd[p + "self_attn.o_proj.weight"])
+        gu = dq(interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]))
+        gu = gu.view(cfg.intermediate // 16, 2, 16, cfg.hidden)
+        dsd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(cfg.intermediate, cfg.hidden)
+        dsd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(cfg.intermediate, cfg.hidden)
+        dsd[p + "mlp.down_proj.weight"] = dq(sd[p + "mlp.down_proj.weight"])
+    dsd["lm_head.weight"] = dq(sd["lm_head.weight"])
+    for i in range(cfg.v_depth):
+        p = f"visual.blocks.{i}."
+        for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+            dsd[p + n] = dq(sd[p + n])
+    return dsd

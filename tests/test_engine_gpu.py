@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, oracle_inputs, ref_config, teacher_forced_parity
+from helpers import load_golden, oracle_inputs, ref_config, teacher_forced_parity, dequantised_sd as _dequantised_sd
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 6e-2
@@ -265,36 +265,6 @@ def test_shared_text_prefix_is_bit_identical(device, monkeypatch, dtype):
     # prompts without a common text prefix, or with the image first, fall back to the plain pass
     assert eng.shared_prefix_len([[1, 2, 3] * 100, [4, 5, 6] * 100]) == 0
     assert eng.shared_prefix_len([[cfg.vision_start_id] + text, [cfg.vision_start_id] + text]) == 0
-
-
-def _dequantised_sd(cfg, sd):
-    """State dict whose LLM projections / lm_head are the engine's e4m3 weights, de-quantised (CPU, same quantiser)."""
-    from vision_inspection_system_amd import hip
-    from vision_inspection_system_amd.weights import interleave_gate_up
-
-    def dq(w):
-        q, s = hip.quantize_fp8_rows(w.to(torch.bfloat16))
-        return q.view(torch.float8_e4m3fn).float() * s[:, None]
-
-    dsd = dict(sd)
-    for i in range(cfg.layers):
-        p = f"model.layers.{i}."
-        qkv = dq(torch.cat([sd[p + f"self_attn.{n}_proj.weight"] for n in ("q", "k", "v")], dim=0))
-        nq, nk = cfg.heads * cfg.head_dim, cfg.kv_heads * cfg.head_dim
-        dsd[p + "self_attn.q_proj.weight"], dsd[p + "self_attn.k_proj.weight"], dsd[p + "self_attn.v_proj.weight"] = \
-            qkv[:nq], qkv[nq:nq + nk], qkv[nq + nk:]
-        dsd[p + "self_attn.o_proj.weight"] = dq(sd[p + "self_attn.o_proj.weight"])
-        gu = dq(interleave_gate_up(sd[p + "mlp.gate_proj.weight"], sd[p + "mlp.up_proj.weight"]))
-        gu = gu.view(cfg.intermediate // 16, 2, 16, cfg.hidden)
-        dsd[p + "mlp.gate_proj.weight"] = gu[:, 0].reshape(cfg.intermediate, cfg.hidden)
-        dsd[p + "mlp.up_proj.weight"] = gu[:, 1].reshape(cfg.intermediate, cfg.hidden)
-        dsd[p + "mlp.down_proj.weight"] = dq(sd[p + "mlp.down_proj.weight"])
-    dsd["lm_head.weight"] = dq(sd["lm_head.weight"])
-    for i in range(cfg.v_depth):
-        p = f"visual.blocks.{i}."
-        for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
-            dsd[p + n] = dq(sd[p + n])
-    return dsd
 
 
 def test_fp8_decode_weights_match_oracle_with_dequantised_weights(setup, device):

@@ -126,3 +126,55 @@ def test_mllama_11b_shapes_one_self_one_cross_layer_vs_oracle(device):
         _pick_ok(f"decode step {t + 1}", eng.logits, ref_logits[t + 1], err)
     del eng
     torch.cuda.empty_cache()
+
+
+def test_qwen2vl_7b_shapes_one_layer_fp8_vs_fake_quant_oracle(device):
+    """BASELINE configs[4] at the exact 7B layer shapes (the fp8 path only ran end to end at the tiny size): LLM
+    projections of the prompt pass on the fp8 MFMA (e4m3 weights with per-row scales, per-token e4m3 activations, K = 3584
+    and 18944) and e4m3 decode weights (W8A16 GEMVs incl. the 152064-row lm_head), one layer deep, against the oracle
+    that fake-quantises the same tensors.  A quantiser is discontinuous (one e4m3 step = 6 %): bf16-level differences
+    between the two pipelines move some activations across rounding boundaries, so the stated tolerance is statistical and
+    relative to the tensor's range R: mean <= 1 % of R, max <= 8 % of R - and the fp8 engine must be closer to the fp8
+    oracle than to the bf16 oracle (it really computes the quantised function)."""
+    from helpers import dequantised_sd
+    from oracle import qwen2vl_ref as R
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = dataclasses.replace(Qwen2VLConfig.qwen2_vl_7b(), layers=1, v_depth=1)
+    sd = synth_state_dict(cfg, seed=5, rng="torch", device=device)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=2560, prefill_dtype="fp8",
+                        decode_weights="fp8")
+    frame = np.random.default_rng(21).integers(0, 256, (980, 980, 3), dtype=np.uint8)
+    ids = _bench_prompt(cfg, (980 // 14) ** 2 // 4)
+    dsd = {k: v.cpu() for k, v in dequantised_sd(cfg, sd).items()}
+    psd = dict(dsd)
+    psd["lm_head.weight"] = sd["lm_head.weight"].cpu()          # the first token's lm_head runs in bf16
+    for i in range(cfg.v_depth):                                # the ViT stays bf16 unless VIS_VIT_FP8 asks otherwise
+        for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
+            psd[f"visual.blocks.{i}.{n}"] = dsd[f"visual.blocks.{i}.{n}"] = sd[f"visual.blocks.{i}.{n}"].cpu()
+    taps, r8, r16 = {}, {}, {}
+    eng.prefill(ids, [torch.from_numpy(frame).to(device)], taps=taps, max_new_tokens=8)
+    pv, grids = oracle_inputs([frame])
+    with torch.no_grad():
+        toks8, logits8 = R.generate(ref_config(cfg), sd, ids, pv, grids, 3, taps=r8, prefill_fp8_sd=psd, decode_sd=dsd)
+        _, logits16 = R.generate(ref_config(cfg), sd, ids, pv, grids, 1, taps=r16)
+
+    def stat(name, got, ref8, ref16=None):
+        got, ref8 = got.float().cpu(), ref8.float()
+        R_ = float(ref8.abs().max())
+        d = (got - ref8).abs()
+        print(f"[fp8 parity] {name}: range {R_:.3f}  max {float(d.max()) / R_ * 100:.2f} %  mean {float(d.mean()) / R_ * 100:.3f} % of range")
+        assert torch.isfinite(got).all()
+        assert float(d.mean()) <= 0.01 * R_ and float(d.max()) <= 0.08 * R_, name
+        if ref16 is not None:
+            assert float(d.mean()) < float((got - ref16.float()).abs().mean()), f"{name}: not closer to the fp8 oracle than to bf16"
+
+    stat("decoder layer, S=2249 -> hidden state (fp8 MFMA)", taps["layer0"], r8["layer0"], r16["layer0"])
+    stat("first-step logits [152064]", taps["first_logits"], logits8[0], logits16[0])
+    for t in range(2):
+        eng.cur_token.fill_(toks8[t])
+        eng.decode(1, use_graph=False)
+        stat(f"decode step {t + 1} logits (e4m3 weights)", eng.logits, logits8[t + 1])
+    del eng
+    torch.cuda.empty_cache()
