@@ -6,7 +6,8 @@ Decode kernels (gemv / decode_attn / argmax / gather) and torch's own fill kerne
 """
 import collections, csv, glob, sys
 
-DECODE = ("gemv_", "decode_attn", "argmax_", "gather_rows", "at::native", "__amd_rocclr", "scatter_rows", "gemm_decode", "skinny_")
+DECODE = ("gemv_", "decode_attn", "argmax_", "gather_rows", "at::native", "__amd_rocclr", "scatter_rows", "gemm_decode", "skinny_",
+          "Custom_Cijk")      # + the library GEMM of bench.py's peak microbenchmark
 f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 n_img = int(sys.argv[2])
 d = collections.defaultdict(list)
@@ -19,6 +20,8 @@ for r in csv.DictReader(open(f)):
     d[(name, int(r["Grid_Size_X"]) // max(wg, 1), int(r["Grid_Size_Y"]))].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 rows = []
 for (name, gx, gy), v in d.items():
+    if len(v) % n_img:      # not once (or k times) per prompt pass: bench.py's 8192^3 microbenchmark launches
+        continue
     v.sort()
     rows.append((sum(v) / n_img / 1e3, name, gx, gy, len(v) / n_img, v[len(v) // 2], v[0]))
 rows.sort(reverse=True)
