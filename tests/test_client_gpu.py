@@ -176,6 +176,9 @@ def test_streamed_batch_replies_equal_single_requests(local_cfg, images):
     texts = [r.choices[0].message.content for r in replies]
     assert texts == [r.choices[0].message.content for r in eager]
     assert texts[0] == texts[2] and replies[0].usage["prompt_tokens"] == eager[0].usage["prompt_tokens"]
+    # per-stage device time rides on the reply (extension): the batch's prompt passes and its shared decode loop
+    tm = replies[0].timings
+    assert tm["sequences"] == 3 and tm["prefill_ms"] > 0 and tm["decode_ms"] > 0 and tm["decode_steps"] >= 1
     bad = ingest.submit(lambda: (_ for _ in ()).throw(OSError("no such file")))
     mixed = agent.client.complete_many(agent.model_id, [futs[0], bad, futs[1]], 0.0, agent.max_tokens)
     assert isinstance(mixed[1], OSError) and mixed[0].choices[0].message.content == texts[0]

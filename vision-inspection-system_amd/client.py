@@ -12,12 +12,15 @@ substrings the reference's retry logic keys on (vlm_inspector.py:113-140).
 """
 from __future__ import annotations
 
+import logging
 import os
 import threading
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional, Tuple
 
 from .config import LOCAL_PROVIDER, Qwen2VLConfig
+
+logger = logging.getLogger("vision_inspection_system_amd.client")
 
 
 # ----------------------------------------------------------------------------- response objects
@@ -39,6 +42,9 @@ class ChatCompletion:
     choices: List[_Choice]
     model: str = ""
     usage: Dict[str, int] = field(default_factory=dict)
+    # device time per stage of the batch this reply was part of (extension; the reference logs wall time only:
+    # vlm_inspector.py:473-479): {"prefill_ms", "decode_ms", "decode_steps", "sequences", "prompt_tokens"}
+    timings: Dict[str, float] = field(default_factory=dict)
 
 
 class _Completions:
@@ -309,6 +315,10 @@ class LocalVLMClient:
                 idx = range(i, min(len(futs), i + eng.max_batch))
                 toks = eng.generate_batch([resolver(j) for j in idx], max_new_tokens=max_new, temperature=temp, seed=self.seed,
                                           ignore_eos=os.environ.get("VIS_IGNORE_EOS") == "1")
+                timing = dict(getattr(eng, "last_timing", {}))
+                if timing:
+                    logger.debug("%s: %d request(s): prompt pass %.1f ms, %d decode steps in %.1f ms (device time)", model_id,
+                                 len(idx), timing["prefill_ms"], timing["decode_steps"], timing["decode_ms"])
                 for j, t in zip(idx, toks):
                     if isinstance(t, Exception):
                         if not lazy:
@@ -317,7 +327,7 @@ class LocalVLMClient:
                         continue
                     out.append(ChatCompletion([_Choice(_Message(_reply_text(model_id, tok.decode(t))))], model=model_id,
                                               usage={"prompt_tokens": n_ids[j], "completion_tokens": len(t),
-                                                     "total_tokens": n_ids[j] + len(t)}))
+                                                     "total_tokens": n_ids[j] + len(t)}, timings=timing))
         return out
 
 

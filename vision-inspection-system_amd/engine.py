@@ -234,6 +234,7 @@ class Qwen2VLEngine:
                 self.vq8.append({n: q8pad(getattr(b, n)) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w")})
         self.slot_prompt_len = [0] * Bm
         self._prefill_streams: List[torch.cuda.Stream] = []
+        self.last_timing: dict = {}
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.min_shared_prefix = 256     # shorter common prefixes are not worth a separate pass
         self.temperature, self.seed = 0.0, 0
@@ -883,7 +884,10 @@ class Qwen2VLEngine:
         ``check_every`` tokens so the decode loop itself never synchronises; output is truncated at the
         first EOS (exclusive)."""
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # per-stage device time (SURVEY section 5: tracing)
+        ev[0].record()
         self.prefill(input_ids, frames, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
+        ev[1].record()
         done, eos = 1, set(self.cfg.eos_ids)
         while done < max_new_tokens:
             if not ignore_eos:
@@ -893,7 +897,10 @@ class Qwen2VLEngine:
             n = min(check_every if not ignore_eos else max_new_tokens, max_new_tokens - done)
             self.decode(n, use_graph=use_graph)
             done += n
-        toks = self.generated(done)
+        ev[2].record()
+        toks = self.generated(done)                                         # D2H: synchronises, the events have completed
+        self.last_timing = {"prompt_tokens": len(input_ids), "prefill_ms": ev[0].elapsed_time(ev[1]),
+                            "decode_ms": ev[1].elapsed_time(ev[2]), "decode_steps": done - 1, "sequences": 1}
         if not ignore_eos:
             for i, t in enumerate(toks):
                 if t in eos:
@@ -921,7 +928,10 @@ class Qwen2VLEngine:
             return [self.generate(r[0], r[1], max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)]
         # every prompt's own limit (prompt + new tokens <= context) is applied by its prefill; the shared loop below
         # runs to the limit of the longest one
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         slots, errors = self.prefill_many(requests, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
+        ev[1].record()
         live = [b for b in range(n_req) if slots[b] is not None]
         B = len(live)
         if B == 0:
@@ -947,7 +957,11 @@ class Qwen2VLEngine:
                 else:
                     self._decode_step_batched(B)
             done += n
+        ev[2].record()
         outs = collect(done)
+        # host waiting for the lazy requests' decodes is inside prefill_ms here: it is the time until all prompts are in
+        self.last_timing = {"prompt_tokens": longest, "prefill_ms": ev[0].elapsed_time(ev[1]),
+                            "decode_ms": ev[1].elapsed_time(ev[2]), "decode_steps": done - 1, "sequences": B}
         if not ignore_eos:
             outs = [seq[:next((i for i, t in enumerate(seq) if t in eos), len(seq))] for seq in outs]
         return [outs[slots[b]] if slots[b] is not None else errors[b] for b in range(n_req)]
