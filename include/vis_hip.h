@@ -147,6 +147,16 @@ int vis_skinny_finalize(const void* part, int ksplit, const void* bias, const vo
 int vis_resize_rgb_u8(const void* src, void* tmp, void* dst, int in_h, int in_w, int out_h, int out_w,
                       const void* kx, const void* bx, int ksx, const void* ky, const void* by, int ksy, void* stream);
 
+/* Service-side JPEG decode, GPU half (csrc/jpeg.hip; host half: include/vis_jpeg_host.h).  Replaces the libjpeg decode
+ * of the data-URI image the reference's agents send (src/agents/vlm_inspector.py:46-88 writes it; the service reads it).
+ * coeffs: int16 [blocks][64] quantised DCT coefficients in natural order, component planes back to back (Y, Cb, Cr),
+ * blocks row-major; qt: int32 [3][64]; planes: workspace of blocks * 64 bytes; rgb: uint8 [height][width][3].
+ * hs / vs: luma sampling factors (1x1, 2x1 or 2x2; chroma is 1x1); bw / bh: blocks per row / column of the luma and the
+ * chroma planes; dw_c / dh_c: real chroma size in samples.  Integer arithmetic throughout: the result equals
+ * libjpeg-turbo's default decoder (islow IDCT, fancy upsampling) bit for bit. */
+int vis_jpeg_to_rgb(const void* coeffs, const void* qt, void* planes, void* rgb, int width, int height, int ncomp,
+                    int hs, int vs, int bw_y, int bh_y, int bw_c, int bh_c, int dw_c, int dh_c, hipStream_t stream);
+
 /* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
  * out[row0 + p][ld_out] in the merge-group order of
  * TF image_processing_pil_qwen2_vl.py:156-190; mean/stdv are HOST pointers to 3 floats. */

@@ -48,6 +48,8 @@ with tempfile.TemporaryDirectory() as d:
     for n in [int(x) for x in a.threads.split(",")]:
         os.environ["VIS_INGEST_THREADS"] = str(n)
         ingest.shutdown()
+        from vision_inspection_system_amd.image_processing import clear_encode_cache
+        clear_encode_cache()            # every measured run encodes its own images (the two agents still share one encode)
         if a.profile:
             import cProfile, pstats
             pr = cProfile.Profile()

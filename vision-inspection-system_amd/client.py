@@ -230,6 +230,16 @@ def local_model_type(path: str) -> str:
     return mt
 
 
+def _frame_to_device(f, device):
+    """Host result of a request's decode -> uint8 [H, W, 3] device frame: either decoded pixels (PIL path, upload) or the
+    entropy-decoded JPEG (upload of the coefficients + the IDCT / upsampling / colour kernels)."""
+    import torch
+    from . import jpeg
+    if isinstance(f, jpeg.JpegCoeffs):
+        return jpeg.to_rgb_device(f, device)
+    return torch.from_numpy(f).to(device)
+
+
 # ----------------------------------------------------------------------------- clients
 class LocalVLMClient:
     """``InferenceClient``-shaped facade over the MI355X engine."""
@@ -248,6 +258,7 @@ class LocalVLMClient:
         The JPEG is decoded on the host; the bicubic resample to the smart_resize target runs on the GPU
         (hip.resize_rgb, bit-exact with PIL) unless VIS_GPU_RESIZE=0 asks for the host PIL path."""
         import numpy as np
+        from . import jpeg
         from .image_processing import decode_data_uri, resize_for_model, target_size
         from .tokenizer import build_chat_ids
         cfg = lm.cfg
@@ -259,6 +270,12 @@ class LocalVLMClient:
                 for part in content:
                     if part.get("type") == "image_url":
                         url = part["image_url"]["url"] if isinstance(part.get("image_url"), dict) else part["image_url"]
+                        # baseline JPEG (what the reference's agents send): Huffman decode here, on this pool thread;
+                        # IDCT / upsampling / colour conversion on the GPU (jpeg.py).  Other flavours: PIL.
+                        jc = jpeg.parse_data_uri(url) if (gpu_resize and jpeg.enabled()) else None
+                        if jc is not None:
+                            frames.append((jc, target_size(jc.size, cfg.patch, cfg.merge, cfg.min_pixels, cfg.max_pixels)))
+                            continue
                         img = decode_data_uri(url)
                         th, tw = target_size(img.size, cfg.patch, cfg.merge, cfg.min_pixels, cfg.max_pixels)
                         if gpu_resize:
@@ -307,7 +324,7 @@ class LocalVLMClient:
             def resolve():
                 ids, frames = futs[j].result()
                 n_ids[j] = len(ids)
-                return ids, [hip.resize_rgb(torch.from_numpy(f).to(eng.device), th, tw) for f, (th, tw) in frames]
+                return ids, [hip.resize_rgb(_frame_to_device(f, eng.device), th, tw) for f, (th, tw) in frames]
             return resolve
 
         with eng.lock:
@@ -335,6 +352,7 @@ class LocalVLMClient:
         """messages -> (token ids, decoded uint8 RGB frame or None).  The JPEG is decoded on the host, the tile canvas is
         chosen on the host; bilinear resample / normalise / patchify and everything after run on the GPU."""
         import numpy as np
+        from . import jpeg
         from .image_processing import decode_data_uri
         from .tokenizer import build_llama_chat_ids
         frames = []
@@ -344,7 +362,8 @@ class LocalVLMClient:
                 for part in content:
                     if part.get("type") == "image_url":
                         url = part["image_url"]["url"] if isinstance(part.get("image_url"), dict) else part["image_url"]
-                        frames.append(np.array(decode_data_uri(url), dtype=np.uint8))
+                        jc = jpeg.parse_data_uri(url) if jpeg.enabled() else None
+                        frames.append(jc if jc is not None else np.array(decode_data_uri(url), dtype=np.uint8))
         if len(frames) > 1:
             raise ValueError("the mllama backend takes one image per request (what the reference sends)")
         return build_llama_chat_ids(lm.tokenizer, messages, len(frames)), (frames[0] if frames else None)
@@ -374,7 +393,7 @@ class LocalVLMClient:
                 def resolve():
                     ids, f = futs[j].result()
                     n_ids[j] = len(ids)
-                    return ids, (torch.from_numpy(f).to(eng.device) if f is not None else None)
+                    return ids, (_frame_to_device(f, eng.device) if f is not None else None)
                 return resolve
 
             with eng.lock:
@@ -390,7 +409,7 @@ class LocalVLMClient:
             with_img = [i for i, (_, f) in enumerate(prepared) if f is not None]
             for g0 in range(0, len(with_img), eng.max_batch):
                 grp = with_img[g0:g0 + eng.max_batch]
-                reqs = [(prepared[i][0], torch.from_numpy(prepared[i][1]).to(eng.device)) for i in grp]
+                reqs = [(prepared[i][0], _frame_to_device(prepared[i][1], eng.device)) for i in grp]
                 outs = eng.generate_batch(reqs, max_new_tokens=max_new, temperature=temp, seed=self.seed,
                                           stop_on_eos=not ignore_eos)
                 for i, t in zip(grp, outs):

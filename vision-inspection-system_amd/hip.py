@@ -46,6 +46,7 @@ _SIGS = {
     "vis_skinny_finalize": "p" + "i" + "ppppp" + "iiiiii" + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_resize_rgb_u8": "ppp" + "iiii" + "ppi" + "ppi" + "p",
+    "vis_jpeg_to_rgb": "pppp" + "i" * 11 + "p",
     "vis_patchify_tiles_u8": "pp" + "iiiiii" + "pp" + "p",
     "vis_add_rows_bf16": "ppp" + "iiii" + "p",
     "vis_decode_cross_attn": "pppppppp" + "iiiii" + "ff" + "p",
@@ -646,6 +647,27 @@ def resize_rgb(frame: torch.Tensor, out_h: int, out_w: int, kind: str = "bicubic
                                   kx.shape[1], _ptr(ky), _ptr(by), ky.shape[1], _stream())
     _check(rc, "vis_resize_rgb_u8")
     return dst
+
+
+def jpeg_to_rgb(coeffs: torch.Tensor, qt: torch.Tensor, jc) -> torch.Tensor:
+    """Entropy-decoded JPEG (jpeg.JpegCoeffs geometry; ``coeffs`` int16 [total_blocks, 64] and ``qt`` int32 [3, 64] on the
+    device) -> uint8 [H, W, 3]: dequantise + integer IDCT per block, triangle chroma upsampling, fixed-point YCbCr -> RGB,
+    bit-exact with libjpeg-turbo / PIL."""
+    if coeffs.dtype != torch.int16 or coeffs.dim() != 2 or coeffs.shape[1] != 64 or not coeffs.is_contiguous():
+        raise HipLibraryError("jpeg_to_rgb: contiguous int16 [blocks, 64] coefficients required")
+    if qt.dtype != torch.int32 or qt.numel() != 192 or not qt.is_contiguous():
+        raise HipLibraryError("jpeg_to_rgb: int32 [3, 64] quantisation tables required")
+    n = jc.ncomp
+    bw_c, bh_c, dw_c, dh_c = (jc.bw[1], jc.bh[1], jc.dw[1], jc.dh[1]) if n == 3 else (0, 0, 0, 0)
+    total = jc.bw[0] * jc.bh[0] + 2 * bw_c * bh_c
+    if coeffs.shape[0] != total:
+        raise HipLibraryError(f"jpeg_to_rgb: {coeffs.shape[0]} coefficient blocks, geometry says {total}")
+    planes = torch.empty(total * 64, dtype=torch.uint8, device=coeffs.device)
+    rgb = torch.empty((jc.height, jc.width, 3), dtype=torch.uint8, device=coeffs.device)
+    rc = load().vis_jpeg_to_rgb(_ptr(coeffs), _ptr(qt), _ptr(planes), _ptr(rgb), jc.width, jc.height, n, jc.hs[0], jc.vs[0],
+                                jc.bw[0], jc.bh[0], bw_c, bh_c, dw_c, dh_c, _stream())
+    _check(rc, "vis_jpeg_to_rgb")
+    return rgb
 
 
 def image_stats(frame: torch.Tensor):
