@@ -498,6 +498,11 @@ def main():
                     help="nccl (= RCCL, the product path) or gloo (CPU rehearsal, with --dry-device cpu)")
     ap.add_argument("--dry-device", default=None, choices=["cpu"],
                     help="cpu: no model, no GPU - exercise launcher, rendezvous, record gather and timing only")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="REHEARSAL on a one-GPU box: all N ranks run the real model on cuda:0 and exchange their records over "
+                         "gloo (RCCL cannot place two ranks on one device).  Exercises launcher, per-rank engines, sharding, "
+                         "the store-voted gather and the timing protocol with real GPU work; the figure is NOT a scaling number "
+                         "and the JSON says so")
     ap.add_argument("--decode-weights", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: BASELINE configs[4] slice (e4m3 weights for the single-sequence decode GEMVs) - NOT the "
                          "headline precision; the JSON says so in dtype/config")
@@ -520,16 +525,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.dry_device == "cpu":
         return run_dry(args, rank, world)
-    if args.backend != "nccl":
-        raise SystemExit("bench.py: --backend gloo is only for --dry-device cpu; the product path is RCCL")
+    if args.backend != "nccl" and not args.share_gpu:
+        raise SystemExit("bench.py: --backend gloo is only for --dry-device cpu or --share-gpu; the product path is RCCL")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0                       # rehearsal: every rank on the one GPU of the box
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     if world > 1:
         from datetime import timedelta
-        dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=900))  # nccl == RCCL on ROCm
+        if args.share_gpu:
+            dist.init_process_group("gloo", timeout=timedelta(seconds=900))
+        else:
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=900))  # nccl == RCCL on ROCm
 
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
@@ -603,7 +613,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -649,7 +659,9 @@ def main():
                        "batch": B,
                        "image_px": args.image_size, "resized_px": list(frame_np.shape[:2]),
                        "image_tokens": n_img_tok, "prompt_tokens": S, "new_tokens": new,
-                       "weights": "seeded random bf16 at exact 7B shapes", "parallelism": f"dp{world} (whole images)"},
+                       "weights": "seeded random bf16 at exact 7B shapes",
+                       "parallelism": f"dp{world} (whole images)" if not args.share_gpu else
+                       f"REHEARSAL: {world} ranks sharing ONE GPU, records over gloo - not a scaling measurement"},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (fp8 or B > 1) else measured_traffic(), "bytes_per_launch": bytes_per_launch,

@@ -182,3 +182,19 @@ def test_streamed_batch_replies_equal_single_requests(local_cfg, images):
     bad = ingest.submit(lambda: (_ for _ in ()).throw(OSError("no such file")))
     mixed = agent.client.complete_many(agent.model_id, [futs[0], bad, futs[1]], 0.0, agent.max_tokens)
     assert isinstance(mixed[1], OSError) and mixed[0].choices[0].message.content == texts[0]
+
+
+def test_bench_two_ranks_sharing_the_gpu_rehearsal():
+    """`bench.py --gpus 2 --share-gpu`: the launcher starts two ranks, each builds its own engine on cuda:0 and inspects its
+    own synthetic image, every step's records are exchanged (store vote + gloo all_gather), rank 0 prints the one JSON line.
+    Real GPU work through the N > 1 code path on a one-GPU box (RCCL itself cannot put two ranks on one device)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--model", "tiny",
+                        "--image-size", "112", "--prompt-tokens", "64", "--new-tokens", "8", "--steps", "2", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
+    assert "REHEARSAL" in out["config"]["parallelism"]
