@@ -39,7 +39,11 @@ def host_lib():
     """libvis_jpeg_host.so (built by `make` / __graft_entry__.build()); raises if it is missing or does not match."""
     global _LIB
     if _LIB is None:
-        lib = ctypes.CDLL(os.path.join(_HERE, "csrc", "libvis_jpeg_host.so"))
+        path = os.path.join(_HERE, "csrc", "libvis_jpeg_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` (or "
+                               "__graft_entry__.build()); VIS_GPU_JPEG=0 decodes every image with PIL instead")
+        lib = ctypes.CDLL(path)
         lib.vis_jpeg_info_size.restype = ctypes.c_int
         if lib.vis_jpeg_info_size() != ctypes.sizeof(_Info):
             raise RuntimeError("libvis_jpeg_host.so does not match include/vis_jpeg_host.h (rebuild: make -C csrc)")
