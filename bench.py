@@ -361,8 +361,10 @@ def e2e_request(engine, cfg, image_size: int, prompt_tokens: int, new: int, reps
     t = sum(times) / len(times)
     return {"ms": t * 1e3, "images_per_s": 1.0 / t, "jpeg_bytes": len(buf.getvalue()),
             "prompt_tokens": usage["prompt_tokens"], "completion_tokens": usage["completion_tokens"],
-            "what": "LocalVLMClient.chat.completions.create: base64 JPEG decode (host) + H2D + GPU bicubic resize + "
-                    "tokenise + prefill + decode + detokenise, one request at a time"}
+            "what": "LocalVLMClient.chat.completions.create: base64 + JPEG Huffman decode (host) + H2D + GPU IDCT / colour + GPU "
+                    "bicubic resize + tokenise + prefill + decode + detokenise, one request at a time; text part first as the "
+                    "reference sends it, so from the second request on the prompt's text prefix comes from the engine's prefix "
+                    "cache (the kernel-only step recomputes it every time)"}
 
 
 GOOD_REPLY = ('```json\n{"object_identified": "steel bracket", "overall_condition": "damaged", "defects": [{"type": '

@@ -424,3 +424,48 @@ def test_lazy_requests_stream_into_the_batch_and_failures_stay_per_request(devic
     out = eng.generate_batch([lazy(0, fail=True), lazy(1)], max_new_tokens=6, ignore_eos=True)
     assert isinstance(out[0], ValueError) and out[1][0] == eager[1][0] and len(out[1]) == 6
     assert eng.generate_batch([lazy(3)], max_new_tokens=5, ignore_eos=True) == [eng.generate(*base[3], max_new_tokens=5, ignore_eos=True)]
+
+
+def test_prefix_cache_across_requests_is_bit_identical(device, monkeypatch):
+    """Prompt caching: the text in front of the image (the agents' fixed inspection prompt) is computed once and its K / V /
+    V^T kept across requests (LRU).  A later single request computes only the rows from the image on - same tokens and
+    bit-identical logits as the full pass; a batch takes its shared prefix from the same cache."""
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=1024, max_batch=4)
+    g = load_golden()
+    fa = [torch.from_numpy(g["frame_a"]).to(device)]
+    n_img = int((g["ids_a"] == cfg.image_token_id).sum())
+    rng = np.random.default_rng(3)
+
+    def prompt(seed, n_text=330, tail=(5, 6, 7)):
+        text = np.random.default_rng(seed).integers(0, 200, n_text).tolist()
+        return text + [cfg.vision_start_id] + [cfg.image_token_id] * n_img + [cfg.vision_end_id] + list(tail)
+
+    pa, pb = prompt(1), prompt(2)
+    assert eng.text_prefix_len(pa) == 320 and eng.text_prefix_len([cfg.vision_start_id] + pa) == 0
+    monkeypatch.setenv("VIS_SHARE_PREFIX", "0")
+    full_a = eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True)
+    logits_full = eng.logits.clone()
+    monkeypatch.setenv("VIS_SHARE_PREFIX", "1")
+    first = eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True)           # miss: prefix pass + suffix pass, kept
+    assert eng.prefix_cache_hits == 0 and len(eng._prefix_cache) == 1
+    again = eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True)           # hit: suffix rows only
+    assert eng.prefix_cache_hits == 1
+    assert first == full_a and again == full_a and torch.equal(eng.logits, logits_full)
+    # same text, another tail / another request in a batch: still the cached prefix
+    other = eng.generate(prompt(1, tail=(9,)), fa, max_new_tokens=4, ignore_eos=True)
+    assert eng.prefix_cache_hits == 2 and len(other) == 4
+    out = eng.generate_batch([(pa, fa), (prompt(1, tail=(9,)), fa)], max_new_tokens=8, ignore_eos=True)
+    assert eng.prefix_cache_hits == 3 and out[0][0] == full_a[0]
+    # LRU bound and switch
+    monkeypatch.setenv("VIS_PREFIX_CACHE", "2")
+    for s in (2, 3, 4):
+        eng.generate(prompt(s), fa, max_new_tokens=2, ignore_eos=True)
+    assert len(eng._prefix_cache) == 2
+    monkeypatch.setenv("VIS_PREFIX_CACHE", "0")
+    eng._prefix_cache.clear()
+    assert eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True) == full_a and len(eng._prefix_cache) == 0

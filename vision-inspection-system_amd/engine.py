@@ -16,6 +16,7 @@ Stages (kernel ids as in SURVEY.md section 8a):
 """
 from __future__ import annotations
 
+import collections
 import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -237,6 +238,12 @@ class Qwen2VLEngine:
         self.last_timing: dict = {}
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self.min_shared_prefix = 256     # shorter common prefixes are not worth a separate pass
+        # K / V / V^T of text prefixes seen before (prompt caching across requests): the reference's agents put the same
+        # ~1000-token inspection prompt in front of every image (vlm_inspector.py:452-470), so a later request - single or
+        # batched - computes only its rows from the image on.  LRU; VIS_PREFIX_CACHE = entries kept (0 = off), ~82 MB each
+        # at 7B shapes and 960 tokens.
+        self._prefix_cache: "collections.OrderedDict[bytes, dict]" = collections.OrderedDict()
+        self.prefix_cache_hits = 0
         self.temperature, self.seed = 0.0, 0
         self._vis_rope_cache: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
         self._rope_cache: Dict[tuple, tuple] = {}
@@ -657,8 +664,7 @@ class Qwen2VLEngine:
         shared = None
         P = self.shared_prefix_len([r[0] for r in first]) if (B > 1 and len(first) > 1) else 0
         if P:
-            shared = self.prefill(list(first[0][0][:P]), (), temperature=temperature, seed=seed, max_new_tokens=0,
-                                  slot=0, collect_prefix=True)
+            shared = self.cached_prefix(first[0][0], P, temperature, seed)
 
         def prefix_for(ids):
             if shared is None or len(ids) <= P:
@@ -716,6 +722,36 @@ class Qwen2VLEngine:
                 for st in streams:
                     t.record_stream(st)
         return slots, errors
+
+    def text_prefix_len(self, ids: Sequence[int]) -> int:
+        """Length (a multiple of 64, 0 = none worth keeping) of the text-only prefix of ONE prompt: everything in front of its
+        first image, leaving at least one row to compute."""
+        cfg = self.cfg
+        a = np.asarray(list(ids), dtype=np.int64)
+        special = np.nonzero((a == cfg.image_token_id) | (a == cfg.vision_start_id))[0]
+        P = int(special[0]) if special.size else len(a) - 1
+        P = (min(P, len(a) - 1) // 64) * 64
+        return P if P >= self.min_shared_prefix else 0
+
+    def cached_prefix(self, ids: Sequence[int], P: int, temperature: float = 0.0, seed: int = 0) -> Optional[dict]:
+        """The K / V / V^T bundle of ``ids[:P]`` (P from text_prefix_len / shared_prefix_len): from the cache, or computed
+        now (one pass over those rows - no more work than the full pass would have spent on them) and kept."""
+        keep = int(os.environ.get("VIS_PREFIX_CACHE", "4"))
+        if P <= 0:
+            return None
+        key = np.asarray(list(ids[:P]), dtype=np.int64).tobytes()
+        hit = self._prefix_cache.get(key) if keep > 0 else None
+        if hit is not None:
+            self._prefix_cache.move_to_end(key)
+            self.prefix_cache_hits += 1
+            return hit
+        bundle = self.prefill(list(ids[:P]), (), temperature=temperature, seed=seed, max_new_tokens=0, slot=0,
+                              collect_prefix=True)
+        if keep > 0:
+            self._prefix_cache[key] = bundle
+            while len(self._prefix_cache) > keep:
+                self._prefix_cache.popitem(last=False)
+        return bundle
 
     def shared_prefix_len(self, id_lists: Sequence[Sequence[int]]) -> int:
         """Length (a multiple of 64, 0 = do not share) of the text-only token prefix common to all prompts of a batch."""
@@ -886,7 +922,10 @@ class Qwen2VLEngine:
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # per-stage device time (tracing)
         ev[0].record()
-        self.prefill(input_ids, frames, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens)
+        # the text in front of the image (the agents' fixed inspection prompt): its K / V come from the prefix cache
+        P = self.text_prefix_len(input_ids) if os.environ.get("VIS_SHARE_PREFIX", "1") != "0" else 0
+        prefix = self.cached_prefix(input_ids, P, temperature, seed) if P else None
+        self.prefill(input_ids, frames, temperature=temperature, seed=seed, max_new_tokens=max_new_tokens, prefix=prefix)
         ev[1].record()
         done, eos = 1, set(self.cfg.eos_ids)
         while done < max_new_tokens:
