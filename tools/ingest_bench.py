@@ -4,7 +4,7 @@ shared decode loop, detokenise, parse, consensus, gates, aggregation - with the 
 on synthetic:mllama-11b (or the canned mock), 128 new tokens per model (EOS ignored: random weights), one rank.
 Prints one JSON line per ingest-thread setting.
 
-  python tools/ingest_bench.py --images 64 --auditor mllama|mock --threads 1,16
+  python tools/ingest_bench.py --images 64 --auditor mllama|mock --threads 1,4,16
 """
 import argparse, json, os, sys, tempfile, time
 import numpy as np
@@ -13,7 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--images", type=int, default=64)
 ap.add_argument("--size", type=int, default=1024)
 ap.add_argument("--auditor", default="mllama", choices=["mllama", "mock"])
-ap.add_argument("--threads", default="1,16")
+ap.add_argument("--threads", default="4")
 ap.add_argument("--new-tokens", type=int, default=128)
 ap.add_argument("--direct", action="store_true", help="VIS_DIRECT_FRAMES=1: no JPEG round trip between agent and engine")
 ap.add_argument("--profile", action="store_true", help="cProfile the measured call (main thread) and print the top entries")

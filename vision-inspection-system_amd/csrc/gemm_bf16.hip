@@ -1412,7 +1412,7 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
   const float cost4 = (float)((t4 + 255) / 256) * (1.41f * nk64 + 4.3f);
   bool huge = forced ? (forced == 4 || forced == 7) : (K >= 256 && M > 128 && N > 128 && cost4 < cost1);
   int cols4 = tn4;  // 256-wide tile columns given to the 256x256 kernel
-  if (!forced && K >= 1024 && M >= 1024 && t4 >= 768 && last != 0 && last < 128) {
+  if (!forced && K >= 1024 && M >= 1024 && t4 >= 512 && last != 0 && last < 128) {   // >= 2 whole rounds + a thin remainder
     cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only; the ragged remainder columns go through this function again
     huge = cols4 > 0;
   }

@@ -23,6 +23,7 @@ self-attention takes the sequence index on its grid and the cross-attention read
 from __future__ import annotations
 
 import math
+import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -286,6 +287,21 @@ class MllamaEngine:
         act = torch.empty((S, cfg.intermediate), dtype=bf, device=dev)
         scale = D ** -0.5
         si = ci = 0
+        # Long-K projections at a prompt's few hundred rows (o: 3 x 16 tiles of 256^2 at K = 4096; down: the same tiles at
+        # K = 14336) leave most of the chip idle as plain tiles: they run as K-slices (f32 slabs + fixed-order finalisation
+        # with the residual, vis_gemm_bf16_splitk).  The slice count is a function of the LAYER shape only, never of the row
+        # count, so a row's summation order - and slot / batch invariance - does not depend on the prompt (A/B: VIS_MLLAMA_SPLITK=0).
+        ks_down = int(os.environ.get("VIS_MLLAMA_SPLITK", "4")) if cfg.intermediate >= 8192 else 0
+        ks_o = int(os.environ.get("VIS_MLLAMA_SPLITK_O", "4")) if H >= 4096 else 0
+        ks_qkv = int(os.environ.get("VIS_MLLAMA_SPLITK_QKV", "0"))
+        swork = torch.empty(max(ks_down, ks_o, 1) * S * max(H, nq if ks_qkv else 0), dtype=torch.float32, device=dev) if (ks_down or ks_o or ks_qkv) else None
+
+        def proj(a, wt, ks):        # x += a @ wt.T
+            if ks >= 2:
+                hip.gemm_splitk(a, wt, swork, ks, residual=x, out=x)
+            else:
+                hip.gemm(a, wt, residual=x, out=x)
+
         for li, lw in enumerate(w.layers):
             if lw.cross:
                 if not has_image:
@@ -300,23 +316,26 @@ class MllamaEngine:
                 hip.rmsnorm(q2.view(S * Hq, D), lw.q_norm, cfg.rms_eps, out=q2.view(S * Hq, D))
                 hip.qkv_rope_split(q2, None, None, q, None, None, None, Hq, 0, D)
                 hip.attn_prefill(q, xk[ci], xvt, att, xwork, False, scale)
-                hip.gemm(att, lw.o_w, residual=x, out=x)
+                proj(att, lw.o_w, ks_o)
                 keep = x[:nm].clone() if nm > 0 else None
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
-                hip.gemm(act, lw.down_w, residual=x, out=x)
+                proj(act, lw.down_w, ks_down)
                 if keep is not None:              # rows before the image: MLP contribution zeroed (TF:...:697-699)
                     x[:nm].copy_(keep)
                 ci += 1
             else:
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
-                hip.gemm(y, lw.qkv_w, out=qkv)
+                if ks_qkv >= 2:
+                    hip.gemm_splitk(y, lw.qkv_w, swork, ks_qkv, out=qkv)
+                else:
+                    hip.gemm(y, lw.qkv_w, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, kcache[si], vcache[si], vt, Hq, Hkv, D, k_pos0=0)
                 hip.attn_prefill_pairs(q, kcache[si], vt, att, work, scale)
-                hip.gemm(att, lw.o_w, residual=x, out=x)
+                proj(att, lw.o_w, ks_o)
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
-                hip.gemm(act, lw.down_w, residual=x, out=x)
+                proj(act, lw.down_w, ks_down)
                 si += 1
             if taps is not None:
                 taps[f"layer{li}"] = x.clone()
