@@ -113,6 +113,7 @@ def test_mllama_backend_through_the_client_and_auditor(local_cfg, images):
     r2 = c.chat.completions.create(model="synthetic:mllama-tiny", messages=msgs, temperature=0.0, max_tokens=10)
     assert r1.choices[0].message.content == r2.choices[0].message.content
     assert r1.usage["completion_tokens"] <= 10 and get_model("synthetic:mllama-tiny").family == "mllama"
+    assert r1.timings["sequences"] == 1 and r1.timings["prefill_ms"] > 0 and r1.timings["decode_steps"] >= 0
     r3 = c.chat.completions.create(model="synthetic:mllama-tiny", messages=[{"role": "user", "content": "OK?"}], max_tokens=5)
     assert isinstance(r3.choices[0].message.content, str)
     cfg = C.get_config()

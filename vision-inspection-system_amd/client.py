@@ -380,7 +380,8 @@ class LocalVLMClient:
 
         def completion(n_ids, t):
             return ChatCompletion([_Choice(_Message(_reply_text(lm.model_id, tok.decode(t))))], model=lm.model_id,
-                                  usage={"prompt_tokens": n_ids, "completion_tokens": len(t), "total_tokens": n_ids + len(t)})
+                                  usage={"prompt_tokens": n_ids, "completion_tokens": len(t), "total_tokens": n_ids + len(t)},
+                                  timings=dict(getattr(eng, "last_timing", {})))
 
         futs = [ingest.then(m, lambda msgs: self._prepare_mllama(lm, msgs)) for m in batch_of_messages]
         if any(isinstance(m, Future) for m in batch_of_messages):

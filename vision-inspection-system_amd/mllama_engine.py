@@ -492,6 +492,8 @@ class MllamaEngine:
         slots: List[Optional[int]] = [None] * n_req
         errors: List[Optional[Exception]] = [None] * n_req
         B = 0
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
         for b, r in enumerate(requests):
             try:
                 ids, fr = r() if callable(r) else r
@@ -505,6 +507,7 @@ class MllamaEngine:
                 continue
             slots[b] = B
             B += 1
+        ev[1].record()
         if B == 0:
             return list(errors)
         longest = max(self.slot_prompt_len[s] for s in range(B))
@@ -528,7 +531,10 @@ class MllamaEngine:
                 else:
                     self._decode_step_batched(B)
             done += n
+        ev[2].record()
         outs = collect(done)
+        self.last_timing = {"prompt_tokens": longest, "prefill_ms": ev[0].elapsed_time(ev[1]),
+                            "decode_ms": ev[1].elapsed_time(ev[2]), "decode_steps": done - 1, "sequences": B}
         if stop_on_eos:
             outs = [seq[:next((i + 1 for i, t in enumerate(seq) if t in eos), len(seq))] for seq in outs]
         return [outs[slots[b]] if slots[b] is not None else errors[b] for b in range(n_req)]
@@ -540,7 +546,10 @@ class MllamaEngine:
     def generate(self, input_ids: Sequence[int], frame: Optional[torch.Tensor] = None, max_new_tokens: int = 128,
                  temperature: float = 0.0, seed: int = 0, stop_on_eos: bool = True, use_graph: bool = True,
                  chunk: int = 32) -> List[int]:
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # per-stage device time, as in Qwen2VLEngine
+        ev[0].record()
         self.prefill(input_ids, frame, temperature=temperature, seed=seed)
+        ev[1].record()
         max_new_tokens = min(max_new_tokens, self.max_ctx - len(input_ids) - 1)
         eos = set(self.cfg.eos_ids)
         done = 1
@@ -551,7 +560,10 @@ class MllamaEngine:
             n = min(chunk, max_new_tokens - done)
             self.decode(n, use_graph)
             done += n
-        toks = self.generated(done)
+        ev[2].record()
+        toks = self.generated(done)                      # D2H: synchronises, the events have completed
+        self.last_timing = {"prompt_tokens": len(input_ids), "prefill_ms": ev[0].elapsed_time(ev[1]),
+                            "decode_ms": ev[1].elapsed_time(ev[2]), "decode_steps": done - 1, "sequences": 1}
         if stop_on_eos:
             for i, t in enumerate(toks):
                 if t in eos:
