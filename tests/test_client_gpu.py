@@ -141,7 +141,7 @@ def test_batch_inspection_with_mllama_auditor(local_cfg, images):
         assert v["safety_verdict"]["verdict"] in ("SAFE", "UNSAFE", "REQUIRES_HUMAN_REVIEW")
 
 
-def test_batch_with_an_unreadable_image_streams_the_rest(local_cfg, images, tmp_path):
+def test_batch_with_an_unreadable_image_streams_the_rest(local_cfg, images, tmp_path, monkeypatch):
     """run_batch_inspection hands the encode futures straight to the local client (agents.prepare_many -> complete_many):
     a file that cannot be opened fails alone (analysis_failed -> GATE_0 -> UNSAFE), the other images are served by the
     shared decode loop, order is kept."""
@@ -151,6 +151,7 @@ def test_batch_with_an_unreadable_image_streams_the_rest(local_cfg, images, tmp_
     bad = tmp_path / "broken.png"
     bad.write_bytes(b"this is not a png")
     paths = [images[0], str(bad), images[1], images[2]]
+    monkeypatch.setenv("VIS_MAX_BATCH", "2")      # two groups: the second one's requests are encoded while the first is on the GPU
     out = run_batch_inspection(paths, "medium", "general")
     res = list(out["image_results"].values())
     assert [v["image_path"] for v in res] == paths

@@ -304,17 +304,23 @@ def run_multi_image_inspection(image_paths: List[str], criticality: str = "mediu
     if _inspect is run_inspection and len(my_idx) > 1 and _local_batching():
         try:  # shared-decode fast path; any problem falls back to the per-image loop below
             group = int(os.environ.get("VIS_MAX_BATCH", "64"))
-            # request-side encode of EVERY image of this rank goes to the ingest pool now (ingest.py): groups 2.. are
-            # encoded while the GPU works on group 1.  The prompt depends on (criticality, domain, notes) only.
+            # Request-side encode on the ingest pool (ingest.py), ONE group ahead: while the GPU works on group g the pool
+            # encodes group g + 1, and no more than two groups' requests (~1 MB of data URI per image and agent) are ever
+            # held in memory - a rank's list may be thousands of images.  The prompt depends on (criticality, domain,
+            # notes) only.
             from .agents import get_auditor, get_inspector
             ctx0 = InspectionContext(image_id="prefetch", criticality=criticality, domain=domain, user_notes=user_notes)
-            my_paths = [image_paths[i] for i in my_idx]
-            insp_f = get_inspector().prepare_many(my_paths, [ctx0] * len(my_paths))
-            aud_f = get_auditor().prepare_many(my_paths, [ctx0] * len(my_paths))
+            insp, aud = get_inspector(), get_auditor()
+
+            def prepare(g0):
+                paths = [image_paths[i] for i in my_idx[g0:g0 + group]]
+                return (insp.prepare_many(paths, [ctx0] * len(paths)), aud.prepare_many(paths, [ctx0] * len(paths))) if paths else None
+
+            ahead = prepare(0)
             for g0 in range(0, len(my_idx), group):
                 chunk = my_idx[g0:g0 + group]
-                outs = run_inspections_batched([image_paths[i] for i in chunk], criticality, domain, user_notes,
-                                               prepared=(insp_f[g0:g0 + group], aud_f[g0:g0 + group]))
+                cur, ahead = ahead, prepare(g0 + group)
+                outs = run_inspections_batched([image_paths[i] for i in chunk], criticality, domain, user_notes, prepared=cur)
                 pre.update(dict(zip(chunk, outs)))
         except Exception as e:
             logger.error(f"batched inspection failed ({e}); falling back to per-image processing", exc_info=True)
