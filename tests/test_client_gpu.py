@@ -200,3 +200,33 @@ def test_bench_two_ranks_sharing_the_gpu_rehearsal():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0
     assert "REHEARSAL" in out["config"]["parallelism"]
+
+
+def test_rccl_backend_single_rank_exchange(device):
+    """The record exchange on the REAL backend (nccl = RCCL), world size 1 - the most a one-GPU box can run of it: communicator
+    init, the store vote, the length + padded-bytes all_gather on device tensors, barrier, MAX all_reduce (bench.py's timing
+    reduction).  Runs in a child process: a process group cannot be re-created inside the test runner."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent(f"""
+        import sys, torch, torch.distributed as dist
+        sys.path.insert(0, {root!r})
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from vision_inspection_system_amd import batch
+        recs = [{{"image": "a", "tokens": list(range(50))}}, {{"image": "b", "tokens": [1, 2, 3]}}]
+        assert batch._all_gather_bytes(dist, b"hello RCCL") == [b"hello RCCL"]
+        merged, dead = batch.gather_records_ft(recs, timeout_s=30)
+        assert merged == recs and dead == [], (merged, dead)
+        assert batch.agree_on("sess", "session_id") == "sess"
+        dist.barrier()
+        t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert float(t.item()) == 1.5
+        dist.destroy_process_group()
+        print("RCCL OK")
+    """)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "RCCL OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
