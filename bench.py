@@ -29,7 +29,9 @@ The single JSON line also carries
   e2e          - what one ``chat.completions.create`` costs on the same 1024x1024 JPEG (data-URI decode, GPU
                  resize, tokenise, prefill, decode, detokenise) next to the kernel-only step;
   plumbing     - BASELINE configs[0]: run_multi_image_inspection with a canned-response client on 448x448
-                 frames (host logic only, no GPU), images/s.
+                 frames (host logic only, no GPU), images/s;
+  batch64, seam64, dual, fp8_batch4 - the per-GPU slices of configs[3] / [2] / [4] (tools/bench_blocks.py), each
+                 with its own HIP events and roofline figure; the headline value / config stay configs[1].
 """
 import argparse
 import io
@@ -153,10 +155,11 @@ def measure_gemv(engine, reps: int = 5):
     return s.elapsed_time(e) * 1e-3 / reps / launches, launches
 
 
-def measured_traffic():
-    """HBM bytes per gemv launch from the committed rocprofv3 PMC passes (profiles/*_gemv_traffic.json), or None."""
+def measured_traffic(kind: str = "gemv"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_<kind>_traffic.json: "gemv" = gemv_bf16_kernel, "decode_stream" = gemm_decode_stream_kernel), or None."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_gemv_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}_traffic.json")))
     if not files:
         return None
     try:
@@ -355,11 +358,19 @@ def e2e_request(engine, cfg, image_size: int, prompt_tokens: int, new: int, reps
             if i:
                 times.append(time.perf_counter() - t0)
             usage = r.usage
+        # cold form: the text prefix is NOT in the engine's prefix cache (a first request with this prompt); graphs and
+        # position tables stay warm, as they would be for any earlier request of another prompt
+        engine._prefix_cache.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        cl.chat.completions.create(model=model_id, messages=messages, temperature=0.0, max_tokens=new)
+        torch.cuda.synchronize()
+        cold = time.perf_counter() - t0
     finally:
         os.environ.pop("VIS_IGNORE_EOS", None)
         CL.unregister_model(model_id, str(engine.device))
     t = sum(times) / len(times)
-    return {"ms": t * 1e3, "images_per_s": 1.0 / t, "jpeg_bytes": len(buf.getvalue()),
+    return {"ms": t * 1e3, "images_per_s": 1.0 / t, "cold_prefix_ms": cold * 1e3, "jpeg_bytes": len(buf.getvalue()),
             "prompt_tokens": usage["prompt_tokens"], "completion_tokens": usage["completion_tokens"],
             "what": "LocalVLMClient.chat.completions.create: base64 + JPEG Huffman decode (host) + H2D + GPU IDCT / colour + GPU "
                     "bicubic resize + tokenise + prefill + decode + detokenise, one request at a time; text part first as the "
@@ -495,6 +506,8 @@ def main():
     ap.add_argument("--new-tokens", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the microbench / e2e / plumbing blocks")
+    ap.add_argument("--no-blocks", action="store_true",
+                    help="skip the batch64 / seam64 / dual / fp8_batch4 blocks (configs[2]/[3]/[4] per-GPU slices, ~2 min)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the product path) or gloo (CPU rehearsal, with --dry-device cpu)")
@@ -688,6 +701,13 @@ def main():
                 out["e2e"] = e2e_request(engine, cfg, args.image_size, args.prompt_tokens, new)
                 out["e2e"]["kernel_only_ms"] = elapsed / args.steps * 1e3
             out["plumbing"] = plumbing_baseline()
+            if B == 1 and not (fp8 or p8) and not args.no_blocks:
+                # configs[2] / [3] / [4] per-GPU slices, each with its own events and roofline (tools/bench_blocks.py); the
+                # headline value / config above stay configs[1]
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_blocks
+                out.update(bench_blocks.run_all(cfg, weights, dev, frame, n_patches, n_img_tok, new, args.prompt_tokens,
+                                                log=lambda m: print(f"[bench] {m}", file=sys.stderr, flush=True)))
         if not args.no_cpu_baseline and args.model == "7b" and world == 1:     # rank 0 at N = 1 only (the other ranks would idle)
             out["cpu_baseline"] = cpu_baseline(cfg, n_patches, S, new)
         print(json.dumps(out), flush=True)

@@ -119,3 +119,39 @@ def test_rank_failure_is_a_result_not_a_hang(tmp_path, mode):
     assert outs[0]["image_results"] == outs[1]["image_results"]
     if mode == "late":       # the late rank sees the same verdict about itself
         assert outs[2]["image_results"] == outs[0]["image_results"]
+
+
+def _worker_degraded(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      VIS_RANK_TIMEOUT_S="5")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vision_inspection_system_amd import batch as B
+    calls = []
+    real = B._all_gather_bytes
+    B._all_gather_bytes = lambda d, p: (calls.append(1), real(d, p))[1]
+    first, miss0 = B.gather_records_ft([{"r": rank, "n": 0}])            # clean: the collective
+    if rank == 1:
+        B._DEGRADED[0] = True       # what the except branch leaves behind when an exchange raised on this rank only
+    second, miss1 = B.gather_records_ft([{"r": rank, "n": 1}])           # rank 1 votes degraded -> everyone uses the store
+    third, miss2 = B.gather_records_ft([{"r": rank, "n": 2}])            # and stays there
+    with open(os.path.join(outdir, f"rank{rank}.json"), "w") as f:
+        json.dump({"first": first, "second": second, "third": third, "missing": [miss0, miss1, miss2],
+                   "collectives": len(calls), "degraded": B._DEGRADED[0]}, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_mode_is_voted_not_local(tmp_path):
+    """a rank whose exchange failed must not take the store path alone while the others enter the
+    collective.  The mode is published by rank 0 from every rank's vote; all ranks follow it."""
+    port = _free_port()
+    mp.spawn(_worker_degraded, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = json.load(open(tmp_path / "rank0.json"))
+    r1 = json.load(open(tmp_path / "rank1.json"))
+    for k in ("first", "second", "third"):
+        assert r0[k] == r1[k] and [x["r"] for x in r0[k]] == [0, 1]
+    assert r0["missing"] == r1["missing"] == [[], [], []]
+    assert r0["collectives"] == r1["collectives"] == 1            # only the first exchange used the default group
+    assert r0["degraded"] and r1["degraded"]

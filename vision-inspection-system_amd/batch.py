@@ -58,6 +58,7 @@ class RankFailure(RuntimeError):
 
 _GATHER_SEQ = [0]            # collectives are SPMD: every rank numbers its gathers the same way
 _DEAD_RANKS: set = set()     # once a rank missed a vote the default group is unusable: stay on the store path
+_DEGRADED = [False]          # this rank saw an exchange fail or run in store mode: it says so in every later vote
 
 
 def rank_timeout_s() -> float:
@@ -100,10 +101,13 @@ def gather_records_ft(records: List[dict], timeout_s: Optional[float] = None) ->
       1. every rank that reaches the exchange sets ``ready/<rank>``;
       2. rank 0 waits for each key up to ``timeout_s`` (VIS_RANK_TIMEOUT_S, default 600) and publishes the list of
          ranks that reported; the others wait for that list;
-      3. all ranks reported -> the payload moves with ONE all_gather pair on the default group (RCCL over xGMI);
-         otherwise the survivors exchange their payloads through the store (KBs per image) and the default group is
-         not touched again in this process.
-    If the coordinator itself is unreachable a rank returns its own records and reports every other rank missing."""
+      3. rank 0 also publishes the MODE of the exchange, and every rank follows the published mode rather than its own
+         view: ``collective`` - all ranks reported and none of them has ever seen an exchange fail - moves the payload
+         with ONE all_gather pair on the default group (RCCL over xGMI); ``store`` - a rank is missing, or any rank
+         reported itself degraded (an earlier exchange raised on it) - lets the survivors exchange their payloads
+         through the store (KBs per image); the default group is then not touched again in this process.
+    If the coordinator itself is unreachable a rank returns its own records, reports every other rank missing and votes
+    ``degraded`` from then on (so the others never wait for it inside a collective)."""
     dist = _dist()
     if dist is None or dist.get_world_size() == 1:
         return list(records), []
@@ -116,26 +120,40 @@ def gather_records_ft(records: List[dict], timeout_s: Optional[float] = None) ->
     pre = f"vis/gather{seq}"
     try:
         store = _default_store()
-        store.set(f"{pre}/ready/{rank}", b"1")
+        store.set(f"{pre}/ready/{rank}", b"degraded" if (_DEGRADED[0] or _DEAD_RANKS) else b"ok")
         if rank == 0:
             alive, deadline = [0], time.monotonic() + T
+            degraded = bool(_DEGRADED[0] or _DEAD_RANKS)
             for r in range(1, W):
                 if r in _DEAD_RANKS:
                     continue
                 try:
                     store.wait([f"{pre}/ready/{r}"], timedelta(seconds=max(0.05, deadline - time.monotonic())))
                     alive.append(r)
+                    degraded |= bytes(store.get(f"{pre}/ready/{r}")) != b"ok"
                 except Exception:
                     logger.error(f"rank {r} did not reach the result exchange within {T:.0f} s: its images are "
                                  f"reported as failed")
-            store.set(f"{pre}/alive", json.dumps(alive).encode())
+            mode = "collective" if (len(alive) == W and not degraded) else "store"
+            store.set(f"{pre}/alive", json.dumps({"alive": alive, "mode": mode}).encode())
         else:
             store.wait([f"{pre}/alive"], timedelta(seconds=2 * T + 5))
-            alive = json.loads(bytes(store.get(f"{pre}/alive")).decode())
+            verdict = json.loads(bytes(store.get(f"{pre}/alive")).decode())
+            alive, mode = verdict["alive"], verdict["mode"]
         dead = sorted(set(range(W)) - set(alive))
-        if not dead and not _DEAD_RANKS:
+        if mode == "collective":
             blobs = _all_gather_bytes(dist, payload)
+            if rank == 0 and seq > 0:
+                # every rank has voted in THIS exchange, so nobody can still be reading the previous one's keys
+                # (an exchange that was not clean leaves the process in store mode for good and never gets here)
+                try:
+                    for r in range(W):
+                        store.delete_key(f"vis/gather{seq - 1}/ready/{r}")
+                    store.delete_key(f"vis/gather{seq - 1}/alive")
+                except Exception:       # a store without delete_key: the keys are a few bytes per exchange
+                    pass
         else:
+            _DEGRADED[0] = True
             _DEAD_RANKS.update(dead)
             if rank in alive:
                 store.set(f"{pre}/payload/{rank}", payload)
@@ -148,7 +166,7 @@ def gather_records_ft(records: List[dict], timeout_s: Optional[float] = None) ->
                 blobs.append(bytes(store.get(f"{pre}/payload/{r}")))
     except Exception as e:       # coordinator (rank 0 / the store) unreachable: report what this rank has
         logger.error(f"result exchange failed on rank {rank} ({e}); returning this rank's records only", exc_info=True)
-        _DEAD_RANKS.update(r for r in range(W) if r != rank)
+        _DEGRADED[0] = True      # published with the next vote: the others then stay out of the collective as well
         return list(records), [r for r in range(W) if r != rank]
     merged: List[dict] = []
     for b in blobs:

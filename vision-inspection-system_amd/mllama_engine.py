@@ -484,6 +484,14 @@ class MllamaEngine:
         if not 1 <= n_req <= self.max_batch:
             raise ValueError(f"batch of {n_req} does not fit max_batch={self.max_batch}")
         lazy = any(callable(r) for r in requests)
+        if lazy and n_req == 1:
+            # one lazy request (always the case with max_batch == 1, where the batched buffers do not even exist): the
+            # single-sequence path; its failure stays its own, as in the batched form
+            try:
+                ids, fr = requests[0]() if callable(requests[0]) else requests[0]
+                return [self.generate(ids, fr, max_new_tokens, temperature, seed, stop_on_eos, use_graph)]
+            except Exception as e:      # noqa: BLE001
+                return [e]
         if not lazy and (n_req == 1 or any(fr is None for _, fr in requests)):
             if n_req > 1:
                 raise ValueError("generate_batch needs an image in every request (text-only prompts go through generate)")
