@@ -446,3 +446,28 @@ def test_ingest_pool_priorities_and_chaining(monkeypatch):
         assert ingest.submit(lambda: 5).result(10) == 5                   # a fresh pool is created on demand
     finally:
         ingest.shutdown()
+
+
+def test_direct_frame_handles_end_with_their_request(tmp_path, monkeypatch):
+    """VIS_DIRECT_FRAMES handles are released when the request that carried them is over (a frame is ~3 MB and
+    nothing else frees it), and the backstop cap follows VIS_MAX_BATCH: two groups x two agents + retries must fit."""
+    import numpy as np
+    from PIL import Image
+    from vision_inspection_system_amd import image_processing as IP
+    p = tmp_path / "f.png"
+    Image.fromarray(np.zeros((40, 50, 3), np.uint8)).save(p)
+    urls = [IP.frame_url_for(p) for _ in range(3)]
+    msgs = [[{"role": "user", "content": [{"type": "text", "text": "x"}, {"type": "image_url", "image_url": {"url": u}}]}]
+            for u in urls]
+    assert IP.decode_data_uri(urls[0]).size == (50, 40)
+    IP.release_frames(msgs[0])
+    IP.release_frames(None)
+    IP.release_frames([{"role": "user", "content": "text only"}])
+    with pytest.raises(ValueError):
+        IP.decode_data_uri(urls[0])
+    assert IP.decode_data_uri(urls[1]).size == (50, 40)          # the others are untouched
+    monkeypatch.setenv("VIS_MAX_BATCH", "64")
+    assert IP.frame_cap() == 512
+    monkeypatch.setenv("VIS_MAX_BATCH", "8")
+    assert IP.frame_cap() == 256
+    IP.release_frames(msgs[1]); IP.release_frames(msgs[2])

@@ -70,9 +70,15 @@ def test_7b_decode_step_agrees_with_prompt_pass(big):
     via_prefill = eng.logits.float().clone()
     scale = float(via_prefill.abs().max())
     diff = float((via_decode - via_prefill).abs().max())
-    # measured 2.6 - 3.0 % of the logit range over r01 / r02 builds (28 layers of bf16 hidden states on N(0, 0.02) weights:
-    # nearly flat logits, range ~ +-5.5); the exact-shape ORACLE comparison is tests/test_fullsize_oracle_gpu.py
-    assert diff <= 0.04 * scale, f"decode vs prefill logits differ by {diff} (scale {scale})"
+    rms = float((via_decode - via_prefill).pow(2).mean().sqrt())
+    print(f"decode vs prompt pass: rms {rms / scale:.5f}, max {diff / scale:.5f} of the logit range {scale:.3f}")
+    # The criterion is the RMS difference over the 152 064 logits (<= 1 % of the logit range): 28 layers of bf16 hidden
+    # states on N(0, 0.02) weights give nearly flat logits (range ~ +-5.5) and an error that is noise-like per logit, so
+    # the MAXIMUM is an extreme-value statistic (~4.5 sigma of 152 k samples) that moves by a tenth of itself between
+    # builds and boxes with nothing wrong (r01 / r02: 2.6 - 3.0 %, once 3.006 % against a 3 % limit - ADVICE r2); it is kept
+    # only as a loose outlier guard (6 sigma).  The exact-shape ORACLE comparison is tests/test_fullsize_oracle_gpu.py.
+    assert rms <= 0.010 * scale, f"decode vs prefill logits: rms difference {rms} (scale {scale})"
+    assert diff <= 6.0 * max(rms, 1e-6) and diff <= 0.05 * scale, f"decode vs prefill logits: outlier {diff} (rms {rms}, scale {scale})"
     top2 = torch.topk(via_prefill, 2).values
     if float(top2[0] - top2[1]) > 2 * diff:       # not a near-tie: the greedy pick must be the same
         assert int(via_decode.argmax()) == int(via_prefill.argmax()) == toks[3]

@@ -89,11 +89,63 @@ def test_flavours_the_parser_declines_and_damaged_data():
     assert J.parse(b.getvalue()) is None                         # 4 components -> PIL
     good = jpeg_bytes(img, quality=85)
     assert J.parse(good) is not None
-    assert J.parse(good[:len(good) // 2]) is not None or True    # a truncated scan decodes zeros or is refused: never crashes
     assert J.parse(b"not a jpeg at all") is None
     assert J.parse(good[:20]) is None                            # header cut short
-    for cut in (2, 10, 100, 200, 300, len(good) - 3):
-        J.parse(good[:cut])                                      # no crash, no out-of-bounds read (run under ASan in CI by hand)
+    # A scan that ends early must NOT come back as a picture (zero bits for the missing half = a half-grey frame the
+    # model would then "inspect"): the parser refuses it and the caller's PIL path raises "image file is truncated"
+    # (ADVICE r2, medium).  Every cut inside the entropy-coded data, down to the last byte before EOI.
+    sos = good.index(b"\xff\xda")
+    for cut in sorted({sos + 16, len(good) // 2, len(good) - 200, len(good) - 10, len(good) - 3, len(good) - 2}):
+        assert J.parse(good[:cut]) is None, cut
+        with pytest.raises(OSError):
+            Image.open(io.BytesIO(good[:cut])).convert("RGB")
+    assert J.parse(good[:-2]) is None                            # complete scan, EOI missing: PIL decides (it pads and warns)
+    assert J.parse(good[:-2] + b"\x00\x00\x00" + good[-2:]) is None       # extra bytes between the scan and EOI
+    mid = (sos + len(good)) // 2
+    assert J.parse(good[:mid] + b"\xff\xd9" + good[mid:]) is None        # an EOI in the middle of the scan
+    assert J.parse(good[:mid] + b"\xff\xd3" + good[mid:]) is None        # an RSTn nobody announced (no DRI)
+    rst = jpeg_bytes(img, quality=85, restart_marker_blocks=2)
+    assert J.parse(rst) is not None
+    k = rst.index(b"\xff\xd1")
+    assert J.parse(rst[:k] + b"\xff\xd5" + rst[k + 2:]) is None          # restart markers out of sequence
+    assert J.parse(rst[:k] + rst[k + 2:]) is None                        # a restart marker lost
+    assert J.parse(rst[:k - 1] + rst[k:]) is None or True                # a data byte lost in front of it: refused or not, no crash
     bad = bytearray(good)
     bad[len(bad) // 2] ^= 0x5A
     J.parse(bytes(bad))                                          # bit flip inside the scan: any result, no crash
+
+
+def test_truncated_request_fails_on_both_decode_paths():
+    """The client hands the engine identical frames on both decode paths - and refuses the same damaged requests."""
+    import base64
+    from vision_inspection_system_amd.image_processing import decode_data_uri
+    good = jpeg_bytes(Image.fromarray(_smooth(np.random.default_rng(5), 96, 128)), quality=85)
+    url = "data:image/jpeg;base64," + base64.b64encode(good[:len(good) // 2]).decode()
+    assert J.parse_data_uri(url) is None
+    with pytest.raises(Exception):
+        np.array(decode_data_uri(url))
+
+
+def test_dc_predictor_leaving_int16_is_refused():
+    """A crafted scan whose DC differences only ever add up: the predictor is range-checked (signed overflow is undefined
+    behaviour in C; no valid stream leaves the int16 range)."""
+    import struct
+    # one 8x8 grey JPEG frame header declaring 4096 x 8 pixels (512 blocks); DC table: one 1-bit code for category 11,
+    # AC table: one 1-bit code for EOB; scan = 512 x [0 | 11111111111 (+2047) | 0]
+    def seg(m, body):
+        return b"\xff" + bytes([m]) + struct.pack(">H", len(body) + 2) + body
+    dqt = seg(0xDB, bytes([0]) + bytes([1] * 64))
+    sof = seg(0xC0, bytes([8]) + struct.pack(">HH", 8, 4096) + bytes([1, 1, 0x11, 0]))
+    dht = seg(0xC4, bytes([0x00, 1] + [0] * 15 + [11]) + bytes([0x10, 1] + [0] * 15 + [0]))
+    sos = seg(0xDA, bytes([1, 1, 0x00, 0, 63, 0]))
+    bits = ("0" + "1" * 11 + "0") * 512
+    bits += "1" * (-len(bits) % 8)
+    scan = bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)).replace(b"\xff", b"\xff\x00")
+    data = b"\xff\xd8" + dqt + sof + dht + sos + scan + b"\xff\xd9"
+    assert J.parse(data) is None
+    ok_bits = ("0" + "1" * 11 + "0") + ("0" + "0" + "1" * 10 + "0") * 511        # +2047, then -2047 + ... stays in range
+    ok_bits = ("0" + "1" * 11 + "0" + "0" + "0" * 11 + "0") * 256                  # +2047, -2047 alternating
+    ok_bits += "1" * (-len(ok_bits) % 8)
+    scan = bytes(int(ok_bits[i:i + 8], 2) for i in range(0, len(ok_bits), 8)).replace(b"\xff", b"\xff\x00")
+    jc = J.parse(b"\xff\xd8" + dqt + sof + dht + sos + scan + b"\xff\xd9")
+    assert jc is not None and jc.coeffs[0, 0] == 2047 and jc.coeffs[1, 0] == 0

@@ -17,7 +17,7 @@ from typing import Any, Dict, Optional
 
 from .client import make_client
 from .config import LOCAL_PROVIDER, get_config
-from .image_processing import direct_frames_enabled, encode_image_optimized, frame_url_for
+from .image_processing import direct_frames_enabled, encode_image_optimized, frame_url_for, release_frames
 from .prompts import AUDITOR_PROMPT, INSPECTOR_PROMPT
 from .response_parsing import parse_json_robust, validate_and_fix_result
 from .schemas import InspectionContext, VLMAnalysisResult
@@ -138,6 +138,7 @@ class VLMInspectorAgent(_BaseAgent):
         """Image + context -> structured result.  Never raises: any failure becomes an
         ``analysis_failed=True`` result (vlm_inspector.py:515-526)."""
         self.logger.info(f"Starting inspection for image: {context.image_id}")
+        messages = None
         try:
             messages = self._messages(image_path, context)
             t0 = time.time()
@@ -147,6 +148,8 @@ class VLMInspectorAgent(_BaseAgent):
         except Exception as e:
             self.logger.error(f"Inspector analysis failed: {e}", exc_info=True)
             return self._failure(e)
+        finally:
+            release_frames(messages)       # VIS_DIRECT_FRAMES handles end with the request (all retries included)
 
     def analyze_many(self, image_paths, contexts, prepared=None) -> list:
         """Batch form of ``analyze`` for clients that can serve several requests with one shared decode loop
@@ -228,6 +231,7 @@ class VLMAuditorAgent(_BaseAgent):
         """Independent analysis of the same image; ``inspector_result`` is accepted and - as in the
         reference (vlm_auditor.py:187-191) - not shown to the model.  Never raises."""
         self.logger.info(f"Starting audit verification for: {context.image_id}")
+        messages = None
         try:
             messages = self._messages(image_path, context)
             t0 = time.time()
@@ -237,6 +241,8 @@ class VLMAuditorAgent(_BaseAgent):
         except Exception as e:
             self.logger.error(f"Auditor verification failed: {e}", exc_info=True)
             return self._failure(e)
+        finally:
+            release_frames(messages)
 
     def verify_many(self, image_paths, contexts, inspector_results=None, prepared=None) -> list:
         """Batch form of ``verify`` (see VLMInspectorAgent.analyze_many)."""
@@ -295,6 +301,9 @@ def _many(agent, image_paths, contexts, prepared=None) -> list:
                 results[i] = agent._interpret(text, contexts[i])
             except Exception as e:
                 results[i] = agent._failure(e)
+    for fut in futs:        # the batch call is over: VIS_DIRECT_FRAMES handles of its requests are released
+        if fut.done() and not fut.cancelled() and fut.exception() is None:
+            release_frames(fut.result())
     return results
 
 

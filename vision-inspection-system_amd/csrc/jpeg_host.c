@@ -221,7 +221,8 @@ typedef struct {
   size_t pos, n;
   uint64_t acc;   // bits left-justified? no: right-justified, `cnt` valid low bits
   int cnt;
-  int marker;     // a marker (not FF00) was reached: feed zero bits from here on
+  int marker;     // a marker (not FF00) or the end of the data was reached: feed zero bits from here on
+  int fake;       // how many of the `cnt` bits (always the lowest ones) are such made-up zero bits
 } Bits;
 
 static void fill(Bits* b) {
@@ -244,8 +245,14 @@ static void fill(Bits* b) {
     }
     b->acc = (b->acc << 8) | (uint64_t)byte;
     b->cnt += 8;
+    if (b->marker) b->fake += 8;
   }
 }
+
+// True when the decoder has consumed bits that were never in the file: the scan ended (marker or end of data) in the
+// middle of an MCU.  libjpeg pads such a scan with zero bits and warns; here the image goes back to the caller as
+// VIS_JPEG_CORRUPT and PIL decides what a damaged file means (it raises "image file is truncated").
+static inline int overran(const Bits* b) { return b->cnt < b->fake; }
 
 static inline int peek(Bits* b, int nbits) { return (int)((b->acc >> (b->cnt - nbits)) & ((1u << nbits) - 1)); }
 static inline void drop(Bits* b, int nbits) { b->cnt -= nbits; }
@@ -293,17 +300,17 @@ int vis_jpeg_decode_coeffs(const uint8_t* d, size_t n, const VisJpegInfo* info, 
   }
   memset(coeffs, 0, off * 64 * sizeof(int16_t));
   Bits b;
-  b.d = d; b.pos = (size_t)info->sos_offset; b.n = n; b.acc = 0; b.cnt = 0; b.marker = 0;
+  b.d = d; b.pos = (size_t)info->sos_offset; b.n = n; b.acc = 0; b.cnt = 0; b.marker = 0; b.fake = 0;
   int pred[3] = {0, 0, 0};
   int until_restart = info->restart_interval, next_rst = 0;
   for (int my = 0; my < info->mcus_y; ++my) {
     for (int mx = 0; mx < info->mcus_x; ++mx) {
       if (info->restart_interval && until_restart == 0) {
         // byte-align, expect RSTn, reset predictors
-        b.acc = 0; b.cnt = 0;
-        if (!b.marker) {  // the reader may not have seen the marker yet if the segment ended on a byte boundary
-          while (b.pos + 1 < b.n && !(b.d[b.pos] == 0xFF && b.d[b.pos + 1] != 0x00)) ++b.pos;
-        }
+        if (b.cnt - b.fake >= 8) return VIS_JPEG_CORRUPT;  // whole unread bytes between the interval's last MCU and RSTn
+        b.acc = 0; b.cnt = 0; b.fake = 0;
+        // (the reader may not have seen the marker yet if the segment ended on a byte boundary: it is then the next
+        // unread byte - anything else in front of it is damage)
         if (b.pos + 1 >= b.n || b.d[b.pos] != 0xFF || b.d[b.pos + 1] != (0xD0 + next_rst)) return VIS_JPEG_CORRUPT;
         b.pos += 2;
         b.marker = 0;
@@ -319,6 +326,7 @@ int vis_jpeg_decode_coeffs(const uint8_t* d, size_t n, const VisJpegInfo* info, 
             const int t = decode_sym(&b, &dc[c]);
             if (t < 0 || t > 11) return VIS_JPEG_CORRUPT;
             pred[c] += receive_extend(&b, t);
+            if (pred[c] < -32768 || pred[c] > 32767) return VIS_JPEG_CORRUPT;  // no valid stream leaves the int16 range
             blk[0] = (int16_t)pred[c];
             int k = 1;
             while (k < 64) {
@@ -338,9 +346,17 @@ int vis_jpeg_decode_coeffs(const uint8_t* d, size_t n, const VisJpegInfo* info, 
           }
         }
       }
+      if (overran(&b)) return VIS_JPEG_CORRUPT;  // the data ended (or a marker came) inside this MCU
       if (info->restart_interval) --until_restart;
     }
   }
+  // After the last MCU: < 8 padding bits, then EOI (fill FF bytes allowed in front of it).  Anything else - extra
+  // bytes, another marker, no EOI at all - is a damaged or unusual file: PIL decides.
+  if (b.cnt - b.fake >= 8) return VIS_JPEG_CORRUPT;
+  size_t q = b.pos;
+  if (q >= n || d[q] != 0xFF) return VIS_JPEG_CORRUPT;
+  while (q + 1 < n && d[q + 1] == 0xFF) ++q;
+  if (q + 1 >= n || d[q + 1] != 0xD9) return VIS_JPEG_CORRUPT;
   return VIS_JPEG_OK;
 }
 

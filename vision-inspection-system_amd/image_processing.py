@@ -151,7 +151,8 @@ def direct_frames_enabled() -> bool:
 
 def frame_url_for(image_path: Union[str, Path], max_size: int = 2048, convert_la: bool = True, logger=None) -> str:
     """a3 without the JPEG: open, thumbnail (LANCZOS) above ``max_size``, RGB; returns a ``vis-frame:`` URL that
-    ``decode_data_uri`` resolves inside this process (the newest 256 frames are kept)."""
+    ``decode_data_uri`` resolves inside this process.  The agent releases the handle when its request is over
+    (``release_frames``); as a backstop only the newest ``frame_cap()`` handles are kept."""
     img = Image.open(image_path)
     if max(img.size) > max_size:
         img.thumbnail((max_size, max_size), Image.Resampling.LANCZOS)
@@ -160,9 +161,35 @@ def frame_url_for(image_path: Union[str, Path], max_size: int = 2048, convert_la
         _FRAME_SEQ[0] += 1
         url = f"vis-frame:{_FRAME_SEQ[0]}"
         _FRAMES[url] = arr
-        while len(_FRAMES) > 256:
+        cap = frame_cap()
+        while len(_FRAMES) > cap:
             _FRAMES.popitem(last=False)
     return url
+
+
+def frame_cap() -> int:
+    """Handles kept at most: the batch seam holds two groups (the one on the GPU and the one encoded ahead) of
+    VIS_MAX_BATCH images for two agents, and a retried image re-encodes - so 4 x group x agents, never fewer than 256."""
+    return max(256, 8 * max(1, int(os.environ.get("VIS_MAX_BATCH", "64"))))
+
+
+def release_frames(messages) -> None:
+    """Drop the ``vis-frame:`` handles a finished request carried (a frame is ~3 MB; nothing else ever frees it)."""
+    if not isinstance(messages, list):
+        return
+    urls = []
+    for m in messages:
+        content = m.get("content") if isinstance(m, dict) else None
+        if isinstance(content, list):
+            for part in content:
+                if isinstance(part, dict) and part.get("type") == "image_url":
+                    u = part["image_url"]["url"] if isinstance(part.get("image_url"), dict) else part.get("image_url")
+                    if isinstance(u, str) and u.startswith("vis-frame:"):
+                        urls.append(u)
+    if urls:
+        with _FRAMES_LOCK:
+            for u in urls:
+                _FRAMES.pop(u, None)
 
 
 def decode_data_uri(url: str) -> Image.Image:
