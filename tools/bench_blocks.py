@@ -203,7 +203,13 @@ def run_all(cfg, weights, dev, frame, n_patches, n_img_tok, new, prompt_tokens, 
     from vision_inspection_system_amd import mllama_weights as MW
     from vision_inspection_system_amd.engine import Qwen2VLEngine
     from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    import logging
     out = {}
+    # the post-processing of the dual / seam blocks warns once per image (noise replies disagree): not on a timing run
+    quiet = [logging.getLogger(n) for n in ("vision_inspection_system_amd", "agent")]
+    levels = [lg.level for lg in quiet]
+    for lg in quiet:
+        lg.setLevel(logging.ERROR)
 
     def guarded(name, fn):
         t0 = time.perf_counter()
@@ -246,4 +252,6 @@ def run_all(cfg, weights, dev, frame, n_patches, n_img_tok, new, prompt_tokens, 
             del eng
     guarded("fp8_batch4", fp8)
     torch.cuda.empty_cache()
+    for lg, lv in zip(quiet, levels):
+        lg.setLevel(lv)
     return out

@@ -1031,8 +1031,13 @@ __device__ __forceinline__ float gumbel_noise(unsigned seed, unsigned step, unsi
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;
-  const float u = ((float)(z >> 40) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
-  return -__logf(-__logf(u));
+  // 23 random bits + 0.5: every value k + 0.5 (k < 2^23) is exact in f32, so u lies in [2^-24, 1 - 2^-24] - never 0 or 1.
+  // (24 bits + 0.5f rounds 16777215.5 up to 2^24, i.e. u = 1 and +inf noise once in 2^24 draws: at V = 152 064 logits
+  // that is a garbage token in ~1 % of the sampled steps.)
+  const float u = ((float)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);
+  // inner log in full precision: for u near 1 (the upper Gumbel tail, the draws that decide rare picks) -log u is
+  // tiny and the fast log's absolute error would be a large relative one; the outer log has no such problem
+  return -__logf(-logf(u));
 }
 
 __global__ __launch_bounds__(256) void argmax_stage1_kernel(const float* __restrict__ logits, int V,
