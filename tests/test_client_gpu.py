@@ -48,6 +48,26 @@ def test_chat_completions_shape(local_cfg, images):
     s1 = c.chat.completions.create(model="synthetic:tiny", messages=msgs, temperature=1.5, max_tokens=12)
     s2 = c.chat.completions.create(model="synthetic:tiny", messages=msgs, temperature=1.5, max_tokens=12)
     assert s1.choices[0].message.content == s2.choices[0].message.content
+    # T -> 0 is the greedy limit (the reference's operating point is T = 0.1 / 0.2: utils/config.py:46-49,:66-69); the
+    # distribution itself is checked at kernel level (test_sampling_follows_softmax_of_logits_over_temperature)
+    cold = c.chat.completions.create(model="synthetic:tiny", messages=msgs, temperature=1e-6, max_tokens=12)
+    assert cold.choices[0].message.content == r1.choices[0].message.content
+    # two threads on one engine (Streamlit: one thread per browser session): engine.lock
+    # serialises them; both get the single-threaded answer
+    import threading
+    got, errs = {}, []
+
+    def ask(name, temp):
+        try:
+            got[name] = [c.chat.completions.create(model="synthetic:tiny", messages=msgs, temperature=temp, max_tokens=12)
+                         .choices[0].message.content for _ in range(3)]
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+    th = [threading.Thread(target=ask, args=("greedy", 0.0)), threading.Thread(target=ask, args=("sampled", 1.5))]
+    [t.start() for t in th]
+    [t.join(120) for t in th]
+    assert not errs and not any(t.is_alive() for t in th)
+    assert got["greedy"] == [r1.choices[0].message.content] * 3 and got["sampled"] == [s1.choices[0].message.content] * 3
     # text-only health-check style call, no temperature
     r3 = c.chat.completions.create(model="synthetic:tiny", messages=[{"role": "user", "content": "Respond with only the word 'OK'"}], max_tokens=10)
     assert isinstance(r3.choices[0].message.content, str)

@@ -282,6 +282,71 @@ def test_attn_prefill(hip, device, S, Hq, Hkv, HD, causal, segments):
     _assert_close(got, ref, atol=2e-2, rtol=2e-2, what=f"attn S={S} HD={HD} causal={causal}")
 
 
+VIT_CASES = [
+    # S, H, segments (None = one), q_row0
+    (100, 2, None, 0),                                     # one partial item: 4 of the 12 waves, 36-row last wave
+    (384, 2, None, 0),                                     # exactly one full item
+    (4900, 16, None, 0),                                   # the 980 x 980 frame: 13 items per head, ragged last tile
+    (1000, 4, [(0, 333), (333, 1000)], 0),                 # two images, unaligned boundary: masks at both tile edges
+    (6432, 3, [(0, 6404), (6404, 6432)], 0),               # mllama-like: a long segment and a 28-row one
+    (700, 2, [(0, 700)], 0),
+]
+
+
+@pytest.mark.parametrize("S,H,segments,q_row0", VIT_CASES)
+def test_attn_prefill_vit_equals_attn_prefill_and_reference(hip, device, S, H, segments, q_row0):
+    """The 12-wave pipelined ViT kernel (vis_attn_prefill_vit) against the fp32 reference AND, bit for bit, against the
+    4-wave kernel behind vis_attn_prefill (same fragments, same accumulation order over the absolute key tiles)."""
+    HD = 80
+    segments = segments or [(0, S)]
+    q = _randn((H, S, HD), device, 140)
+    k = _randn((H, S, HD), device, 141)
+    v = _randn((H, S, HD), device, 142)
+    ld = ((S + 63) // 64) * 64
+    vt = torch.zeros((H, HD, ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v.permute(0, 2, 1)
+    vt = vt[:, :, hip.vt_key_order(ld, device)].contiguous()
+    scale = HD ** -0.5
+    out = torch.full((S, H * HD), 7.0, dtype=torch.bfloat16, device=device)
+    hip.attn_prefill_vit(q, k, vt, out, hip.make_vit_work(segments, device), scale)
+    base = torch.zeros_like(out)
+    hip.attn_prefill(q, k, vt, base, hip.make_attn_work(segments, False, device, heads=H), False, scale)
+    assert torch.equal(out, base), "pipelined and 4-wave kernels must agree bit for bit"
+    heads = [0, H - 1] if S > 1024 else list(range(H))
+    ref = torch.cat([_attn_ref(q[h:h + 1].float().cpu(), k[h:h + 1].float().cpu(), v[h:h + 1].float().cpu(), segments,
+                               False, scale) for h in heads], dim=1)
+    got = torch.cat([out[:, h * HD:(h + 1) * HD] for h in heads], dim=1)
+    _assert_close(got, ref, atol=2e-2, rtol=2e-2, what=f"vit attention S={S}")
+
+
+def test_attn_prefill_vit_spiked_max_and_cross_keys(hip, device):
+    """Rescale branch (a dominating key in a late tile) and keys that are not the queries' own rows (the mllama tower's
+    second item group: queries n_real.. attend keys 0..n_real), with ready-made items and a repeated launch (the LDS pad
+    rows must survive from tile to tile and from launch to launch)."""
+    S, H, HD = 900, 2, 80
+    q = _randn((H, S, HD), device, 150, 0.5)
+    k = _randn((H, S, HD), device, 151, 0.5)
+    v = _randn((H, S, HD), device, 152)
+    k[:, 770] = q[:, 10] * 8.0          # key 770 (13th tile) dominates query 10
+    ld = 960
+    vt = torch.zeros((H, HD, ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v.permute(0, 2, 1)
+    vt = vt[:, :, hip.vt_key_order(ld, device)].contiguous()
+    items = [(0, 384, 0, 900), (384, 316, 0, 900), (700, 200, 0, 700)]
+    work = hip.make_vit_work(items, device, segments=False)
+    out = torch.zeros((S, H * HD), dtype=torch.bfloat16, device=device)
+    for _ in range(2):
+        hip.attn_prefill_vit(q, k, vt, out, work, HD ** -0.5)
+    qf, kf, vf = q.float().cpu(), k.float().cpu(), v.float().cpu()
+    ref = torch.empty((S, H, HD))
+    for (q0, qn, k0, k1) in items:
+        sc = torch.einsum("hqd,hkd->hqk", qf[:, q0:q0 + qn], kf[:, k0:k1]) * HD ** -0.5
+        ref[q0:q0 + qn] = torch.einsum("hqk,hkd->qhd", torch.softmax(sc, dim=-1), vf[:, k0:k1])
+    _assert_close(out, ref.reshape(S, H * HD), atol=2e-2, rtol=2e-2, what="vit attention, spiked max / cross keys")
+    with pytest.raises(hip.HipLibraryError):
+        hip.make_vit_work([(0, 385, 0, 900)], device, segments=False)
+
+
 def test_attn_prefill_spiked_max(hip, device):
     """Force the online-softmax rescale branch: one key with a huge score late in the sequence."""
     S, H, HD = 300, 2, 128
@@ -863,3 +928,71 @@ def test_decode_attn_streaming_form(hip, device, monkeypatch, Hq, Hkv, B, T):
         kk, vv = xk[b, :, :n].float().cpu(), xv[b, :, :n].float().cpu()
         ref = torch.stack([torch.softmax((kk[h // G] @ qq[h]) * HD ** -0.5, 0) @ vv[h // G] for h in range(Hq)])
         _assert_close(res["2"][b].reshape(Hq, HD), ref, atol=2e-2, rtol=2e-2, what=f"streaming cross attention seq {b}")
+
+
+# ----------------------------------------------------------------------------- K12 sampling
+def _sample_many(hip, device, logits, T, n, seed, B=1):
+    """n Gumbel-max draws per row through vis_argmax_f32 (the step counter advances by itself: a fresh noise stream per
+    draw, exactly as in the decode graph)."""
+    V = logits.shape[-1]
+    lg = logits.to(device).float().reshape(1, V).repeat(B, 1).contiguous()
+    tokens = torch.zeros((B, n), dtype=torch.int32, device=device)
+    cur = torch.zeros(B, dtype=torch.int32, device=device)
+    step = torch.zeros(B, dtype=torch.int32, device=device)
+    wv = torch.empty(256 * B, dtype=torch.float32, device=device)
+    wi = torch.empty(256 * B, dtype=torch.int32, device=device)
+    for _ in range(n):
+        hip.argmax(lg if B > 1 else lg[0], wv, wi, tokens if B > 1 else tokens[0], cur, step, T, seed)
+    return tokens.cpu().numpy()
+
+
+@pytest.mark.parametrize("T", [0.1, 0.2, 1.0])
+def test_sampling_follows_softmax_of_logits_over_temperature(hip, device, T):
+    """The reference calls its models with temperature 0.1 / 0.2 (utils/config.py:46-49,:66-69; vlm_inspector.py:105-111).
+    The Gumbel-max pick must sample softmax(logits / T): chi-square of 20 000 draws over 64 logits against the exact
+    probabilities (bins with an expectation below 5 merged), at the reference's operating points and at T = 1."""
+    from scipy import stats
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(64, generator=g) * 1.5
+    if T < 0.5:     # keep several outcomes alive at low temperature: a cluster of near-equal leaders
+        logits[:6] = logits.max() + torch.tensor([0.0, -0.02, -0.05, -0.1, -0.2, -0.3])
+    n = 20000
+    draws = np.concatenate([_sample_many(hip, device, logits, T, n // 4, seed)[0] for seed in (1, 2, 3, 4)])
+    p = torch.softmax(logits.double() / T, dim=0).numpy()
+    obs = np.bincount(draws, minlength=64).astype(np.float64)
+    exp = p * n
+    big = exp >= 5
+    o = np.append(obs[big], obs[~big].sum())
+    e = np.append(exp[big], exp[~big].sum())
+    if e[-1] < 1e-9:
+        assert o[-1] == 0
+        o, e = o[:-1], e[:-1]
+    assert len(e) >= 3, "the test distribution must keep several outcomes"
+    chi2, pval = stats.chisquare(o, e * o.sum() / e.sum())
+    assert pval > 1e-3, f"T={T}: chi2 {chi2:.1f} over {len(e)} bins, p = {pval:.2e}"
+
+
+def test_sampling_limits_and_stream_independence(hip, device):
+    """T -> 0 reproduces the greedy pick; temperature 0 IS greedy (first index on ties); the slots of a batch draw from
+    independent noise streams (seed mixing by slot) while every slot alone follows the same distribution; a fixed seed
+    reproduces its draws; no draw ever leaves the support (u = 1 -> +inf noise would: 152 064 logits x 2 000 steps)."""
+    g = torch.Generator().manual_seed(9)
+    logits = torch.randn(64, generator=g)
+    greedy = int(logits.argmax())
+    assert (_sample_many(hip, device, logits, 0.0, 8, 5) == greedy).all()
+    assert (_sample_many(hip, device, logits, 1e-4, 64, 5) == greedy).all()
+    tie = logits.clone(); tie[40] = tie[3] = logits.max() + 1.0
+    assert (_sample_many(hip, device, tie, 0.0, 4, 5) == 3).all()
+    a = _sample_many(hip, device, logits, 1.0, 512, 11, B=4)
+    b = _sample_many(hip, device, logits, 1.0, 512, 11, B=4)
+    assert (a == b).all()                                        # reproducible
+    for i in range(4):
+        for j in range(i + 1, 4):
+            agree = float((a[i] == a[j]).mean())                 # independent slots agree with probability sum p^2
+            p = torch.softmax(logits.double(), 0)
+            assert abs(agree - float((p * p).sum())) < 0.08, (i, j, agree)
+    assert not (a[0] == _sample_many(hip, device, logits, 1.0, 512, 12, B=4)[0]).all()      # another seed, other draws
+    # full-vocabulary support check: one dominant token at p ~ 1 - 1e-9 must win every draw
+    big = torch.full((152064,), -30.0); big[777] = 0.0
+    draws = _sample_many(hip, device, big, 1.0, 2000, 3)
+    assert (draws == 777).all(), f"{(draws != 777).sum()} draws left the support"

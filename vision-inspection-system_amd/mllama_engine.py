@@ -176,9 +176,9 @@ class MllamaEngine:
         return frame.contiguous(), th, tw, ar_id
 
     # ------------------------------------------------------------------ vision tower
-    def _vision_work(self, n_real: int, n_all: int) -> torch.Tensor:
-        items = [(q0, min(128, n_real - q0), 0, n_all) for q0 in range(0, n_real, 128)]
-        items += [(q0, min(128, n_all - q0), 0, n_real) for q0 in range(n_real, n_all, 128)]
+    def _vision_work(self, n_real: int, n_all: int, block: int = 128) -> torch.Tensor:
+        items = [(q0, min(block, n_real - q0), 0, n_all) for q0 in range(0, n_real, block)]
+        items += [(q0, min(block, n_all - q0), 0, n_real) for q0 in range(n_real, n_all, block)]
         return torch.tensor(items, dtype=torch.int32, device=self.device).reshape(-1, 4).contiguous()
 
     def vision_forward(self, frame: torch.Tensor, taps: Optional[dict] = None) -> Tuple[torch.Tensor, int]:
@@ -194,7 +194,8 @@ class MllamaEngine:
         x = torch.zeros((N, E), dtype=bf, device=dev)                      # pad rows start as exact zeros
         hip.gemm(patches, w.patch_w, residual=w.cls_pos[ar_id].view(TP, E), out=x[:TP])
         hip.layernorm(x[:TP], w.ln_pre_w, w.ln_pre_b, 1e-5, out=x[:TP])
-        work = self._vision_work(nR, N)
+        vit = D == 80 and hip.vit_attention_enabled()      # 12-wave pipelined kernel (bit-identical results)
+        work = self._vision_work(nR, N, hip.VIT_BLOCK_Q if vit else 128)
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
@@ -210,7 +211,10 @@ class MllamaEngine:
             hip.layernorm(x, b.ln1_w, b.ln1_b, cfg.v_eps, out=y)
             hip.gemm(y, b.qkv_w, out=qkv)
             hip.qkv_rope_split(qkv, None, None, q, k, None, vt, Hh, Hh, D)
-            hip.attn_prefill(q, k, vt, att, work, False, scale)
+            if vit:
+                hip.attn_prefill_vit(q, k, vt, att, work, scale)
+            else:
+                hip.attn_prefill(q, k, vt, att, work, False, scale)
             hip.gemm(att, b.o_w, residual=x, out=x)
             hip.layernorm(x, b.ln2_w, b.ln2_b, cfg.v_eps, out=y)
             hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_GELU_ERF, out=hmid)
