@@ -83,16 +83,6 @@ int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O,
                           int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
                           float scale, int q_row0, vis_stream_t stream);
 
-/* K6, the ViT form (HD = 80, non-causal): work items {q0, qn <= 384, k0, k1}, one 12-wave workgroup each - three
- * groups of four waves run QK^T, softmax and P*V of consecutive tiles as a three-stage pipeline, so that every SIMD
- * always holds one wave in each phase (v_mfma_f32_32x32x16_bf16; the softmax denominator comes out of the pad rows of the
- * V^T image).  Tensors as vis_attn_prefill_rows; results equal vis_attn_prefill_rows(..., HD = 80, causal = 0) bit for
- * bit.  For long segments (whole images, TF modeling_qwen2_vl.py:356-423; mllama tower :234-268); windows and other short
- * items belong to vis_attn_prefill. */
-int vis_attn_prefill_vit(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
-                         int Hq, int Hkv, int Sq, int k_tokens, int vt_ld, int ldo, float scale, int q_row0,
-                         vis_stream_t stream);
-
 /* K7, balanced form (HD = 128, causal, keys from 0): work = n_work x int4 {qB0, qBn, qA0, qAn}, a late and an early
  * 128-row query block of one sequence per 512-thread workgroup (qAn = 0: none), so that every workgroup of the causal
  * grid carries the same number of key tiles.  Results equal vis_attn_prefill_rows(..., causal = 1). */

@@ -46,18 +46,6 @@ torch.cuda.synchronize()
 t = s.elapsed_time(e) / a.reps * 1e-3
 fl = 4.0 * S * S * HD * Hq * (0.5 if causal else 1.0)
 print(f"{a.which}: {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s")
-if not causal and HD == 80:
-    vw = hip.make_vit_work([(0, S)], dev)
-    for _ in range(2):
-        hip.attn_prefill_vit(q, k, vt, o, vw, HD ** -0.5)
-    torch.cuda.synchronize()
-    s.record()
-    for _ in range(a.reps):
-        hip.attn_prefill_vit(q, k, vt, o, vw, HD ** -0.5)
-    e.record()
-    torch.cuda.synchronize()
-    t = s.elapsed_time(e) / a.reps * 1e-3
-    print(f"{a.which} 12-wave pipelined ({vw.shape[0]} items): {t*1e3:.3f} ms  {fl/t/1e12:.1f} TFLOP/s")
 if causal and HD == 128:
     pw = hip.make_attn_pairs(0, S, dev)
     for _ in range(2):

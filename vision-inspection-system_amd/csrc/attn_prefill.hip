@@ -54,6 +54,9 @@ struct AttnArgs {
   int Sq, k_tokens, vt_ld, ldo, group;
   float scale_log2;
   int q_row0;        // work-list query rows are positions of the whole sequence; Q / O hold rows q_row0 .. q_row0 + Sq - 1
+#ifdef VIT_VARIANTS_STAMPS
+  unsigned long long* stamps;   // tools/probes/attn_vit_variants.hip only: s_memtime stamps of workgroup (0, 0)
+#endif
 };
 
 #define ATT_NEG (-1.0e30f)
@@ -458,10 +461,10 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
 // ---------------------------------------------------------------------------
 // K6 (r03): the ViT kernel - head_dim 80, non-causal - on v_mfma_f32_32x32x16_bf16.
 //
-// Why another MFMA shape: a 16x16x32 MFMA holds its SIMD's vector issue for 8 of its 16 cycles, a 32x32x16 one for 8
-// of its 32 (MI355X_MICROARCH.md, cycle constants) - and flash attention at head_dim 80 issues ~11 VALU instructions
-// per MFMA of the 16-wide form (fma + exp + max + add + pack per score).  PMC on the kernel above: MFMA pipe 37 % busy,
-// VALU and MFMA each waiting for the other's issue slots.  Here a wave owns ONE 32-row query block:
+// Why another MFMA shape: flash attention at head_dim 80 issues ~11 vector instructions per MFMA of the 16-wide form
+// (fma + exp + max + add + pack per score, 16 leftover dims on a third MFMA form); the 32-wide form needs 22 MFMAs and
+// ~100 vector instructions per (32 query x 64 key) wave tile instead of 40 and ~330, has no tail form, and its softmax
+// denominator is free (below).  Here a wave owns ONE 32-row query block:
 //   S^T[key][q] = K * Q^T      A = K rows from LDS (32 keys x 16 d per MFMA, one ds_read_b128), B = Q^T in registers;
 //                              head_dim 80 = 5 k-steps of 16, no tail form; 10 MFMAs per 64-key tile
 //   softmax                    the query is the lane (lane & 31), its 64 keys of the tile are 32 registers here and 32 on
@@ -474,7 +477,14 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
 //                              for themselves: LDS row 80 of the V^T image holds ones, so O^T[80][q] IS the softmax
 //                              denominator (sum of the bf16-rounded probabilities, exactly the weights P*V uses) - no
 //                              v_add per score, no extra MFMA.
-// 22 MFMAs x 32 cycles per (32 query x 64 key) wave-tile, 176 cycles of issue hold (16-wide form: 40 x 16, 320 held).
+// Measured (r03, 4900 patches x 16 heads, N(0,1) data): 192-195 us against 203-214 us for the 16-wide kernel.  PMC
+// (profiles/r03_vit_attention_pmc.txt): MFMA pipe 44 % busy, vector instructions active 50 % of the SIMD's time, and the
+// two never overlap beyond the MFMA's own issue cycles (SQ_VALU_MFMA_COEXEC_CYCLES = 8 x the MFMA count): on this part a
+// SIMD's time is MFMA-busy + vector-issue cycles, whichever wave they come from.  Two restructurings that try to hide one
+// behind the other - a 12-wave workgroup whose three wave groups run QK^T / softmax / P*V as a three-stage pipeline, and a
+// hand-placed MFMA / VALU stream inside each wave at 32-key half tiles - are correct and land on the same time
+// (tools/probes/attn_vit_variants.hip, vit_probe.py: stamps show a ~100-instruction softmax phase taking 700 cycles alone
+// and 1700 beside two MFMA waves, with or without s_setprio).  They are kept as probe sources, not in this library.
 // LDS images: K dense 160-byte rows, 16-byte chunk index XOR ((row >> 3) & 1) - under the ds_read_b128 lane groups
 // ({0-3,12-15,20-27}, ...) with 32 rows per instruction this is the conflict-free form (10 r mod 16 repeats with period
 // 8; the XOR moves rows 8..15 / 24..31 to the odd slots); V^T 128-byte rows, chunk XOR ((d >> 1) & 7), as above.  Both
@@ -686,272 +696,6 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         if (db == 2 && g >= 2) break;                // d >= 80: pad rows
-        const int d0 = 32 * db + 8 * g + 4 * hh;
-        u32x2 o2;
-        o2[0] = pack2bf(oacc[db][4 * g] * a, oacc[db][4 * g + 1] * a);
-        o2[1] = pack2bf(oacc[db][4 * g + 2] * a, oacc[db][4 * g + 3] * a);
-        *(u32x2*)(ost + r31 * OROW + d0 * 2) = o2;
-      }
-  }
-  __syncthreads();
-  if (active) {
-    for (int it = lane; it < 32 * 10; it += 64) {
-      const int row = (it * 6554) >> 16, c = it - row * 10;
-      const int q = wq0 + row;
-      if (q < q0 + qn) {
-        const u32x4 o = *(const u32x4*)(ost + row * OROW + c * 16);
-        *(u32x4*)(p.O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// K6 (r03), the form the ViT runs on: the same arithmetic as attn_vit32_kernel - bit for bit: same fragments, same
-// accumulation order over absolute 64-key tiles - as a THREE-STAGE PIPELINE inside one 12-wave workgroup.
-//
-// attn_vit32_kernel leaves the matrix pipe ~35 % busy: a wave's tile is QK^T (10 MFMAs) -> softmax (~100 dependent VALU
-// instructions, 34 of them v_exp_f32) -> P*V (12 MFMAs), each phase waiting for the one before it, and the three waves a
-// SIMD hosts belong to three different workgroups whose barriers couple them to waves on OTHER SIMDs - nothing makes the
-// co-resident waves' phases complement each other.  Here a workgroup is 12 waves = three groups of four (one wave of
-// each group per SIMD), a wave again owns 32 query rows (384 rows per work item), and group g runs g phases behind
-// group g - 1: between two workgroup barriers every SIMD holds exactly one wave in QK^T, one in softmax and one in P*V
-// - matrix work (320 + 384 MFMA cycles) beside vector work by construction (MI355X_MICROARCH.md, "Two waves per SIMD",
-// taken to three).  One barrier per phase; every wave executes 3 nt + 2 of them.
-// K / V^T tiles: two LDS buffers.  Group 0 issues the LDS-DMA (three 1-KiB pieces per wave and tile half): K of tile
-// T + 1 at the start of its QK^T phase of tile T (that buffer's last reader, group 2's QK^T of tile T - 1, ended one
-// barrier earlier), V^T of tile T + 1 at the start of its P*V phase of tile T (last reader: group 2's P*V of tile
-// T - 1, one barrier earlier) - i.e. during its two MFMA phases, whose issue slots are free - and waits with COUNTED
-// vmcnt(3) (the three youngest pieces stay in flight across the barrier) before the barrier that precedes the first use.
-__device__ __forceinline__ void vit_phase_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__global__ __launch_bounds__(768, 1) void attn_vit32x3_kernel(AttnArgs p) {
-  constexpr int HD = 80, KS = HD / 16, NDB = 3;
-  constexpr int K_BYTES = 12288, V_BYTES = 12288, BUF = K_BYTES + V_BYTES;
-  constexpr int OROW = HD * 2 + 16;
-  __shared__ __attribute__((aligned(16))) char lds[12 * 32 * OROW > 2 * BUF ? 12 * 32 * OROW : 2 * BUF];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..11
-  const int grp = wave >> 2;                                      // pipeline stage offset
-  const int r31 = lane & 31, hh = lane >> 5;
-  const int head = blockIdx.x, hkv = head / p.group;
-  const int4 wk = p.work[blockIdx.y];
-  const int q0 = wk.x, qn = wk.y, k0 = wk.z, k1 = wk.w;
-  const int kt_begin = k0 & ~63;
-  const int nt = (k1 - kt_begin + 63) >> 6;
-  const int wq0 = q0 + wave * 32;
-  const bool active = wave * 32 < qn;
-
-  const bf16_t* Kh = p.K + (size_t)hkv * p.k_tokens * HD;
-  const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
-
-  if (tid < 256) {      // pad rows 80..95 of both V^T images: row 80 = 1.0, rows 81..95 = 0
-    const int b = tid >> 7, slot = tid & 127;
-    const uint32_t v = (slot < 8) ? 0x3f803f80u : 0u;
-    *(u32x4*)(lds + b * BUF + K_BYTES + 80 * 128 + slot * 16) = (u32x4){v, v, v, v};
-  }
-
-  bf16x8 qf[KS];
-  {
-    const int qrow = min(wq0 + r31, p.q_row0 + p.Sq - 1) - p.q_row0;
-    const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD + 8 * hh;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ks * 16));
-  }
-
-  // LDS-DMA (group 0 = threads 0..255 only): slot ps = i * 256 + tid for the two full pieces, 512 + 32 wave + lane
-  // (lanes 0..31) for the third - every wave of the group issues exactly three pieces per half tile, so one counted
-  // vmcnt serves all four
-  const int t256 = tid & 255;
-  uint32_t dk_off[3], dv_off[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int ps = (i < 2) ? i * 256 + t256 : 512 + 32 * (wave & 3) + (lane & 31);
-    const int row = (ps * 6554) >> 16;                  // ps / 10 for ps < 768
-    const int c = ps - row * 10;
-    dk_off[i] = (uint32_t)row * (HD * 2) + ((c ^ ((row >> 3) & 1)) << 4);
-    const int d = ps >> 3, cv = ps & 7;
-    dv_off[i] = (uint32_t)d * (uint32_t)(p.vt_ld * 2) + ((cv ^ ((d >> 1) & 7)) << 4);
-  }
-  auto piece = [&](const char* src, char* dst, int i) {
-    if (i < 2) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    } else if (lane < 32) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    }
-  };
-  auto load_k = [&](int kt, int buf) {
-    char* base = lds + buf * BUF;
-    if (kt + 64 <= p.k_tokens) {
-      const char* kbase = (const char*)Kh + (size_t)kt * (HD * 2);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        piece(kbase + dk_off[i], base + (i < 2 ? i * 4096 + (wave & 3) * 1024 : 8192 + (wave & 3) * 512), i);
-    } else {        // ragged last tile of a head: rows past k_tokens re-read the last key (masked in the softmax)
-      const char* kbase = (const char*)Kh;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int ps = (i < 2) ? i * 256 + t256 : 512 + 32 * (wave & 3) + (lane & 31);
-        const int row = (ps * 6554) >> 16;
-        const int c = ps - row * 10;
-        const int key = min(kt + row, p.k_tokens - 1);
-        const uint32_t off = (uint32_t)key * (HD * 2) + ((c ^ ((row >> 3) & 1)) << 4);
-        piece(kbase + off, base + (i < 2 ? i * 4096 + (wave & 3) * 1024 : 8192 + (wave & 3) * 512), i);
-      }
-    }
-  };
-  auto load_v = [&](int kt, int buf) {
-    char* base = lds + buf * BUF + K_BYTES;
-    const char* vbase = (const char*)(Vh + kt);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      piece(vbase + dv_off[i], base + (i < 2 ? i * 4096 + (wave & 3) * 1024 : 8192 + (wave & 3) * 512), i);
-  };
-
-  const int k_lane = r31 * (HD * 2) + ((hh ^ ((r31 >> 3) & 1)) << 4);
-  int v_lane[4];
-#pragma unroll
-  for (int c2 = 0; c2 < 4; ++c2) v_lane[c2] = K_BYTES + r31 * 128 + ((((2 * c2) | hh) ^ ((r31 >> 1) & 7)) << 4);
-
-  f32x16 oacc[NDB];
-#pragma unroll
-  for (int db = 0; db < NDB; ++db)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
-  float mrow = ATT_NEG;
-
-  if (grp == 0 && nt > 0) {
-    load_k(kt_begin, 0);
-    load_v(kt_begin, 0);
-  }
-  __syncthreads();                                   // (vmcnt(0) + barrier: tile 0 and the pad rows are in place)
-  for (int i = 0; i < grp; ++i) vit_phase_barrier(); // the stagger: group g starts g phases late
-
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int kt = kt_begin + t * 64;
-    const bool more = (t + 1 < nt);
-    const char* kb_ = lds + cur * BUF;
-    // ================= phase 0: S^T = K * Q^T
-    if (grp == 0 && more) load_k(kt + 64, cur ^ 1);
-    f32x16 sacc[2];
-    if (active) {
-      bf16x8 kf[2][KS];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) kf[kb][ks] = *(const bf16x8*)(kb_ + k_lane + kb * (32 * HD * 2) + ks * 32);
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], acc, 0, 0, 0);
-        sacc[kb] = acc;
-      }
-    }
-    vit_phase_barrier();
-    // ================= phase 1: online softmax (log2 domain); the other 32 keys of this query are on lane ^ 32
-    bf16x8 pf[2][2];
-    float alpha = 1.0f;
-    if (active) {
-      const bool need_mask = (kt < k0) || (kt + 64 > k1);
-      if (need_mask) {
-        const int kbase = kt + 4 * hh;
-        int lo = k0 - kbase, hi = k1 - kbase;
-        asm volatile("" : "+v"(lo), "+v"(hi));
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int e = 32 * kb + 8 * (i >> 2) + (i & 3);
-            sacc[kb][i] = ((lo <= e) && (hi > e)) ? sacc[kb][i] : ATT_NEG;
-          }
-      }
-      float mx = att_max3(sacc[0][0], sacc[0][1], sacc[0][2]);
-#pragma unroll
-      for (int i = 3; i < 15; i += 2) mx = att_max3(mx, sacc[0][i], sacc[0][i + 1]);
-      mx = att_max3(mx, sacc[0][15], sacc[1][0]);
-#pragma unroll
-      for (int i = 1; i < 15; i += 2) mx = att_max3(mx, sacc[1][i], sacc[1][i + 1]);
-      mx = att_max(mx, sacc[1][15]);
-      {
-        const uint32_t u = __float_as_uint(mx);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        mx = att_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      const float mnew = att_max(mrow, mx * p.scale_log2);
-      alpha = att_exp2(mrow - mnew);
-      mrow = mnew;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        float e[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = att_exp2(__builtin_fmaf(sacc[kb][i], p.scale_log2, -mnew));
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-          u32x4 pk;
-          pk[0] = pack2bf(e[4 * t2], e[4 * t2 + 1]);
-          pk[1] = pack2bf(e[4 * t2 + 2], e[4 * t2 + 3]);
-          pk[2] = pack2bf(e[4 * t2 + 8], e[4 * t2 + 9]);
-          pk[3] = pack2bf(e[4 * t2 + 10], e[4 * t2 + 11]);
-          pf[kb][t2] = __builtin_bit_cast(bf16x8, pk);
-        }
-      }
-      if (!__all(alpha == 1.0f)) {      // rescale O^T here, in the vector phase (the query is the lane)
-        float a = alpha;
-        asm volatile("" : "+v"(a));
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) oacc[db][i] *= a;
-      }
-    }
-    // V^T of this tile was issued one tile ago (prologue for tile 0); the only younger pieces are K of tile t + 1
-    if (grp == 0) {
-      if (more) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    vit_phase_barrier();
-    // ================= phase 2: O^T += V^T * P^T
-    if (grp == 0 && more) load_v(kt + 64, cur ^ 1);
-    if (active) {
-      bf16x8 vf[NDB][4];
-#pragma unroll
-      for (int db = 0; db < NDB; ++db)
-#pragma unroll
-        for (int c2 = 0; c2 < 4; ++c2) vf[db][c2] = *(const bf16x8*)(kb_ + v_lane[c2] + db * (32 * 128));
-#pragma unroll
-      for (int c2 = 0; c2 < 4; ++c2)
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][c2], pf[c2 >> 1][c2 & 1], oacc[db], 0, 0, 0);
-    }
-    // K of tile t + 1 (issued in phase 0) must have landed before the next barrier; V^T of tile t + 1 may stay in flight
-    if (grp == 0) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    vit_phase_barrier();
-    cur ^= 1;
-  }
-  for (int i = grp; i < 2; ++i) vit_phase_barrier();   // groups 0 / 1 wait for the later groups' last phases
-  __syncthreads();
-
-  // ---- normalise (denominator = O^T row 80 = register 8 of block 2 on the lower lane half), stage the wave's
-  //      32 x 80 tile in LDS, store whole 16-byte chunks
-  char* ost = lds + wave * 32 * OROW;
-  if (active) {
-    const uint32_t lu = __float_as_uint(oacc[2][8]);
-    const auto sw = __builtin_amdgcn_permlane32_swap(lu, lu, false, false);
-    const float l = __uint_as_float(sw[0]);
-    const float a = (l > 0.f) ? 1.0f / l : 0.f;
-#pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (db == 2 && g >= 2) break;
         const int d0 = 32 * db + 8 * g + 4 * hh;
         u32x2 o2;
         o2[0] = pack2bf(oacc[db][4 * g] * a, oacc[db][4 * g + 1] * a);
@@ -1214,27 +958,6 @@ extern "C" int vis_attn_prefill_pairs(const void* Q, const void* K, const void* 
   return vis_check_launch();
 }
 
-// The ViT form (head_dim 80, non-causal): work items of up to 384 query rows, one 12-wave workgroup each
-// (attn_vit32x3_kernel).  Same Q / K / V^T / O layouts and the same results, bit for bit, as vis_attn_prefill on the same
-// rows (the key-tile grid is absolute).  Meant for long segments (whole images); windows and other short items belong
-// to vis_attn_prefill, whose 4-wave workgroups pack three to a CU.
-extern "C" int vis_attn_prefill_vit(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
-                                    int Hq, int Hkv, int Sq, int k_tokens, int vt_ld, int ldo, float scale, int q_row0,
-                                    hipStream_t stream) {
-  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || q_row0 < 0) return VIS_ERR_ARG;
-  if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * 80 || n_work > 65535) return VIS_ERR_ARG;
-  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
-  AttnArgs p;
-  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
-  p.work = (const int4*)work;
-  p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
-  p.scale_log2 = scale * 1.4426950408889634f;
-  p.q_row0 = q_row0;
-  vis_clear_error();
-  hipLaunchKernelGGL(attn_vit32x3_kernel, dim3(Hq, n_work), dim3(768), 0, stream, p);
-  return vis_check_launch();
-}
-
 // vis_attn_prefill with a row offset: the work items' query rows (and the causal rule key <= query) are positions of
 // the whole sequence, while Q / O hold only rows q_row0 .. q_row0 + Sq - 1 (the prompt pass of a request whose first
 // q_row0 tokens were computed elsewhere: a text prefix shared by the images of a batch).
@@ -1273,6 +996,7 @@ extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* V
     else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, stream, p);
   } else {
     // non-causal head_dim 80 (the ViT): the 32x32x16 kernel; VIS_ATTN80=16 keeps the 16x16x32 kernel (A/B runs)
+    // non-causal head_dim 80 (the ViT towers): the 32x32x16 kernel; VIS_ATTN80=16 keeps the 16x16x32 kernel (A/B runs)
     static const bool wide = [] { const char* e = getenv("VIS_ATTN80"); return !(e && atoi(e) == 16); }();
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<80, true>), grid, block, pad_lds, stream, p);
     else if (wide) hipLaunchKernelGGL(attn_vit32_kernel, grid, block, 0, stream, p);

@@ -294,21 +294,11 @@ class Qwen2VLEngine:
         if cfg.vision_arch == "qwen2_5_vl":
             return self._vision_forward_windowed(x, grids, starts, counts, N, padded, cos, sin)
         segs = [(r0, r0 + c) for r0, c in zip(starts, counts)]
-        # whole images at head_dim 80: the 12-wave pipelined kernel (hip.attn_prefill_vit; results bit-identical to
-        # attn_prefill, VIS_ATTN_VIT=0 keeps the latter)
-        vit = D == 80 and hip.vit_attention_enabled()
-        work = self._vis_work_cache.get((vit,) + tuple(segs))
+        work = self._vis_work_cache.get(tuple(segs))
         if work is None:
             if len(self._vis_work_cache) >= 16:
                 self._vis_work_cache.clear()
-            work = self._vis_work_cache[(vit,) + tuple(segs)] = hip.make_vit_work(segs, dev) if vit else \
-                hip.make_attn_work(segs, False, dev, heads=Hh)
-
-        def attend():
-            if vit:
-                hip.attn_prefill_vit(q, k, vt, att, work, scale)
-            else:
-                hip.attn_prefill(q, k, vt, att, work, False, scale)
+            work = self._vis_work_cache[tuple(segs)] = hip.make_attn_work(segs, False, dev, heads=Hh)
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
@@ -328,7 +318,7 @@ class Qwen2VLEngine:
                 hip.quant_rows_fp8(x, xq, sx, norm_w=b.ln1_w, norm_b=b.ln1_b, eps=1e-6)
                 hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=b.qkv_b, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
-                attend()
+                hip.attn_prefill(q, k, vt, att, work, False, scale)
                 hip.quant_rows_fp8(att, xq, sx)
                 hip.gemm_fp8(xq, sx, *q8["proj_w"], bias=b.proj_b, residual=x, out=x)
                 hip.quant_rows_fp8(x, xq, sx, norm_w=b.ln2_w, norm_b=b.ln2_b, eps=1e-6)
@@ -348,7 +338,7 @@ class Qwen2VLEngine:
             for bi, b in enumerate(w.vit):
                 hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
-                attend()
+                hip.attn_prefill(q, k, vt, att, work, False, scale)
                 hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
                 hip.layernorm(x, b.ln2_w, b.ln2_b, 1e-6, out=y)
                 hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid)
@@ -380,8 +370,7 @@ class Qwen2VLEngine:
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
         E, Hh, D = cfg.v_embed, cfg.v_heads, cfg.v_head_dim
         m = cfg.merge ** 2
-        vit = D == 80 and hip.vit_attention_enabled()       # the full-attention blocks: 12-wave pipelined kernel
-        key = ("win", vit, tuple(grids))
+        key = ("win", tuple(grids))
         lay = self._vis_work_cache.get(key)
         if lay is None:
             row_idx = np.arange(N, dtype=np.int32)                 # pad rows (if any) stay where they are
@@ -404,8 +393,7 @@ class Qwen2VLEngine:
                 self._vis_work_cache.clear()
             lay = self._vis_work_cache[key] = (
                 torch.from_numpy(row_idx).to(dev), torch.from_numpy(rev).to(dev),
-                hip.make_attn_work(win_segs, False, dev, heads=Hh),
-                hip.make_vit_work(full_segs, dev) if vit else hip.make_attn_work(full_segs, False, dev, heads=Hh),
+                hip.make_attn_work(win_segs, False, dev, heads=Hh), hip.make_attn_work(full_segs, False, dev, heads=Hh),
                 torch.from_numpy(cp[row_idx]).to(dev), torch.from_numpy(sp[row_idx]).to(dev))
         row_idx, rev, work_win, work_full, cw, sw = lay
         xw = torch.empty_like(x)
@@ -427,10 +415,7 @@ class Qwen2VLEngine:
         for bi, b in enumerate(w.vit):
             hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
             hip.qkv_rope_split(qkv, cw, sw, q, k, None, vt, Hh, Hh, D)
-            if bi in cfg.v_fullatt and vit:
-                hip.attn_prefill_vit(q, k, vt, att, work_full, scale)
-            else:
-                hip.attn_prefill(q, k, vt, att, work_full if bi in cfg.v_fullatt else work_win, False, scale)
+            hip.attn_prefill(q, k, vt, att, work_full if bi in cfg.v_fullatt else work_win, False, scale)
             hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
             hip.rmsnorm(x, b.ln2_w, 1e-6, out=y)
             hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_SWIGLU, out=hmid)

@@ -34,7 +34,6 @@ _SIGS = {
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_attn_prefill_rows": "ppppp" + "iiiiiiiii" + "f" + "i" + "p",
     "vis_attn_prefill_pairs": "ppppp" + "iiiiiiii" + "f" + "i" + "p",
-    "vis_attn_prefill_vit": "ppppp" + "iiiiiii" + "f" + "i" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_gemv_fp8w": "ppppppp" + "iiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
@@ -386,45 +385,6 @@ def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.
     rc = load().vis_attn_prefill_rows(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
                                       S, T, vt.shape[2], out.stride(0), 1 if causal else 0, scale, int(q_row0), _stream())
     _check(rc, "vis_attn_prefill_rows")
-    return out
-
-
-VIT_BLOCK_Q = 384      # query rows per work item of attn_prefill_vit: 12 waves x 32 rows
-
-
-def vit_attention_enabled() -> bool:
-    """VIS_ATTN_VIT=0 keeps the 4-wave kernels of attn_prefill for the head_dim-80 towers (A/B runs; same results)."""
-    return os.environ.get("VIS_ATTN_VIT", "1") != "0"
-
-
-def make_vit_work(items_or_segments, device, segments: bool = True) -> torch.Tensor:
-    """Work list for attn_prefill_vit: every segment (start, end) cut into items of <= 384 query rows attending the
-    whole segment - or, with ``segments=False``, ready-made (q0, qn <= 384, k0, k1) items."""
-    if segments:
-        items = [(q0, min(VIT_BLOCK_Q, e - q0), s, e) for (s, e) in items_or_segments for q0 in range(s, e, VIT_BLOCK_Q)]
-    else:
-        items = list(items_or_segments)
-    if any(it[1] > VIT_BLOCK_Q or it[1] <= 0 for it in items):
-        raise HipLibraryError("make_vit_work: items must have 1..384 query rows")
-    return torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
-
-
-def attn_prefill_vit(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
-                     scale: float, q_row0: int = 0) -> torch.Tensor:
-    """Non-causal head_dim-80 prefill attention, the ViT form (12-wave workgroups, three-stage pipeline; work from
-    make_vit_work): same tensors and - bit for bit - the same results as attn_prefill(..., causal=False)."""
-    _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
-    Hq, S, HD = q.shape
-    Hkv, T, _ = k.shape
-    if not (q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()):
-        raise HipLibraryError("attn_prefill_vit: contiguous tensors required")
-    if HD != 80 or vt.shape[0] != Hkv or vt.shape[1] != HD or out.shape[0] != S or out.stride(1) != 1:
-        raise HipLibraryError("attn_prefill_vit: bad shapes (head_dim must be 80)")
-    if work.dtype != torch.int32 or work.dim() != 2 or work.shape[1] != 4 or not work.is_contiguous():
-        raise HipLibraryError("attn_prefill_vit: work must be int32 [n,4]")
-    rc = load().vis_attn_prefill_vit(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv,
-                                     S, T, vt.shape[2], out.stride(0), scale, int(q_row0), _stream())
-    _check(rc, "vis_attn_prefill_vit")
     return out
 
 

@@ -194,8 +194,7 @@ class MllamaEngine:
         x = torch.zeros((N, E), dtype=bf, device=dev)                      # pad rows start as exact zeros
         hip.gemm(patches, w.patch_w, residual=w.cls_pos[ar_id].view(TP, E), out=x[:TP])
         hip.layernorm(x[:TP], w.ln_pre_w, w.ln_pre_b, 1e-5, out=x[:TP])
-        vit = D == 80 and hip.vit_attention_enabled()      # 12-wave pipelined kernel (bit-identical results)
-        work = self._vision_work(nR, N, hip.VIT_BLOCK_Q if vit else 128)
+        work = self._vision_work(nR, N)
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
@@ -211,10 +210,7 @@ class MllamaEngine:
             hip.layernorm(x, b.ln1_w, b.ln1_b, cfg.v_eps, out=y)
             hip.gemm(y, b.qkv_w, out=qkv)
             hip.qkv_rope_split(qkv, None, None, q, k, None, vt, Hh, Hh, D)
-            if vit:
-                hip.attn_prefill_vit(q, k, vt, att, work, scale)
-            else:
-                hip.attn_prefill(q, k, vt, att, work, False, scale)
+            hip.attn_prefill(q, k, vt, att, work, False, scale)
             hip.gemm(att, b.o_w, residual=x, out=x)
             hip.layernorm(x, b.ln2_w, b.ln2_b, cfg.v_eps, out=y)
             hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_GELU_ERF, out=hmid)
