@@ -132,3 +132,60 @@ def dequantised_sd(cfg, sd):
         for n in ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"):
             dsd[p + n] = dq(sd[p + n])
     return dsd
+
+
+# ----------------------------------------------------------------------------- real model directories
+HF_DIRS = os.path.join(GOLDEN, "hf_dirs")
+
+
+def materialize_hf_dir(family: str, dst) -> str:
+    """Complete local HuggingFace model directory for ``family`` (qwen2vl_tiny / qwen25vl_tiny / mllama_tiny) under ``dst``:
+    the committed files transformers 5.15 wrote (tests/golden/gen_hf_dir.py: config.json, generation_config.json,
+    preprocessor_config.json, tokenizer.json, ...) plus model.safetensors REBUILT here from the seeded synth_state_dict under
+    exactly the tensor names, shapes and dtype save_pretrained used (manifest.json) - the 26 MB file is not committed."""
+    import json
+    import shutil
+    from safetensors.torch import save_file
+    src = os.path.join(HF_DIRS, family)
+    dst = str(dst)
+    os.makedirs(dst, exist_ok=True)
+    for f in os.listdir(src):
+        if f not in ("manifest.json", "expected.npz"):
+            shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+    with open(os.path.join(src, "manifest.json")) as f:
+        manifest = json.load(f)
+    if family == "mllama_tiny":
+        from vision_inspection_system_amd.mllama_weights import MllamaConfig, synth_state_dict
+        sd = synth_state_dict(MllamaConfig.tiny(), seed=0)
+
+        def synth_name(k):       # the names save_pretrained writes (old checkpoint layout) -> the module names synth uses
+            if k == "language_model.lm_head.weight":
+                return "lm_head.weight"
+            if k.startswith("language_model.model."):
+                return "model.language_model." + k[len("language_model.model."):]
+            return "model." + k
+    else:
+        from vision_inspection_system_amd.config import Qwen2VLConfig
+        from vision_inspection_system_amd.weights import synth_state_dict
+        cfg = Qwen2VLConfig.tiny() if family == "qwen2vl_tiny" else Qwen2VLConfig.tiny_2_5()
+        sd = synth_state_dict(cfg, seed=0)
+
+        def synth_name(k):
+            return k
+    out, used = {}, set()
+    for k, meta in manifest.items():
+        s = synth_name(k)
+        if s not in sd:
+            raise KeyError(f"{family}: save_pretrained wrote {k!r}; no synthetic tensor {s!r}")
+        t = sd[s].reshape(meta["shape"]).to(getattr(torch, meta["dtype"])).contiguous()
+        out[k] = t
+        used.add(s)
+    unused = [k for k in sd if k not in used]
+    if unused:
+        raise KeyError(f"{family}: synthetic tensors never written by save_pretrained: {unused[:4]}")
+    save_file(out, os.path.join(dst, "model.safetensors"), metadata={"format": "pt"})
+    return dst
+
+
+def hf_expected(family: str):
+    return np.load(os.path.join(HF_DIRS, family, "expected.npz"))

@@ -45,6 +45,9 @@ class Qwen2VLConfig:
     merge: int = 2
     min_pixels: int = 56 * 56
     max_pixels: int = 28 * 28 * 1280
+    # normalisation constants of the image processor (CLIP's; a checkpoint's preprocessor_config.json may override them)
+    image_mean: Tuple[float, float, float] = (0.48145466, 0.4578275, 0.40821073)
+    image_std: Tuple[float, float, float] = (0.26862954, 0.26130258, 0.27577711)
     # vision tower family: "qwen2_vl" (LayerNorm, fc1/QuickGELU/fc2, full attention per image) or "qwen2_5_vl" (the
     # reference's code default, utils/config.py:42-45: RMSNorm, SwiGLU MLP with biases of width v_mlp, attention inside
     # v_window-pixel windows except in the v_fullatt blocks; TF:models/qwen2_5_vl/modeling_qwen2_5_vl.py:294-472)
@@ -143,10 +146,47 @@ class Qwen2VLConfig:
         else:
             vis_extra = dict(v_mlp=int(v.get("embed_dim", 1280) * v.get("mlp_ratio", 4)))
         rope = t.get("rope_scaling") or t.get("rope_parameters") or c.get("rope_scaling") or {}
-        eos = c.get("eos_token_id", t.get("eos_token_id", 151645))
-        eos_ids = tuple(eos) if isinstance(eos, (list, tuple)) else (int(eos),)
+        # end-of-sequence ids: config.json (top level or text_config; either may be null), then generation_config.json
+        eos = c.get("eos_token_id")
+        if eos is None:
+            eos = t.get("eos_token_id")
+        gen_path = os.path.join(path, "generation_config.json")
+        if os.path.exists(gen_path):
+            with open(gen_path) as f:
+                g_eos = json.load(f).get("eos_token_id")
+            if g_eos is not None:
+                as_list = lambda e: list(e) if isinstance(e, (list, tuple)) else [int(e)]      # noqa: E731
+                eos = as_list(g_eos) + [e for e in (as_list(eos) if eos is not None else []) if e not in as_list(g_eos)]
+        if eos is None:
+            eos = 151645
+        eos_ids = tuple(int(e) for e in eos) if isinstance(eos, (list, tuple)) else (int(eos),)
         if 151643 not in eos_ids and t.get("vocab_size", 0) > 151643:
             eos_ids = eos_ids + (151643,)
+        # preprocessor_config.json (the checkpoint's image processor): pixel bounds of smart_resize and the normalisation
+        # constants.  Both spellings occur: min_pixels / max_pixels, and size = {shortest_edge, longest_edge}
+        # (TF:models/qwen2_vl/image_processing_qwen2_vl.py).  A released checkpoint's bounds decide how many image tokens
+        # a frame becomes - reading them keeps that equal to what the published model runs.
+        pre = {}
+        pre_path = os.path.join(path, "preprocessor_config.json")
+        if os.path.exists(pre_path):
+            with open(pre_path) as f:
+                pre = json.load(f)
+        size = pre.get("size") or {}
+        pix = {}
+        mn = pre.get("min_pixels", size.get("shortest_edge"))
+        mx = pre.get("max_pixels", size.get("longest_edge"))
+        if mn is not None:
+            pix["min_pixels"] = int(mn)
+        if mx is not None:
+            pix["max_pixels"] = int(mx)
+        if pre.get("image_mean") is not None:
+            pix["image_mean"] = tuple(float(x) for x in pre["image_mean"])
+        if pre.get("image_std") is not None:
+            pix["image_std"] = tuple(float(x) for x in pre["image_std"])
+        for key, mine in (("patch_size", v.get("patch_size", 14)), ("merge_size", v.get("spatial_merge_size", 2)),
+                          ("temporal_patch_size", v.get("temporal_patch_size", 2))):
+            if pre.get(key) is not None and int(pre[key]) != int(mine):
+                raise ValueError(f"{pre_path}: {key} = {pre[key]} contradicts config.json ({mine})")
         return cls(
             name=os.path.basename(os.path.normpath(path)),
             hidden=t["hidden_size"], layers=t["num_hidden_layers"], heads=t["num_attention_heads"],
@@ -157,7 +197,7 @@ class Qwen2VLConfig:
             patch=v.get("patch_size", 14), **vis_extra,
             temporal=v.get("temporal_patch_size", 2), merge=v.get("spatial_merge_size", 2),
             image_token_id=c.get("image_token_id", 151655), vision_start_id=c.get("vision_start_token_id", 151652),
-            vision_end_id=c.get("vision_end_token_id", 151653), eos_ids=eos_ids)
+            vision_end_id=c.get("vision_end_token_id", 151653), eos_ids=eos_ids, **pix)
 
 
 # ----------------------------------------------------------------------------- B4: reference Config surface

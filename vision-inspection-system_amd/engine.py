@@ -26,7 +26,6 @@ import torch
 
 from . import hip
 from .config import Qwen2VLConfig
-from .image_processing import CLIP_MEAN, CLIP_STD
 from .weights import DeviceWeights, PATCH_K_PAD
 
 
@@ -275,7 +274,7 @@ class Qwen2VLEngine:
         kp = w.patch_w.shape[1]
         patches = (torch.zeros if padded else torch.empty)((N, kp), dtype=bf, device=dev)
         for f, r0 in zip(frames, starts):
-            hip.patchify(f, patches, r0, CLIP_MEAN, CLIP_STD)
+            hip.patchify(f, patches, r0, cfg.image_mean, cfg.image_std)
         x = hip.gemm(patches, w.patch_w)
         key = tuple(grids)
         if key not in self._vis_rope_cache:

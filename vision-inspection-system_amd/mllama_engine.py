@@ -31,7 +31,6 @@ import numpy as np
 import torch
 
 from . import hip
-from .image_processing import CLIP_MEAN, CLIP_STD
 from .mllama_weights import MllamaConfig, MllamaDeviceWeights
 
 
@@ -190,7 +189,7 @@ class MllamaEngine:
         npad = (8 - P % 8) % 8
         TP, N, nR = T * P, T * (P + npad), n_tiles * P
         patches = torch.zeros((TP, w.patch_w.shape[1]), dtype=bf, device=dev)
-        hip.patchify_tiles(frame, patches, th, tw, cfg.image_size, CLIP_MEAN, CLIP_STD)
+        hip.patchify_tiles(frame, patches, th, tw, cfg.image_size, cfg.image_mean, cfg.image_std)
         x = torch.zeros((N, E), dtype=bf, device=dev)                      # pad rows start as exact zeros
         hip.gemm(patches, w.patch_w, residual=w.cls_pos[ar_id].view(TP, E), out=x[:TP])
         hip.layernorm(x[:TP], w.ln_pre_w, w.ln_pre_b, 1e-5, out=x[:TP])

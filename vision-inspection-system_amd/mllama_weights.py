@@ -56,6 +56,8 @@ class MllamaConfig:
     image_size: int = 560
     patch: int = 14
     max_tiles: int = 4
+    image_mean: Tuple[float, float, float] = (0.48145466, 0.4578275, 0.40821073)
+    image_std: Tuple[float, float, float] = (0.26862954, 0.26130258, 0.27577711)
     name: str = "llama-3.2-11b-vision"
 
     @property
@@ -345,7 +347,30 @@ def config_from_hf_dir(path: str) -> MllamaConfig:
         raise ValueError(f"{path}: not an mllama checkpoint (model_type={c.get('model_type')!r})")
     t, v = c["text_config"], c["vision_config"]
     rope = t.get("rope_scaling") or t.get("rope_parameters") or {}
-    eos = t.get("eos_token_id", c.get("eos_token_id", [128001, 128008, 128009]))
+    eos = t.get("eos_token_id")
+    if eos is None:
+        eos = c.get("eos_token_id")
+    gen_path = os.path.join(path, "generation_config.json")
+    if eos is None and os.path.exists(gen_path):
+        with open(gen_path) as f:
+            eos = json.load(f).get("eos_token_id")
+    if eos is None:
+        eos = [128001, 128008, 128009]
+    # preprocessor_config.json: the tile geometry must be the one the vision tower was built for
+    pre, extra = {}, {}
+    pre_path = os.path.join(path, "preprocessor_config.json")
+    if os.path.exists(pre_path):
+        with open(pre_path) as f:
+            pre = json.load(f)
+    size = pre.get("size") or {}
+    if size.get("height") is not None and (int(size["height"]) != int(v["image_size"]) or int(size.get("width", size["height"])) != int(v["image_size"])):
+        raise ValueError(f"{pre_path}: tile size {size} contradicts config.json image_size {v['image_size']}")
+    if pre.get("max_image_tiles") is not None and int(pre["max_image_tiles"]) != int(v["max_num_tiles"]):
+        raise ValueError(f"{pre_path}: max_image_tiles {pre['max_image_tiles']} contradicts config.json ({v['max_num_tiles']})")
+    if pre.get("image_mean") is not None:
+        extra["image_mean"] = tuple(float(x) for x in pre["image_mean"])
+    if pre.get("image_std") is not None:
+        extra["image_std"] = tuple(float(x) for x in pre["image_std"])
     return MllamaConfig(
         hidden=t["hidden_size"], layers=t["num_hidden_layers"], heads=t["num_attention_heads"],
         kv_heads=t["num_key_value_heads"], intermediate=t["intermediate_size"], vocab=t["vocab_size"],
@@ -358,7 +383,7 @@ def config_from_hf_dir(path: str) -> MllamaConfig:
         v_hidden=v["hidden_size"], v_heads=v["attention_heads"], v_layers=v["num_hidden_layers"],
         v_global_layers=v["num_global_layers"], v_mlp=v["intermediate_size"],
         v_inter=tuple(v["intermediate_layers_indices"]), v_eps=v.get("norm_eps", 1e-5), image_size=v["image_size"],
-        patch=v["patch_size"], max_tiles=v["max_num_tiles"], name=os.path.basename(os.path.normpath(path)))
+        patch=v["patch_size"], max_tiles=v["max_num_tiles"], name=os.path.basename(os.path.normpath(path)), **extra)
 
 
 def load_safetensors_dir(cfg: MllamaConfig, path: str, device) -> MllamaDeviceWeights:
