@@ -493,6 +493,116 @@ def run_dry(args, rank: int, world: int) -> None:
         dist.destroy_process_group()
 
 
+def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
+    """BASELINE configs[3] as a workload: the unit is the reference's batch call,
+    run_multi_image_inspection (src/orchestration/graph.py:269-387; README run_batch_inspection), on ``--images`` PNG files.
+    Rank 0 writes the files, the directory is agreed through the rendezvous store, every rank calls run_batch_inspection
+    on the FULL list (rank r inspects paths[r::W]; the records move with ONE all_gather pair) - so the time of the call,
+    max over ranks, is the strong-scaling time of the batch.  Each rank runs the whole seam: a3 encode on its ingest pool
+    (VIS_INGEST_THREADS sized from the host cores per rank), data-URI decode, engine, parse, consensus, gates.
+    ``--dry-device cpu``: both agents on the canned-response client (no model, no GPU): launcher, file agreement,
+    sharding, gather and timing only - the CPU rehearsal used by tests/test_bench_launcher.py."""
+    import tempfile
+    import torch.distributed as dist
+    from PIL import Image
+    dry = args.dry_device == "cpu"
+    if not dry:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
+        if args.share_gpu:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+    if world > 1:
+        from datetime import timedelta
+        if dry or args.share_gpu:
+            dist.init_process_group("gloo", timeout=timedelta(seconds=900))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), timeout=timedelta(seconds=900))
+    from vision_inspection_system_amd import client as CL, config as C
+    from vision_inspection_system_amd.batch import agree_on, gather_records, run_batch_inspection
+    from vision_inspection_system_amd.image_processing import clear_encode_cache
+    cores = os.cpu_count() or world
+    os.environ.setdefault("VIS_INGEST_THREADS", str(max(1, min(8, cores // world - 1))))
+    os.environ["VIS_IGNORE_EOS"] = "1"
+    reply = ('{"object_identified": "part", "overall_condition": "good", "defects": [], "overall_confidence": "high", '
+             '"analysis_reasoning": "no visible damage"}')
+    os.environ["VIS_SYNTHETIC_REPLY"] = reply           # random weights answer noise: keep the agents on the success path
+    CL.set_mock_reply(reply)
+    model_id = {"7b": "synthetic:7b", "7b25": "synthetic:qwen2.5-vl-7b", "tiny": "synthetic:tiny"}[args.model]
+    new = args.new_tokens if args.model != "tiny" else min(args.new_tokens, 24)
+    local_aud = args.auditor == "mllama" and not dry
+    C.set_config(C.Config(
+        vlm_inspector_provider="mock" if dry else "mi355x", vlm_inspector_model=model_id, vlm_inspector_max_tokens=new,
+        vlm_inspector_temperature=0.0, vlm_auditor_provider="mi355x" if local_aud else "mock",
+        vlm_auditor_model=("synthetic:mllama-11b" if args.model != "tiny" else "synthetic:mllama-tiny") if local_aud else "mock",
+        vlm_auditor_max_tokens=new, vlm_auditor_temperature=0.0, max_image_dimension=2048))
+    size = args.image_size if args.model != "tiny" else min(args.image_size, 128)
+    tmp = None
+    if rank == 0:
+        tmp = tempfile.mkdtemp(prefix="vis_batch256_")
+        for i in range(args.images):
+            rng = np.random.default_rng(1234 + i)
+            Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(
+                os.path.join(tmp, f"frame{i:04d}.png"), compress_level=1)
+    d = agree_on(tmp or "", "batch256_dir")             # written before it is published: the files are complete
+    paths = [os.path.join(d, f"frame{i:04d}.png") for i in range(args.images)]
+    try:
+        run_batch_inspection(paths[:max(2 * world, min(4 * world, args.images))], "medium", "general")   # models, graphs, pools
+        clear_encode_cache()
+        CL.TIMING_LOG.clear()
+        if world > 1:
+            dist.barrier()
+        if not dry:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run_batch_inspection(paths, "medium", "general")
+        if not dry:
+            torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64,
+                             device="cpu" if (dry or args.share_gpu) else torch.device("cuda", local_rank))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        dev_ms = sum(x.get("prefill_ms", 0.0) + x.get("decode_ms", 0.0) for x in CL.TIMING_LOG)
+        per_rank = gather_records([{"rank": rank, "call_s": mine, "images": len(range(rank, args.images, world)),
+                                    "engine_device_s": dev_ms * 1e-3, "engine_share_of_call": dev_ms * 1e-3 / max(mine, 1e-9),
+                                    "groups": len(CL.TIMING_LOG)}], world)
+        if rank == 0:
+            done = out["session_results"]["completed_images"]
+            if len(out["image_results"]) != args.images:
+                raise SystemExit(f"bench.py: {len(out['image_results'])} image results, expected {args.images}")
+            print(json.dumps({
+                "metric": "inspected images/sec (1024x1024, Qwen2-VL-7B), run_batch_inspection over the whole seam"
+                if args.model == "7b" and not dry else "images/sec (rehearsal)",
+                "value": args.images / elapsed, "unit": "images/s", "n_gpus": world, "steps": 1, "warmup": 1,
+                "ms_per_step": elapsed * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "none" if dry else "bf16", "data": "synthetic", "dry": dry,
+                "config": {"workload": f"configs[3]: run_batch_inspection, {args.images} x {size}x{size} PNG files sharded "
+                                       f"paths[r::{world}] over {world} rank(s), one gather of the records; Inspector "
+                                       f"{'canned (no model)' if dry else model_id}, Auditor {args.auditor if not dry else 'canned'}",
+                           "images": args.images, "completed": done, "new_tokens": new,
+                           "ingest_threads_per_rank": int(os.environ["VIS_INGEST_THREADS"]), "host_cpus": cores,
+                           "parallelism": f"dp{world} (whole images)" if not args.share_gpu else
+                           f"REHEARSAL: {world} ranks sharing ONE GPU, records over gloo - not a scaling measurement"},
+                "per_rank": sorted(per_rank, key=lambda r: r["rank"]),
+                "note": "engine_share_of_call = device time of the rank's prompt passes + decode loops / its wall time of "
+                        "the call: what is left is ingest (a3 encode / decode) the pool did not hide, host launch work "
+                        "and the gather"}), flush=True)
+    finally:
+        if world > 1:
+            dist.barrier()
+        if rank == 0 and tmp:
+            import shutil
+            shutil.rmtree(tmp, ignore_errors=True)
+        CL.set_mock_reply(None)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -526,6 +636,15 @@ def main():
     ap.add_argument("--prompt-order", default="image-first", choices=["image-first", "text-first"],
                     help="text-first: the reference's message order (text part, then image part); with --batch > 1 the "
                          "common text prefix is then computed once per batch")
+    ap.add_argument("--workload", default="step", choices=["step", "batch256"],
+                    help="batch256: BASELINE configs[3] as a workload - rank 0 writes --images seeded 1024x1024 PNG files, "
+                         "every rank calls run_batch_inspection on the FULL list (strong scaling: rank r inspects "
+                         "paths[r::W], whole seam per rank - a3 encode, JPEG decode, ingest pool, Inspector engine, parse, "
+                         "consensus, gates - and ONE gather of the records), timed across the call")
+    ap.add_argument("--images", type=int, default=256, help="--workload batch256: number of PNG files")
+    ap.add_argument("--auditor", default="mock", choices=["mock", "mllama"],
+                    help="--workload batch256: Auditor on the canned-response client (Inspector-only timing) or on the "
+                         "local Llama-3.2-11B-Vision engine (dual-VLM batch inspection)")
     ap.add_argument("--batch", type=int, default=1,
                     help="images per step per GPU; > 1 uses the batched decode path (BASELINE configs[3]/[4] style "
                          "batch inspection) - NOT the headline single-image configuration")
@@ -538,6 +657,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.workload == "batch256":
+        return run_batch256(args, rank, world, local_rank)
     if args.dry_device == "cpu":
         return run_dry(args, rank, world)
     if args.backend != "nccl" and not args.share_gpu:

@@ -49,3 +49,15 @@ def test_the_product_path_refuses_gloo_and_cpu():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--backend", "gloo", "--model", "tiny"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and "dry-device" in (r.stderr + r.stdout)
+
+
+def test_batch256_workload_three_ranks_on_cpu():
+    """`bench.py --gpus 3 --workload batch256` (BASELINE configs[3] as a workload), rehearsed with canned-response agents:
+    rank 0 writes the PNG files, the directory is agreed through the store, every rank calls run_batch_inspection on the
+    full list, rank r inspects paths[r::3], one gather, strong-scaling JSON line with a per-rank breakdown."""
+    r = _run(["--gpus", "3", "--workload", "batch256", "--images", "14"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["n_gpus"] == 3 and out["scaling"] == "strong" and out["dry"] is True and out["value"] > 0
+    assert out["config"]["images"] == 14 and out["config"]["completed"] == 14
+    assert [p["images"] for p in out["per_rank"]] == [5, 5, 4] and [p["rank"] for p in out["per_rank"]] == [0, 1, 2]

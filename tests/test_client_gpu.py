@@ -222,6 +222,24 @@ def test_bench_two_ranks_sharing_the_gpu_rehearsal():
     assert "REHEARSAL" in out["config"]["parallelism"]
 
 
+def test_bench_batch256_workload_two_ranks_sharing_the_gpu():
+    """`bench.py --gpus 2 --share-gpu --workload batch256` (BASELINE configs[3] as a workload) on tiny weights: rank 0 writes
+    the PNG files, both ranks run the whole seam (a3 encode, data-URI decode, engine, parse, consensus, gates) on
+    paths[r::2], one gather, strong-scaling JSON with the per-rank engine share."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--model", "tiny",
+                        "--workload", "batch256", "--images", "10", "--new-tokens", "8"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["dry"] is False
+    assert out["config"]["completed"] == 10 and [p["images"] for p in out["per_rank"]] == [5, 5]
+    assert all(p["engine_device_s"] > 0 and p["groups"] >= 1 for p in out["per_rank"])
+    assert "REHEARSAL" in out["config"]["parallelism"]
+
+
 def test_rccl_backend_single_rank_exchange(device):
     """The record exchange on the REAL backend (nccl = RCCL), world size 1 - the most a one-GPU box can run of it: communicator
     init, the store vote, the length + padded-bytes all_gather on device tensors, barrier, MAX all_reduce (bench.py's timing

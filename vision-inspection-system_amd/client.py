@@ -61,6 +61,10 @@ class _Chat:
         self.completions = _Completions(owner)
 
 
+# device time of every generate_batch group served in this process (extension; bench.py --workload batch256 reads and
+# clears it): [{"model", "prefill_ms", "decode_ms", "decode_steps", "sequences", "prompt_tokens"}]
+TIMING_LOG: List[dict] = []
+
 # ----------------------------------------------------------------------------- engine registry
 _ENGINES: Dict[Tuple[str, str], Any] = {}
 _ENGINES_LOCK = threading.Lock()
@@ -334,6 +338,8 @@ class LocalVLMClient:
                                           ignore_eos=os.environ.get("VIS_IGNORE_EOS") == "1")
                 timing = dict(getattr(eng, "last_timing", {}))
                 if timing:
+                    TIMING_LOG.append({"model": model_id, **timing})
+                    del TIMING_LOG[:-4096]
                     logger.debug("%s: %d request(s): prompt pass %.1f ms, %d decode steps in %.1f ms (device time)", model_id,
                                  len(idx), timing["prefill_ms"], timing["decode_steps"], timing["decode_ms"])
                 for j, t in zip(idx, toks):
@@ -402,6 +408,9 @@ class LocalVLMClient:
                     idx = range(g0, min(len(futs), g0 + eng.max_batch))
                     outs = eng.generate_batch([resolver(j) for j in idx], max_new_tokens=max_new, temperature=temp,
                                               seed=self.seed, stop_on_eos=not ignore_eos)
+                    if getattr(eng, "last_timing", None):
+                        TIMING_LOG.append({"model": lm.model_id, **eng.last_timing})
+                        del TIMING_LOG[:-4096]
                     out.extend(t if isinstance(t, Exception) else completion(n_ids[j], t) for j, t in zip(idx, outs))
             return out
         prepared = [f.result() for f in futs]
