@@ -529,6 +529,7 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
     os.environ["VIS_SYNTHETIC_REPLY"] = reply           # random weights answer noise: keep the agents on the success path
     CL.set_mock_reply(reply)
     model_id = {"7b": "synthetic:7b", "7b25": "synthetic:qwen2.5-vl-7b", "tiny": "synthetic:tiny"}[args.model]
+    os.environ.setdefault("VIS_TINY_MAX_CTX", "4096")   # the tiny model's byte tokenizer spends one token per prompt character
     new = args.new_tokens if args.model != "tiny" else min(args.new_tokens, 24)
     local_aud = args.auditor == "mllama" and not dry
     C.set_config(C.Config(

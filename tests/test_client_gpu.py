@@ -236,7 +236,7 @@ def test_bench_batch256_workload_two_ranks_sharing_the_gpu():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["value"] > 0 and out["dry"] is False
     assert out["config"]["completed"] == 10 and [p["images"] for p in out["per_rank"]] == [5, 5]
-    assert all(p["engine_device_s"] > 0 and p["groups"] >= 1 for p in out["per_rank"])
+    assert all(p["engine_device_s"] > 0 and p["groups"] >= 1 for p in out["per_rank"]), out["per_rank"]
     assert "REHEARSAL" in out["config"]["parallelism"]
 
 

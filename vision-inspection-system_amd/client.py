@@ -119,14 +119,14 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
             if kind == "tiny":
                 cfg = Qwen2VLConfig.tiny()
                 w = W.pack_device_weights(cfg, W.synth_state_dict(cfg, seed), device)
-                max_ctx = min(max_ctx, 1024)
+                max_ctx = min(max_ctx, int(os.environ.get("VIS_TINY_MAX_CTX", "1024")))
             elif kind in ("7b", "qwen2-vl-7b"):
                 cfg = Qwen2VLConfig.qwen2_vl_7b()
                 w = W.random_device_weights(cfg, device, seed)
             elif kind in ("tiny25", "qwen2.5-vl-tiny"):
                 cfg = Qwen2VLConfig.tiny_2_5()
                 w = W.pack_device_weights(cfg, W.synth_state_dict(cfg, seed), device)
-                max_ctx = min(max_ctx, 1024)
+                max_ctx = min(max_ctx, int(os.environ.get("VIS_TINY_MAX_CTX", "1024")))
             elif kind in ("7b25", "qwen2.5-vl-7b"):
                 cfg = Qwen2VLConfig.qwen2_5_vl_7b()
                 w = W.random_device_weights(cfg, device, seed)
@@ -164,7 +164,7 @@ def _load_mllama(model_id: str, device, max_ctx: int, max_batch: int = 1) -> Opt
         if parts[1] == "mllama-tiny":
             cfg = MW.MllamaConfig.tiny()
             w = MW.pack_device_weights(cfg, MW.synth_state_dict(cfg, seed), device)
-            max_ctx = min(max_ctx, 1024)
+            max_ctx = min(max_ctx, int(os.environ.get("VIS_TINY_MAX_CTX", "1024")))
         elif parts[1] in ("mllama-11b", "mllama"):
             cfg = MW.MllamaConfig.mllama_11b()
             w = MW.random_device_weights(cfg, device, seed)
