@@ -622,6 +622,128 @@ class Qwen2VLEngine:
             if taps is not None and li == 0:
                 taps["layer0"] = x.clone()
 
+    def _prefill_group(self, items: Sequence[tuple], prefix: dict, temperature: float, seed: int,
+                       max_new_tokens: Optional[int]) -> None:
+        """The prompt pass of SEVERAL requests that share one text prefix and one prompt structure (the images of a batch
+        inspection: same template, same frame size) as ONE pass over their stacked suffix rows.
+
+        items: [(slot, input_ids, ids_dev or None, image_embeds)] - all prompts have the same length S and the image tokens
+        in the same places.  Per request n = S - P rows (7B bench prompt: 1289 = 5.04 row tiles of 256: a sixth of the LLM
+        GEMM tiles is padding, and the qkv / o projections fill 0.42 / 0.33 of a round of the chip); stacked, k requests
+        give k n rows (four: 20.1 tiles, 1.5 / 1.15 rounds).  Only the row-independent kernels see the stack - embedding
+        gather, projections, norms, finalisations; rope / KV write / attention run per request on its own rows, KV-cache
+        slot and V^T buffer.  Every row's arithmetic is what the single-request pass does (a projection's K order does
+        not depend on M, the down projection is two K-slices either way, key tiles are absolute), so tokens and logits
+        are bit-identical to it (tests/test_engine_gpu.py, test_fullsize_gpu.py)."""
+        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        self.temperature, self.seed = float(temperature), int(seed)
+        k = len(items)
+        S = len(items[0][1])
+        P = int(prefix["len"])
+        n = S - P
+        H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
+        L = len(w.llm)
+        ids0 = np.asarray(list(items[0][1]), dtype=np.int64)
+        is_img = ids0 == cfg.image_token_id
+        grids_n = int(is_img.sum())
+        n_dec = self.max_ctx - S if max_new_tokens is None else min(self.max_ctx - S, max_new_tokens + 1)
+        ld = _round_up(S, 64)
+        nq = (Hq + 2 * Hkv) * D
+        x = torch.empty((k * n, H), dtype=bf, device=dev)
+        tabs = None
+        for j, (slot, ids, ids_dev, img) in enumerate(items):
+            ids_np = np.asarray(list(ids), dtype=np.int64)
+            if len(ids_np) != S or not np.array_equal(ids_np == cfg.image_token_id, is_img) or \
+                    not np.array_equal(ids_np[:P], prefix["ids"]) or img.shape[0] != grids_n:
+                raise ValueError("_prefill_group: the prompts of a group must share length, image positions and prefix")
+            if ids_np.min() < 0 or ids_np.max() >= cfg.vocab:
+                raise ValueError("token id out of range")
+            if tabs is None:     # rope tables / scatter index: one structure for the whole group (cached per structure)
+                key = ("grp", S, n_dec, grids_n, bool(is_img[0]), np.flatnonzero(np.diff(is_img.view(np.int8))).tobytes())
+                tabs = self._rope_cache.get(key)
+                if tabs is None:
+                    raise ValueError("_prefill_group: rope tables missing (prefill_many prepares them)")
+            self.cos_b[slot][:S + n_dec].copy_(tabs[0], non_blocking=True)
+            self.sin_b[slot][:S + n_dec].copy_(tabs[1], non_blocking=True)
+            if ids_dev is None:
+                ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
+            xj = x[j * n:(j + 1) * n]
+            hip.gather_rows(w.embed, ids_dev[P:], xj)
+            hip.scatter_rows(img, tabs[2] - P, xj)
+            self.kcache_b[slot][:, :, :P].copy_(prefix["k"])
+            self.vcache_b[slot][:, :, :P].copy_(prefix["v"])
+        s0 = items[0][0]                      # every slot of the group now holds the same (contiguous) tables
+        cos, sin = self.cos_b[s0][P:S], self.sin_b[s0][P:S]
+        work = self._pairs_cache.get((P, S))
+        if work is None:
+            if len(self._pairs_cache) >= 64:
+                self._pairs_cache.clear()
+            work = self._pairs_cache[(P, S)] = hip.make_attn_pairs(P, S, dev)
+        y = torch.empty((k * n, H), dtype=bf, device=dev)
+        qkv = torch.empty((k * n, nq), dtype=bf, device=dev)
+        q = torch.empty((k, Hq, n, D), dtype=bf, device=dev)
+        vt_all = torch.empty((k, L, Hkv, D, ld), dtype=bf, device=dev)
+        for j in range(k):
+            vt_all[j][:, :, :, :P].copy_(prefix["vt"])
+        att = torch.empty((k * n, Hq * D), dtype=bf, device=dev)
+        act = torch.empty((k * n, cfg.intermediate), dtype=bf, device=dev)
+        scale = D ** -0.5
+        splitk_work = torch.empty(2 * k * n * H, dtype=torch.float32, device=dev) \
+            if (cfg.intermediate >= 8192 and H % 8 == 0) else None
+        hip.rmsnorm(x, w.llm[0].ln1_w, cfg.rms_eps, out=y)
+        for li, lw in enumerate(w.llm):
+            hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
+            for j, (slot, _, _, _) in enumerate(items):
+                rows = slice(j * n, (j + 1) * n)
+                kc, vc, vt = self.kcache_b[slot][li], self.vcache_b[slot][li], vt_all[j][li]
+                hip.qkv_rope_split(qkv[rows], cos, sin, q[j], kc, vc, vt, Hq, Hkv, D, k_pos0=P, vt_col0=P)
+                hip.attn_prefill_pairs(q[j], kc, vt, att[rows], work, scale, q_row0=P)
+            hip.gemm(att, lw.o_w, residual=x, out=x)
+            hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
+            hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
+            nxt = w.llm[li + 1].ln1_w if li + 1 < L else None
+            if splitk_work is not None:
+                hip.gemm_splitk_part(act, lw.down_w, splitk_work, 2)
+                hip.splitk_finalize_norm(splitk_work, 2, x, residual=x, norm_w=nxt, y_out=y if nxt is not None else None,
+                                         eps=cfg.rms_eps)
+            else:
+                hip.gemm(act, lw.down_w, residual=x, out=x)
+                if nxt is not None:
+                    hip.rmsnorm(x, nxt, cfg.rms_eps, out=y)
+        for j, (slot, _, _, _) in enumerate(items):
+            logits = self.logits_b[slot]
+            hip.gemv(x[(j + 1) * n - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+            self.step_b[slot:slot + 1].fill_(S - 1)
+            hip.argmax(logits, self.ws_val[256 * slot:256 * (slot + 1)], self.ws_idx[256 * slot:256 * (slot + 1)],
+                       self.tokens_b[slot], self.cur_b[slot:slot + 1], self.step_b[slot:slot + 1], self.temperature,
+                       self.seed + 0x9E3779B9 * slot)
+            self.slot_prompt_len[slot] = S
+            if slot == 0:
+                self.prompt_len = S
+                self._decoded = 0
+                self.decode_limit = S + n_dec
+
+    def _group_tables(self, ids: Sequence[int], n_img_tokens: int, max_new_tokens: Optional[int], frames) -> None:
+        """Rope tables + image-token scatter index of a prompt structure, under the key _prefill_group looks up."""
+        cfg, dev = self.cfg, self.device
+        ids_np = np.asarray(list(ids), dtype=np.int64)
+        S = len(ids_np)
+        is_img = ids_np == cfg.image_token_id
+        n_dec = self.max_ctx - S if max_new_tokens is None else min(self.max_ctx - S, max_new_tokens + 1)
+        key = ("grp", S, n_dec, n_img_tokens, bool(is_img[0]), np.flatnonzero(np.diff(is_img.view(np.int8))).tobytes())
+        if key in self._rope_cache:
+            return
+        grids = [(1, f.shape[0] // cfg.patch, f.shape[1] // cfg.patch) for f in frames]
+        pos3, next_pos = rope_index(cfg, ids_np, grids)
+        cos_np, sin_np = mrope_cos_sin(cfg, pos3)
+        dpos = np.broadcast_to((next_pos + np.arange(n_dec))[None, :], (3, n_dec))
+        dcos, dsin = mrope_cos_sin(cfg, dpos)
+        img_idx = np.nonzero(is_img)[0].astype(np.int32)
+        if len(self._rope_cache) >= 16:
+            self._rope_cache.pop(next(iter(self._rope_cache)))
+        self._rope_cache[key] = (torch.from_numpy(np.concatenate([cos_np, dcos])).to(dev),
+                                 torch.from_numpy(np.concatenate([sin_np, dsin])).to(dev), torch.from_numpy(img_idx).to(dev))
+
     def prefill_many(self, requests: Sequence, temperature: float = 0.0,
                      seed: int = 0, max_new_tokens: Optional[int] = None,
                      ids_dev: Optional[Sequence[torch.Tensor]] = None) -> Tuple[List[Optional[int]], List[Optional[Exception]]]:
@@ -700,9 +822,43 @@ class Qwen2VLEngine:
                     n = sum((f.shape[0] // cfg.patch) * (f.shape[1] // cfg.patch) // cfg.merge ** 2 for f in resolved[b][1])
                     embeds[b] = out[r0:r0 + n]
                     r0 += n
+            # Requests of the group that share the text prefix AND the prompt structure (the images of a batch inspection)
+            # run their suffix rows as ONE stacked pass (_prefill_group: full LLM GEMM tiles and rounds instead of
+            # 5.04-tile, 0.4-round grids per image); VIS_MERGE_PREFILL=0 keeps one pass per request (A/B, same results).
+            merged: List[int] = []
+            if shared is not None and self.prefill_dtype == "bf16" and os.environ.get("VIS_MERGE_PREFILL", "1") != "0":
+                cand = [b for b in grp_all if b in embeds and prefix_for(resolved[b][0]) is not None]
+                if len(cand) >= 2:
+                    first_ids = np.asarray(list(resolved[cand[0]][0]), dtype=np.int64)
+                    same = [b for b in cand if len(resolved[b][0]) == len(first_ids)
+                            and embeds[b].shape[0] == embeds[cand[0]].shape[0]
+                            and [f.shape for f in resolved[b][1]] == [f.shape for f in resolved[cand[0]][1]]
+                            and np.array_equal(np.asarray(list(resolved[b][0]), dtype=np.int64) == cfg.image_token_id,
+                                               first_ids == cfg.image_token_id)]
+                    if len(same) >= 2:
+                        merged = same
+            slot_of = {b: next_slot + i for i, b in enumerate(grp_all)}       # slots follow the request order
+            next_slot += len(grp_all)
+            if merged:
+                st = streams[(g0 // vb) % n_streams]         # consecutive groups alternate streams
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    items = []
+                    for b in merged:
+                        ids, frames = resolved[b]
+                        for f in frames:
+                            f.record_stream(st)
+                        embeds[b].record_stream(st)
+                        items.append((slot_of[b], ids, ids_dev[b] if ids_dev else None, embeds[b]))
+                        slots[b] = slot_of[b]
+                    self._group_tables(resolved[merged[0]][0], int(embeds[merged[0]].shape[0]), max_new_tokens,
+                                       resolved[merged[0]][1])
+                    self._prefill_group(items, shared, temperature, seed, max_new_tokens)
             for b in grp_all:
+                if b in merged:
+                    continue
                 ids, frames = resolved[b]
-                st = streams[next_slot % n_streams]
+                st = streams[slot_of[b] % n_streams]
                 st.wait_stream(cur)              # the frames' upload / resize and the group's ViT pass ran on `cur`
                 with torch.cuda.stream(st):
                     for f in frames:
@@ -710,10 +866,9 @@ class Qwen2VLEngine:
                     if b in embeds:
                         embeds[b].record_stream(st)
                     self.prefill(ids, frames, ids_dev=ids_dev[b] if ids_dev else None, temperature=temperature, seed=seed,
-                                 max_new_tokens=max_new_tokens, slot=next_slot, split_vit=False, image_embeds=embeds.get(b),
+                                 max_new_tokens=max_new_tokens, slot=slot_of[b], split_vit=False, image_embeds=embeds.get(b),
                                  prefix=prefix_for(ids))
-                slots[b] = next_slot
-                next_slot += 1
+                slots[b] = slot_of[b]
         for st in streams:
             cur.wait_stream(st)
         if shared is not None:
