@@ -45,8 +45,8 @@ def collect(prefix, want):
     return rows, dur
 print("# MFMA-busy / wait / cache counters per dispatch (rocprofv3 --pmc, separate passes; MI355X). tools/mfma_pmc.sh")
 for prefix, want, what in (("gemm", "gemm_bf16", "LLM gate/up GEMM 2249 x 37888 x 3584 (tools/gemm_bench.py)"),
-                           ("vit", "attn_prefill", "ViT attention 4900 x 16 heads x d80 (tools/attn_bench.py --which vit)"),
-                           ("llm", "attn_prefill", "LLM causal attention S=2249 28/4 heads d128, unpaired + paired kernels")):
+                           ("vit", "attn_", "ViT attention 4900 x 16 heads x d80 (tools/attn_bench.py --which vit): attn_vit32_kernel"),
+                           ("llm", "attn_", "LLM causal attention S=2249 28/4 heads d128, unpaired + paired kernels")):
     rows, dur = collect(prefix, want)
     print(f"\n## {what}")
     for k, cs in rows.items():

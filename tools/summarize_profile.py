@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--write")
     ap.add_argument("--bench-log")
     ap.add_argument("--out", default="profiles")
+    ap.add_argument("--traffic-kernel", default="gemv_bf16_kernel", help="kernel (name prefix) of the FETCH / WRITE passes")
+    ap.add_argument("--traffic-name", default="gemv", help="profiles/<round>_<name>_traffic.json")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     if a.stats:
@@ -56,16 +58,16 @@ def main():
     if a.fetch and a.write:
         def per_launch(d, name):
             vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(one(os.path.join(d, "**", "*_counter_collection.csv"))))
-                    if r["Counter_Name"] == name and r["Kernel_Name"].startswith("gemv_bf16_kernel")]
+                    if r["Counter_Name"] == name and a.traffic_kernel in r["Kernel_Name"]]
             return sum(vals) / len(vals), len(vals)
         fetch_kb, n1 = per_launch(a.fetch, "FETCH_SIZE")
         write_kb, n2 = per_launch(a.write, "WRITE_SIZE")
-        out = {"kernel": "gemv_bf16_kernel", "launches_sampled": [n1, n2], "FETCH_SIZE_KB_per_launch": fetch_kb,
+        out = {"kernel": a.traffic_kernel, "launches_sampled": [n1, n2], "FETCH_SIZE_KB_per_launch": fetch_kb,
                "WRITE_SIZE_KB_per_launch": write_kb,
                "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads -> x2 "
                              "(MI355X_MICROARCH.md, HBM); WRITE_SIZE taken as is",
                "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
-        with open(os.path.join(a.out, f"{a.round}_gemv_traffic.json"), "w") as f:
+        with open(os.path.join(a.out, f"{a.round}_{a.traffic_name}_traffic.json"), "w") as f:
             json.dump(out, f, indent=1)
     if a.bench_log:
         for line in open(a.bench_log):
