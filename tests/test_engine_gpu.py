@@ -262,7 +262,7 @@ def test_shared_text_prefix_is_bit_identical(device, monkeypatch, dtype):
     assert shared == plain
     assert torch.equal(logits_shared, eng.logits_b[:3])
     assert shared[0] == shared[2]
-    # requests 0 and 2 have one prompt structure: in the bf16 configuration their suffix rows ran as ONE stacked pass
+    # requests 0 and 2 have one prompt structure: their suffix rows ran as ONE stacked pass
     # (_prefill_group); forced apart (VIS_MERGE_PREFILL=0) the result is the same bit for bit - and so is a group of four
     monkeypatch.setenv("VIS_SHARE_PREFIX", "1")
     four = [(ids_for(frames[0], [7, 8, 9]), [frames[0]]), (ids_for(frames[0], [9, 9, 9]), [frames[0]]),
@@ -272,10 +272,10 @@ def test_shared_text_prefix_is_bit_identical(device, monkeypatch, dtype):
     monkeypatch.setattr(eng, "_prefill_group", lambda items, *a, **k: (calls.append(len(items)), real(items, *a, **k))[1])
     stacked = eng.generate_batch(four, max_new_tokens=8, ignore_eos=True)
     logits_stacked = eng.logits_b[:4].clone()
-    assert calls == ([4] if dtype == "bf16" else [])
+    assert calls == [4]
     monkeypatch.setenv("VIS_MERGE_PREFILL", "0")
     apart = eng.generate_batch(four, max_new_tokens=8, ignore_eos=True)
-    assert calls == ([4] if dtype == "bf16" else []) and stacked == apart and torch.equal(logits_stacked, eng.logits_b[:4])
+    assert calls == [4] and stacked == apart and torch.equal(logits_stacked, eng.logits_b[:4])
     assert stacked[0] == stacked[3] == shared[0]
     monkeypatch.delenv("VIS_MERGE_PREFILL")
     # prompts without a common text prefix, or with the image first, fall back to the plain pass

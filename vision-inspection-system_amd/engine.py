@@ -689,15 +689,40 @@ class Qwen2VLEngine:
         act = torch.empty((k * n, cfg.intermediate), dtype=bf, device=dev)
         scale = D ** -0.5
         splitk_work = torch.empty(2 * k * n * H, dtype=torch.float32, device=dev) \
-            if (cfg.intermediate >= 8192 and H % 8 == 0) else None
-        hip.rmsnorm(x, w.llm[0].ln1_w, cfg.rms_eps, out=y)
-        for li, lw in enumerate(w.llm):
-            hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
+            if (cfg.intermediate >= 8192 and H % 8 == 0 and self.prefill_dtype != "fp8") else None
+
+        def attend(li):        # rope / KV write / attention: per request, on its rows, cache slot and V^T buffer
             for j, (slot, _, _, _) in enumerate(items):
                 rows = slice(j * n, (j + 1) * n)
                 kc, vc, vt = self.kcache_b[slot][li], self.vcache_b[slot][li], vt_all[j][li]
                 hip.qkv_rope_split(qkv[rows], cos, sin, q[j], kc, vc, vt, Hq, Hkv, D, k_pos0=P, vt_col0=P)
                 hip.attn_prefill_pairs(q[j], kc, vt, att[rows], work, scale, q_row0=P)
+
+        if self.prefill_dtype == "fp8":
+            # configs[4]: every projection on the fp8 MFMA; the per-token activation quantiser is row-wise, so it stacks
+            # like the projections do (the layer body of _llm_layers_fp8 over k n rows)
+            M = k * n
+            xq = torch.empty((M, H), dtype=torch.uint8, device=dev)
+            aq = torch.empty((M, Hq * D), dtype=torch.uint8, device=dev)
+            hq = torch.zeros((M, self.kpad), dtype=torch.uint8, device=dev)
+            sx = torch.empty(M, dtype=torch.float32, device=dev)
+            dwork = torch.empty(2 * M * H, dtype=torch.float32, device=dev) if (self.kpad >= 8192 and H % 8 == 0) else None
+            for li, lw in enumerate(w.llm):
+                q8 = self.q8[li]
+                hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+                hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=lw.qkv_b, out=qkv)
+                attend(li)
+                hip.quant_rows_fp8(att, aq, sx)
+                hip.gemm_fp8(aq, sx, *q8["o_w"], residual=x, out=x)
+                hip.quant_rows_fp8(x, xq, sx, norm_w=lw.ln2_w, eps=cfg.rms_eps)
+                hip.gemm_fp8(xq, sx, *q8["gateup_w"], act=hip.ACT_SWIGLU, out=act)
+                hip.quant_rows_fp8(act, hq[:, :cfg.intermediate], sx)
+                hip.gemm_fp8(hq, sx, *q8.get("down_w_pad", q8["down_w"]), residual=x, out=x, work=dwork, ksplit=2)
+        else:
+            hip.rmsnorm(x, w.llm[0].ln1_w, cfg.rms_eps, out=y)
+        for li, lw in enumerate(w.llm if self.prefill_dtype != "fp8" else ()):
+            hip.gemm(y, lw.qkv_w, bias=lw.qkv_b, out=qkv)
+            attend(li)
             hip.gemm(att, lw.o_w, residual=x, out=x)
             hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
             hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
@@ -826,7 +851,7 @@ class Qwen2VLEngine:
             # run their suffix rows as ONE stacked pass (_prefill_group: full LLM GEMM tiles and rounds instead of
             # 5.04-tile, 0.4-round grids per image); VIS_MERGE_PREFILL=0 keeps one pass per request (A/B, same results).
             merged: List[int] = []
-            if shared is not None and self.prefill_dtype == "bf16" and os.environ.get("VIS_MERGE_PREFILL", "1") != "0":
+            if shared is not None and os.environ.get("VIS_MERGE_PREFILL", "1") != "0":
                 cand = [b for b in grp_all if b in embeds and prefix_for(resolved[b][0]) is not None]
                 if len(cand) >= 2:
                     first_ids = np.asarray(list(resolved[cand[0]][0]), dtype=np.int64)
