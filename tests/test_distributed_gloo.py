@@ -67,7 +67,7 @@ def _worker_failure(rank, world, port, paths, outdir, mode):
     """mode 'dead': the last rank exits before the exchange; 'late': it arrives after the others gave up."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      VIS_RANK_TIMEOUT_S="2")
+                      VIS_RANK_TIMEOUT_S="5")      # generous: a loaded CI host must not turn a live rank into a "dead" one
     import time
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -80,7 +80,7 @@ def _worker_failure(rank, world, port, paths, outdir, mode):
 
     def fake_inspect(image_path, criticality, domain, user_notes):
         if rank == world - 1 and mode == "late":
-            time.sleep(1.2)          # 3 images x 1.2 s > the 2 s the others wait
+            time.sleep(2.2)          # 3 images x 2.2 s > the 5 s the others wait
         return {"inspector_result": {"who": rank}, "auditor_result": {}, "safety_verdict": {"verdict": "SAFE"},
                 "consensus": {"combined_defects": []}, "processing_time": 0.01}
     t0 = time.monotonic()
@@ -108,7 +108,7 @@ def test_rank_failure_is_a_result_not_a_hang(tmp_path, mode):
     outs = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(world) if (tmp_path / f"rank{r}.json").exists()]
     assert len(outs) == (2 if mode == "dead" else 3)
     for o in outs[:2]:
-        assert o["_elapsed"] < 15
+        assert o["_elapsed"] < 45
         res = o["image_results"]
         assert [v["image_path"] for v in res.values()] == paths
         done = [v.get("completed") for v in res.values()]
