@@ -80,7 +80,7 @@ def _worker_failure(rank, world, port, paths, outdir, mode):
 
     def fake_inspect(image_path, criticality, domain, user_notes):
         if rank == world - 1 and mode == "late":
-            time.sleep(2.2)          # 3 images x 2.2 s > the 5 s the others wait
+            time.sleep(3.5)          # rank 2's two images x 3.5 s > the 5 s the others wait
         return {"inspector_result": {"who": rank}, "auditor_result": {}, "safety_verdict": {"verdict": "SAFE"},
                 "consensus": {"combined_defects": []}, "processing_time": 0.01}
     t0 = time.monotonic()
