@@ -522,7 +522,7 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
     from vision_inspection_system_amd.batch import agree_on, gather_records, run_batch_inspection
     from vision_inspection_system_amd.image_processing import clear_encode_cache
     cores = os.cpu_count() or world
-    os.environ.setdefault("VIS_INGEST_THREADS", str(max(1, min(8, cores // world - 1))))
+    os.environ.setdefault("VIS_INGEST_THREADS", str(max(1, min(4, cores // world - 1))))   # more threads only fight the launch thread for the GIL (8: -15 %)
     os.environ["VIS_IGNORE_EOS"] = "1"
     reply = ('{"object_identified": "part", "overall_condition": "good", "defects": [], "overall_confidence": "high", '
              '"analysis_reasoning": "no visible damage"}')

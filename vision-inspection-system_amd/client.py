@@ -241,7 +241,8 @@ def _frame_to_device(f, device):
     from . import jpeg
     if isinstance(f, jpeg.JpegCoeffs):
         return jpeg.to_rgb_device(f, device)
-    return torch.from_numpy(f).to(device)
+    from . import hip
+    return hip.upload(f, device)
 
 
 # ----------------------------------------------------------------------------- clients

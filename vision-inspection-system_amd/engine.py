@@ -484,7 +484,7 @@ class Qwen2VLEngine:
         if slot == 0:
             self.decode_limit = S + n_dec
         if ids_dev is None:
-            ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
+            ids_dev = hip.upload(ids_np.astype(np.int32), dev)
         H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
         L = len(w.llm)
         P = 0
@@ -666,7 +666,7 @@ class Qwen2VLEngine:
             self.cos_b[slot][:S + n_dec].copy_(tabs[0], non_blocking=True)
             self.sin_b[slot][:S + n_dec].copy_(tabs[1], non_blocking=True)
             if ids_dev is None:
-                ids_dev = torch.from_numpy(ids_np.astype(np.int32)).to(dev)
+                ids_dev = hip.upload(ids_np.astype(np.int32), dev)
             xj = x[j * n:(j + 1) * n]
             hip.gather_rows(w.embed, ids_dev[P:], xj)
             hip.scatter_rows(img, tabs[2] - P, xj)

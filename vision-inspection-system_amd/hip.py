@@ -58,6 +58,31 @@ _SIGS = {
 _CT = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float, "u": ctypes.c_uint, "l": ctypes.c_longlong}
 
 
+_UPLOAD_STREAMS: dict = {}
+
+
+def upload(arr, device) -> "torch.Tensor":
+    """Host array -> device tensor WITHOUT blocking the launching thread.
+
+    ``torch.from_numpy(a).to(device)`` copies from pageable memory: the call is synchronous AND stream-ordered, i.e. the
+    host sleeps until everything already queued on the current stream has run (cProfile of run_batch_inspection, r03: 192
+    such calls = 0.98 s of a 2.8 s batch - the launch thread could not run ahead of the GPU).  Here the array goes through
+    a pinned staging copy on a dedicated upload stream; the current stream is made to wait for it with an event, the host
+    is not.  PyTorch's pinned-memory allocator keeps the staging block alive until the copy has completed."""
+    import numpy as _np
+    dev = torch.device(device)
+    st = _UPLOAD_STREAMS.get(dev)
+    if st is None:
+        st = _UPLOAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    src = torch.from_numpy(_np.ascontiguousarray(arr)).pin_memory()
+    with torch.cuda.stream(st):
+        out = src.to(dev, non_blocking=True)
+    cur = torch.cuda.current_stream(dev)
+    cur.wait_stream(st)
+    out.record_stream(cur)
+    return out
+
+
 class HipLibraryError(RuntimeError):
     """The gfx950 extension is missing or an entry point rejected its arguments."""
 

@@ -112,6 +112,6 @@ def to_rgb_device(jc: JpegCoeffs, device):
     """H2D of the coefficients + the two HIP kernels -> uint8 [H, W, 3] on ``device`` (current stream)."""
     import torch
     from . import hip
-    coeffs = torch.from_numpy(jc.coeffs).to(device, non_blocking=True)
-    qt = torch.from_numpy(jc.qt.astype(np.int32)).to(device, non_blocking=True)
+    coeffs = hip.upload(jc.coeffs, device)                 # pinned staging on the upload stream: the host does not wait
+    qt = hip.upload(jc.qt.astype(np.int32), device)
     return hip.jpeg_to_rgb(coeffs, qt, jc)

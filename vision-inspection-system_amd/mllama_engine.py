@@ -223,7 +223,7 @@ class MllamaEngine:
                 j += 1
         hip.layernorm(x, w.ln_post_w, w.ln_post_b, 1e-5, out=x)
         tile_of = np.concatenate([np.repeat(np.arange(T), P), np.repeat(np.arange(T), npad)]).astype(np.int32)
-        idx = torch.from_numpy(ar_id * T + tile_of).to(dev)
+        idx = hip.upload(ar_id * T + tile_of, dev)
         hip.add_rows(x, w.post_tile.view(-1, E), idx)
         for b in w.v_global:
             layer(b)
@@ -273,7 +273,7 @@ class MllamaEngine:
             xvt = torch.empty((Hkv, D, self.Tk), dtype=bf, device=dev)
             q2 = torch.empty((S, Hq * D), dtype=bf, device=dev)
         x = torch.empty((S, H), dtype=bf, device=dev)
-        hip.gather_rows(w.embed, torch.from_numpy(ids_np.astype(np.int32)).to(dev), x)
+        hip.gather_rows(w.embed, hip.upload(ids_np.astype(np.int32), dev), x)
         cos, sin = self.cos_t[:S], self.sin_t[:S]
         work = hip.make_attn_pairs(0, S, dev)        # causal self-attention: paired query blocks (hip.attn_prefill_pairs)
         ld = _round_up(S, 64)
