@@ -548,7 +548,10 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
     d = agree_on(tmp or "", "batch256_dir")             # written before it is published: the files are complete
     paths = [os.path.join(d, f"frame{i:04d}.png") for i in range(args.images)]
     try:
-        run_batch_inspection(paths[:max(2 * world, min(4 * world, args.images))], "medium", "general")   # models, graphs, pools
+        # warm-up = one call of the same shape (models, pools, and the decode graph of the per-rank group size - a graph is
+        # captured per batch size, 0.4 s at 7B shapes); lists longer than one group per rank warm up on one group per rank
+        group = int(os.environ.get("VIS_MAX_BATCH", "64"))
+        run_batch_inspection(paths[:min(args.images, group * world)], "medium", "general")
         clear_encode_cache()
         CL.TIMING_LOG.clear()
         if world > 1:
