@@ -501,12 +501,26 @@ class MllamaEngine:
         B = 0
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         ev[0].record()
+        # The prompt passes are independent kernel chains (own buffers, own cache slot): issued round-robin on two HIP
+        # streams (VIS_PREFILL_STREAMS, as in Qwen2VLEngine.prefill_many) the ragged last round of one image's GEMM /
+        # attention grids - the 6432-row tower is 1-1.5 rounds of the chip per projection - is filled by the other's.
+        n_streams = max(1, min(n_req, int(os.environ.get("VIS_PREFILL_STREAMS", "2"))))
+        cur = torch.cuda.current_stream(self.device)
+        if n_streams > 1 and len(getattr(self, "_prefill_streams", [])) < n_streams:
+            self._prefill_streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
         for b, r in enumerate(requests):
             try:
                 ids, fr = r() if callable(r) else r
                 if fr is None:
                     raise ValueError("generate_batch needs an image in every request")
-                self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B)
+                if n_streams > 1:
+                    st = self._prefill_streams[B % n_streams]
+                    st.wait_stream(cur)          # the frame's upload / JPEG kernels ran on `cur`
+                    with torch.cuda.stream(st):
+                        fr.record_stream(st)
+                        self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B)
+                else:
+                    self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B)
             except Exception as e:      # noqa: BLE001 - a lazy request's failure stays its own
                 if not lazy:
                     raise
@@ -514,6 +528,9 @@ class MllamaEngine:
                 continue
             slots[b] = B
             B += 1
+        if n_streams > 1:
+            for st in self._prefill_streams[:n_streams]:
+                cur.wait_stream(st)
         ev[1].record()
         if B == 0:
             return list(errors)
