@@ -232,9 +232,82 @@ class MllamaEngine:
             taps["vision_features"] = feats
         return hip.gemm(feats, w.proj_w, bias=w.proj_b), n_tiles
 
+    def vision_forward_many(self, frames: Sequence[torch.Tensor]) -> List[Tuple[torch.Tensor, int]]:
+        """The tower over SEVERAL requests' images in one pass (the batch seam: verify_many).  One image is 6432 rows:
+        its projections are 1 - 2 rounds of the chip (qkv 390 tiles, fc1 520) and its attention list 816 workgroups for 768
+        slots - two rounds, the second 6 % full; four images stacked make whole rounds of all of them.  Every image
+        starts on a 64-row boundary (the attention kernel walks keys in absolute 64-row tiles), so its features - and with
+        them the whole answer - are bit-identical to the single-image pass
+        (test_batched_decode_matches_single_and_is_batch_invariant).  Row order inside an image as in vision_forward."""
+        k = len(frames)
+        if k == 1:
+            return [self.vision_forward(frames[0])]
+        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        T, P, E, Hh, D = cfg.max_tiles, cfg.tile_tokens, cfg.v_hidden, cfg.v_heads, cfg.v_head_dim
+        npad = (8 - P % 8) % 8
+        TP, N = T * P, T * (P + npad)
+        NS = _round_up(N, 64)                         # rows per image in the stack
+        x = torch.zeros((k * NS, E), dtype=bf, device=dev)
+        items, n_tiles_of = [], []
+        tile_of = np.concatenate([np.repeat(np.arange(T), P), np.repeat(np.arange(T), npad),
+                                  np.zeros(NS - N, dtype=np.int64)]).astype(np.int32)
+        idx_all = np.empty(k * NS, dtype=np.int32)
+        for i, frame in enumerate(frames):
+            fr, th, tw, ar_id = self.prepare_image(frame)
+            n_tiles = th * tw
+            n_tiles_of.append(n_tiles)
+            r0, nR = i * NS, n_tiles * P
+            patches = torch.zeros((TP, w.patch_w.shape[1]), dtype=bf, device=dev)
+            hip.patchify_tiles(fr, patches, th, tw, cfg.image_size, cfg.image_mean, cfg.image_std)
+            hip.gemm(patches, w.patch_w, residual=w.cls_pos[ar_id].view(TP, E), out=x[r0:r0 + TP])
+            hip.layernorm(x[r0:r0 + TP], w.ln_pre_w, w.ln_pre_b, 1e-5, out=x[r0:r0 + TP])
+            items += [(r0 + q0, min(128, nR - q0), r0, r0 + N) for q0 in range(0, nR, 128)]
+            items += [(r0 + q0, min(128, N - q0), r0, r0 + nR) for q0 in range(nR, N, 128)]
+            idx_all[r0:r0 + NS] = ar_id * T + tile_of
+        work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
+        M = k * NS
+        y = torch.empty((M, E), dtype=bf, device=dev)
+        qkv = torch.empty((M, 3 * E), dtype=bf, device=dev)
+        q = torch.empty((Hh, M, D), dtype=bf, device=dev)
+        kk = torch.empty((Hh, M, D), dtype=bf, device=dev)
+        vt = torch.empty((Hh, D, M), dtype=bf, device=dev)
+        att = torch.zeros((M, E), dtype=bf, device=dev)          # the NS - N tail rows of an image are never written
+        hmid = torch.empty((M, cfg.v_mlp), dtype=bf, device=dev)
+        feats = torch.empty((k, TP, cfg.v_out), dtype=bf, device=dev)
+        scale = D ** -0.5
+
+        def layer(b):
+            hip.layernorm(x, b.ln1_w, b.ln1_b, cfg.v_eps, out=y)
+            hip.gemm(y, b.qkv_w, out=qkv)
+            hip.qkv_rope_split(qkv, None, None, q, kk, None, vt, Hh, Hh, D)
+            hip.attn_prefill(q, kk, vt, att, work, False, scale)
+            hip.gemm(att, b.o_w, residual=x, out=x)
+            hip.layernorm(x, b.ln2_w, b.ln2_b, cfg.v_eps, out=y)
+            hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_GELU_ERF, out=hmid)
+            hip.gemm(hmid, b.fc2_w, bias=b.fc2_b, residual=x, out=x)
+
+        def take(col0):
+            for i in range(k):
+                feats[i][:, col0:col0 + E].copy_(x[i * NS:i * NS + TP])
+
+        j = 0
+        for li, b in enumerate(w.v_layers):
+            layer(b)
+            if li in cfg.v_inter:
+                take(E * (1 + j))
+                j += 1
+        hip.layernorm(x, w.ln_post_w, w.ln_post_b, 1e-5, out=x)
+        hip.add_rows(x, w.post_tile.view(-1, E), hip.upload(idx_all, dev))
+        for b in w.v_global:
+            layer(b)
+        take(0)
+        cross = hip.gemm(feats.view(k * TP, cfg.v_out), w.proj_w, bias=w.proj_b)
+        return [(cross[i * TP:(i + 1) * TP], n_tiles_of[i]) for i in range(k)]
+
     # ------------------------------------------------------------------ prefill
     def prefill(self, input_ids: Sequence[int], frame: Optional[torch.Tensor] = None, taps: Optional[dict] = None,
-                temperature: float = 0.0, seed: int = 0, slot: int = 0) -> None:
+                temperature: float = 0.0, seed: int = 0, slot: int = 0,
+                cross_states: Optional[Tuple[torch.Tensor, int]] = None) -> None:
         cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
         if not 0 <= slot < self.max_batch:
             raise ValueError("slot out of range")
@@ -261,7 +334,8 @@ class MllamaEngine:
         nm = int(locs[0]) if has_image else 0
         cross = None
         if has_image:
-            cross, n_tiles = self.vision_forward(frame, taps)
+            # cross_states: the tower's output for this frame computed elsewhere (generate_batch stacks several requests' images)
+            cross, n_tiles = cross_states if cross_states is not None else self.vision_forward(frame, taps)
             nR = n_tiles * P
             nkeys_m1.fill_(nR - 1)
             if taps is not None:
@@ -508,26 +582,49 @@ class MllamaEngine:
         cur = torch.cuda.current_stream(self.device)
         if n_streams > 1 and len(getattr(self, "_prefill_streams", [])) < n_streams:
             self._prefill_streams = [torch.cuda.Stream(device=self.device) for _ in range(n_streams)]
-        for b, r in enumerate(requests):
-            try:
-                ids, fr = r() if callable(r) else r
-                if fr is None:
-                    raise ValueError("generate_batch needs an image in every request")
-                if n_streams > 1:
-                    st = self._prefill_streams[B % n_streams]
-                    st.wait_stream(cur)          # the frame's upload / JPEG kernels ran on `cur`
-                    with torch.cuda.stream(st):
-                        fr.record_stream(st)
-                        self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B)
-                else:
-                    self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B)
-            except Exception as e:      # noqa: BLE001 - a lazy request's failure stays its own
+        vb = max(1, int(os.environ.get("VIS_VIT_BATCH", "4"))) if n_streams > 1 else 1
+        for g0 in range(0, n_req, vb):
+            grp = []                                     # (request index, ids, frame) of the requests that resolved
+            for b in range(g0, min(n_req, g0 + vb)):
+                r = requests[b]
+                try:
+                    ids, fr = r() if callable(r) else r
+                    if fr is None:
+                        raise ValueError("generate_batch needs an image in every request")
+                    grp.append((b, ids, fr))
+                except Exception as e:      # noqa: BLE001 - a lazy request's failure stays its own
+                    if not lazy:
+                        raise
+                    errors[b] = e
+            if not grp:
+                continue
+            try:      # the tower once over the group's images (whole rounds of the chip), on the current stream
+                crosses = self.vision_forward_many([fr for _, _, fr in grp]) if len(grp) > 1 else [None] * len(grp)
+            except Exception as e:      # noqa: BLE001
                 if not lazy:
                     raise
-                errors[b] = e
+                for b, _, _ in grp:
+                    errors[b] = e
                 continue
-            slots[b] = B
-            B += 1
+            for (b, ids, fr), cs in zip(grp, crosses):
+                try:
+                    if n_streams > 1:
+                        st = self._prefill_streams[B % n_streams]
+                        st.wait_stream(cur)          # the frame's upload / JPEG kernels and the group's tower ran on `cur`
+                        with torch.cuda.stream(st):
+                            fr.record_stream(st)
+                            if cs is not None:
+                                cs[0].record_stream(st)
+                            self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B, cross_states=cs)
+                    else:
+                        self.prefill(ids, fr, temperature=temperature, seed=seed, slot=B, cross_states=cs)
+                except Exception as e:      # noqa: BLE001
+                    if not lazy:
+                        raise
+                    errors[b] = e
+                    continue
+                slots[b] = B
+                B += 1
         if n_streams > 1:
             for st in self._prefill_streams[:n_streams]:
                 cur.wait_stream(st)
