@@ -137,3 +137,32 @@ def test_batched_decode_matches_single_and_is_batch_invariant(device):
     # a text-only request cannot join a batch (the batched step always runs the cross layers)
     with pytest.raises(ValueError):
         eng.generate_batch([reqs[0], ([1, 5, 6, 7], None)], max_new_tokens=4)
+
+
+def test_stacked_prompt_passes_equal_one_pass_per_request(device, monkeypatch):
+    """verify_many sends the same Auditor prompt with every image: the requests of a group run the tower once over their
+    stacked images and the text decoder once over their stacked rows (MllamaEngine.vision_forward_many / _prefill_group).
+    Tokens and first-step logits must be exactly those of one pass per request - also against the single-sequence path's
+    first token - for images of different tile counts."""
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    from vision_inspection_system_amd.mllama_weights import MllamaConfig, pack_device_weights, synth_state_dict
+    cfg = MllamaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    eng = MllamaEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=6)
+    g = np.load(os.path.join(HERE, "golden", "mllama_tiny.npz"))
+    ids = g["b_ids"].tolist()                                            # text first, image token last (the reference's order)
+    frames = [torch.from_numpy(g[f"{c}_image"]).to(device) for c in "abc"]           # 2, 4 and 1 tiles
+    reqs = [(ids, frames[0]), (ids, frames[1]), (ids, frames[2]), (ids, frames[0]), (ids, frames[1])]
+    calls = []
+    real = eng._prefill_group
+    monkeypatch.setattr(eng, "_prefill_group", lambda items, *a, **k: (calls.append(len(items)), real(items, *a, **k))[1])
+    stacked = eng.generate_batch(reqs, max_new_tokens=10, stop_on_eos=False)
+    logits = eng.logits_b[:5].clone()
+    assert calls == [4]                                                  # groups of four: [4 stacked] + [1 alone]
+    monkeypatch.setenv("VIS_MERGE_PREFILL", "0")
+    monkeypatch.setenv("VIS_VIT_BATCH", "1")
+    apart = eng.generate_batch(reqs, max_new_tokens=10, stop_on_eos=False)
+    assert calls == [4] and apart == stacked and torch.equal(logits, eng.logits_b[:5])
+    assert stacked[0] == stacked[3] and stacked[1] == stacked[4]
+    for b in range(3):
+        assert eng.generate(ids, frames[b], max_new_tokens=10, stop_on_eos=False)[0] == stacked[b][0]

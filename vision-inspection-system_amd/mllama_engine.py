@@ -423,6 +423,118 @@ class MllamaEngine:
             self.prompt_len, self._decoded = S, 0
             self.decode_limit = self.max_ctx
 
+    def _prefill_group(self, items: Sequence[tuple], temperature: float, seed: int) -> None:
+        """The text decoder's prompt pass of SEVERAL requests with one prompt layout (verify_many: the same Auditor prompt in
+        front of every image) over their stacked rows.  items: [(slot, ids, cross_states, n_tiles)], all prompts S tokens
+        long with the image token at the same index.  At S ~ 700 a request is 2.75 row tiles of 256: stacked, four give 11
+        (gate/up 112 x 3 = 1.3 rounds per request -> 4.8 for four).  Only the row-independent kernels see the stack
+        (projections, norms); K / V projection of the image, rope / cache write and both attentions run per request.  The
+        K order of every projection is M-independent and the K-slice counts are a function of the layer shape, so a
+        request's tokens are those of its own pass (test_batched_decode_matches_single_and_is_batch_invariant)."""
+        cfg, w, dev, bf = self.cfg, self.w, self.device, torch.bfloat16
+        self.temperature, self.seed = float(temperature), int(seed)
+        k = len(items)
+        S = len(items[0][1])
+        H, Hq, Hkv, D = cfg.hidden, cfg.heads, cfg.kv_heads, cfg.head_dim
+        P, TP = cfg.tile_tokens, self.TP
+        ids0 = np.asarray(list(items[0][1]), dtype=np.int64)
+        nm = int(np.nonzero(ids0 == cfg.image_token_id)[0][0])
+        M = k * S
+        x = torch.empty((M, H), dtype=bf, device=dev)
+        xworks, xvts = [], []
+        for j, (slot, ids, cross, n_tiles) in enumerate(items):
+            ids_np = np.asarray(list(ids), dtype=np.int64)
+            locs = np.nonzero(ids_np == cfg.image_token_id)[0]
+            if len(ids_np) != S or len(locs) != 1 or int(locs[0]) != nm:
+                raise ValueError("_prefill_group: the prompts of a group must share length and image-token position")
+            if ids_np.min() < 0 or ids_np.max() >= cfg.vocab + 8:
+                raise ValueError("token id out of range")
+            hip.gather_rows(w.embed, hip.upload(ids_np.astype(np.int32), dev), x[j * S:(j + 1) * S])
+            nR = n_tiles * P
+            self.nkeys_b[slot:slot + 1].fill_(nR - 1)
+            xitems = [(q0, min(128, nm - q0), 0, TP) for q0 in range(0, nm, 128)] + \
+                     [(q0, min(128, S - q0), 0, nR) for q0 in range(nm, S, 128)]
+            xworks.append(torch.tensor(xitems, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous())
+            xvts.append(torch.empty((Hkv, D, self.Tk), dtype=bf, device=dev))
+        kvbuf = torch.empty((TP, 2 * Hkv * D), dtype=bf, device=dev)
+        q2 = torch.empty((M, Hq * D), dtype=bf, device=dev)
+        cos, sin = self.cos_t[:S], self.sin_t[:S]
+        work = hip.make_attn_pairs(0, S, dev)
+        ld = _round_up(S, 64)
+        nq = (Hq + 2 * Hkv) * D
+        y = torch.empty((M, H), dtype=bf, device=dev)
+        qkv = torch.empty((M, nq), dtype=bf, device=dev)
+        q = torch.empty((k, Hq, S, D), dtype=bf, device=dev)
+        vt = torch.empty((k, Hkv, D, ld), dtype=bf, device=dev)
+        att = torch.empty((M, Hq * D), dtype=bf, device=dev)
+        act = torch.empty((M, cfg.intermediate), dtype=bf, device=dev)
+        scale = D ** -0.5
+        ks_down = int(os.environ.get("VIS_MLLAMA_SPLITK", "4")) if cfg.intermediate >= 8192 else 0
+        ks_o = int(os.environ.get("VIS_MLLAMA_SPLITK_O", "4")) if H >= 4096 else 0
+        ks_qkv = int(os.environ.get("VIS_MLLAMA_SPLITK_QKV", "0"))
+        swork = torch.empty(max(ks_down, ks_o, 1) * M * max(H, nq if ks_qkv else 0), dtype=torch.float32, device=dev) \
+            if (ks_down or ks_o or ks_qkv) else None
+
+        def proj(a, wt, ks):        # x += a @ wt.T
+            if ks >= 2:
+                hip.gemm_splitk(a, wt, swork, ks, residual=x, out=x)
+            else:
+                hip.gemm(a, wt, residual=x, out=x)
+
+        si = ci = 0
+        for lw in w.layers:
+            if lw.cross:
+                for j, (slot, _, cross, _) in enumerate(items):
+                    hip.gemm(cross, lw.kv_w, out=kvbuf)
+                    for h in range(Hkv):
+                        hip.rmsnorm(kvbuf[:, h * D:(h + 1) * D], lw.k_norm, cfg.rms_eps, out=kvbuf[:, h * D:(h + 1) * D])
+                    hip.qkv_rope_split(kvbuf, None, None, None, self.xk_b[slot][ci], self.xv_b[slot][ci], xvts[j], 0, Hkv, D,
+                                       k_pos0=0)
+                hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
+                hip.gemm(y, lw.qkv_w, out=q2)
+                hip.rmsnorm(q2.view(M * Hq, D), lw.q_norm, cfg.rms_eps, out=q2.view(M * Hq, D))
+                for j, (slot, _, _, _) in enumerate(items):
+                    rows = slice(j * S, (j + 1) * S)
+                    hip.qkv_rope_split(q2[rows], None, None, q[j], None, None, None, Hq, 0, D)
+                    hip.attn_prefill(q[j], self.xk_b[slot][ci], xvts[j], att[rows], xworks[j], False, scale)
+                proj(att, lw.o_w, ks_o)
+                keep = [x[j * S:j * S + nm].clone() for j in range(k)] if nm > 0 else None
+                hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
+                hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
+                proj(act, lw.down_w, ks_down)
+                if keep is not None:              # rows before the image: MLP contribution zeroed (TF:...:697-699)
+                    for j in range(k):
+                        x[j * S:j * S + nm].copy_(keep[j])
+                ci += 1
+            else:
+                hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
+                if ks_qkv >= 2:
+                    hip.gemm_splitk(y, lw.qkv_w, swork, ks_qkv, out=qkv)
+                else:
+                    hip.gemm(y, lw.qkv_w, out=qkv)
+                for j, (slot, _, _, _) in enumerate(items):
+                    rows = slice(j * S, (j + 1) * S)
+                    kc, vc = self.kcache_b[slot][si], self.vcache_b[slot][si]
+                    hip.qkv_rope_split(qkv[rows], cos, sin, q[j], kc, vc, vt[j], Hq, Hkv, D, k_pos0=0)
+                    hip.attn_prefill_pairs(q[j], kc, vt[j], att[rows], work, scale)
+                proj(att, lw.o_w, ks_o)
+                hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
+                hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
+                proj(act, lw.down_w, ks_down)
+                si += 1
+        for j, (slot, _, _, _) in enumerate(items):
+            logits = self.logits_b[slot]
+            hip.gemv(x[(j + 1) * S - 1], w.lm_head, logits, norm_w=w.norm_w, eps=cfg.rms_eps)
+            self.step_b[slot:slot + 1].fill_(S - 1)
+            hip.argmax(logits, self.ws_val[256 * slot:256 * (slot + 1)], self.ws_idx[256 * slot:256 * (slot + 1)],
+                       self.tokens_b[slot], self.cur_b[slot:slot + 1], self.step_b[slot:slot + 1], self.temperature,
+                       self.seed + 0x9E3779B9 * slot)
+            self.slot_prompt_len[slot] = S
+            if slot == 0:
+                self.has_image = True
+                self.prompt_len, self._decoded = S, 0
+                self.decode_limit = self.max_ctx
+
     # ------------------------------------------------------------------ decode
     def _decode_step(self) -> None:
         cfg, w = self.cfg, self.w
@@ -605,6 +717,31 @@ class MllamaEngine:
                     raise
                 for b, _, _ in grp:
                     errors[b] = e
+                continue
+            # requests with one prompt layout (the Auditor's fixed prompt): ONE stacked text pass (VIS_MERGE_PREFILL=0: A/B)
+            stack = len(grp) > 1 and n_streams > 1 and os.environ.get("VIS_MERGE_PREFILL", "1") != "0"
+            if stack:
+                l0 = [i for i, t in enumerate(grp[0][1]) if t == self.cfg.image_token_id]
+                stack = all(len(ids) == len(grp[0][1]) and
+                            [i for i, t in enumerate(ids) if t == self.cfg.image_token_id] == l0 for _, ids, _ in grp) and len(l0) == 1
+            if stack:
+                st = self._prefill_streams[(g0 // vb) % n_streams]      # consecutive groups alternate streams
+                st.wait_stream(cur)
+                try:
+                    with torch.cuda.stream(st):
+                        items = []
+                        for (b, ids, fr), cs in zip(grp, crosses):
+                            cs[0].record_stream(st)
+                            items.append((B + len(items), ids, cs[0], cs[1]))
+                        self._prefill_group(items, temperature, seed)
+                    for (b, _, _) in grp:
+                        slots[b] = B
+                        B += 1
+                except Exception as e:      # noqa: BLE001
+                    if not lazy:
+                        raise
+                    for b, _, _ in grp:
+                        errors[b] = e
                 continue
             for (b, ids, fr), cs in zip(grp, crosses):
                 try:
