@@ -84,6 +84,21 @@ __device__ __forceinline__ float att_max(float a, float b) {
   asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
+// The online softmax keeps a REFERENCE m per query instead of the strict running maximum: m is the first tile's maximum
+// and afterwards follows a tile's maximum only when that exceeds it by more than ATT_LAZY (log2 units), so
+// p = exp2(s - m) <= 2^ATT_LAZY = 256 instead of <= 1.  Still exact after the final division (numerator and denominator
+// carry the same m; bf16 keeps its relative precision, the f32 sums stay far from overflow), and after the first tile of
+// a row nothing moves on almost every tile: no alpha, no O rescale (48 multiplies per tile in the 32-wide kernel, taken
+// on ~2/3 of the tiles with the strict maximum on N(0,1) scores), no per-score subtraction (the kernels keep -m as the
+// C operand of the first QK^T MFMA).  The decision is per lane = per query, a function of that query's own keys in the
+// fixed absolute tile order, so results still do not depend on what shares the wave, the launch or the batch.
+// -DATT_LAZY=0.0f gives the strict maximum.
+#ifndef ATT_LAZY
+#define ATT_LAZY 8.0f
+#endif
+// (Packing the score scaling as v_pk_fma_f32 - two scores per instruction - was measured SLOWER than two v_fma_f32:
+// 189-191 us against 184-185 us on the ViT shape, same box, tools/probes/attn_ab.sh; a packed f32 op holds the issue port
+// for both halves.)
 // max over lanes l, l^16, l^32, l^48 (hmax4 of common.hip.h without the canonicalising self-maxes)
 __device__ __forceinline__ float att_hmax4(float x) {
   const uint32_t u = __float_as_uint(x);
@@ -94,8 +109,21 @@ __device__ __forceinline__ float att_hmax4(float x) {
   return att_max(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
+// Q fragments are multiplied by scale_log2 once, when they are loaded (one more bf16 rounding of Q, no multiply per score
+// afterwards): the QK^T MFMAs then produce scores in the log2 domain, and with the running reference -m as the C operand
+// of their first k-step the accumulators hold s - m directly.
+__device__ __forceinline__ bf16x8 att_scaled_q8(const bf16_t* q, float scale) {
+  float f[8];
+  unpack8(*(const u32x4*)q, f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f[i] *= scale;
+  return __builtin_bit_cast(bf16x8, pack8(f));
+}
+
 template <int HD, bool CAUSAL>
-__global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(AttnArgs p) {
+// (head_dim 80 here is the A/B fallback of attn_vit32_kernel and the causal form nothing in the engines uses: it is
+// compiled for two workgroups per CU since the -m seed registers arrived - at three it spilled ten dwords.)
+__global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   constexpr int DKS = (HD + 31) / 32;           // QK^T k-steps over d: 4 / 3
   constexpr int ND = HD / 16;                   // P*V output blocks over d: 8 / 5
   constexpr int KCH = HD / 8;                   // valid 16-B chunks per K row: 16 / 10
@@ -142,8 +170,16 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
     const int qrow = min(wq0 + qb * 16 + l15, p.q_row0 + p.Sq - 1) - p.q_row0;
     const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
 #pragma unroll
-    for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ds * 32 + 8 * h));
-    qt[qb] = TAIL16 ? __builtin_bit_cast(bf16x4s, *(const u32x2*)(qp + DKF * 32 + 4 * h)) : (bf16x4s){0, 0, 0, 0};
+    for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = att_scaled_q8(qp + ds * 32 + 8 * h, p.scale_log2);
+    if constexpr (TAIL16) {
+      const u32x2 raw = *(const u32x2*)(qp + DKF * 32 + 4 * h);
+      u32x2 sc;
+      sc[0] = pack2bf(__uint_as_float(raw[0] << 16) * p.scale_log2, __uint_as_float(raw[0] & 0xffff0000u) * p.scale_log2);
+      sc[1] = pack2bf(__uint_as_float(raw[1] << 16) * p.scale_log2, __uint_as_float(raw[1] & 0xffff0000u) * p.scale_log2);
+      qt[qb] = __builtin_bit_cast(bf16x4s, sc);
+    } else {
+      qt[qb] = (bf16x4s){0, 0, 0, 0};
+    }
   }
 
 
@@ -258,7 +294,8 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
     for (int nb = 0; nb < NACC; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {ATT_NEG, ATT_NEG};
+  // -m of each q-block's query (the lane's), the C operand of the first QK^T k-step: see attn_vit32_kernel
+  f32x4 negm[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
   float lsum[2] = {0.f, 0.f};      // !MFMA_SUM: sum over this lane's keys (4 h-rows are added at the end)
   const uint32_t one2 = (l15 == 0) ? 0x3f803f80u : 0u;
   const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
@@ -280,11 +317,8 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
       constexpr int NQ = decltype(nq_tag)::value;
       const char* kb = lds + cur * BUF;
       const char* vb = kb + K_BYTES;
-      // ---- S^T = K * Q^T
-      // the first k-step takes a literal zero as its C operand (an inline constant of the MFMA): zero-initialising
-      // the 8 accumulators first cost 32 v_mov per tile and wave
+      // ---- S^T = K * (scale Q)^T - m: the first k-step takes -m (negm) as its C operand
       f32x4 sacc[4][NQ];
-      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < DKF; ++ds) {
         bf16x8 kf[4];
@@ -300,7 +334,7 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
 #pragma unroll
           for (int qb = 0; qb < NQ; ++qb) {
             if constexpr ((ATT_PROBE & 8) != 0) { sacc[kbk][qb] = (f32x4){kf[kbk][0], kf[kbk][1], qf[qb][ds][0], 1.0f}; continue; }
-            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], ds == 0 ? zero4 : sacc[kbk][qb], 0, 0, 0);
+            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], ds == 0 ? negm[qb] : sacc[kbk][qb], 0, 0, 0);
           }
       }
 
@@ -319,10 +353,10 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
           for (int qb = 0; qb < NQ; ++qb)
             sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(kt4[kbk], qt[qb], sacc[kbk][qb], 0, 0, 0);
       }
-      // ---- online softmax (query on the lane, keys in registers), log2 domain:
-      //      p = exp2(s * scale_log2 - m), one FMA + one raw v_exp_f32 per score
-      float alpha[NQ];
-      bf16x8 pf[2][NQ];
+      // ---- online softmax (query on the lane, keys in registers), log2 domain: the accumulators hold s - m, so
+      //      p = one raw v_exp_f32 per score; m is set by the first tile and then only moves when a tile's maximum
+      //      exceeds it by more than ATT_LAZY (delta below, per lane = per query; the branch is per wave)
+      float delta[NQ];
 #pragma unroll
       for (int qb = 0; qb < NQ; ++qb) {
         const int q = wq0 + qb * 16 + l15;
@@ -354,22 +388,42 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
         mx = att_max3(mx, sacc[3][qb][1], sacc[3][qb][2]);
         mx = att_max3(mx, sacc[3][qb][3], sacc[3][qb][3]);
         mx = att_hmax4(mx);  // over the four 16-lane rows (keys 4h..4h+3): two permlane swaps, no LDS round trip
-        // raw scores are masked with -1e30; scaled they stay a huge negative number
-        const float mnew = att_max(mrow[qb], mx * p.scale_log2);
-        alpha[qb] = att_exp2(mrow[qb] - mnew);
-        mrow[qb] = mnew;
+        delta[qb] = (t == 0 || mx > ATT_LAZY) ? mx : 0.f;
+      }
+      // ---- a reference moved: shift this tile's scores and -m, rescale O (rows 4h+r of each q-block) and the lane sums
+      if (!__all((delta[0] == 0.f) && (delta[NQ - 1] == 0.f))) {
+        asm volatile("" : "+v"(delta[0]));  // keep this a real (rarely taken) branch: nothing of it is speculated
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb) {
+          const float d = delta[qb];
+          const float nm = negm[qb][0] - d;
+          negm[qb] = (f32x4){nm, nm, nm, nm};
+#pragma unroll
+          for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[kbk][qb][r] -= d;
+          const float alpha = att_exp2(-d);
+          if constexpr (!MFMA_SUM) lsum[qb] *= alpha;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(alpha, 4 * h + r, 64);
+#pragma unroll
+            for (int nb = 0; nb < NACC; ++nb) oacc[qb][nb][r] *= a;
+          }
+        }
+      }
+      bf16x8 pf[2][NQ];
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) {
         float pv[4][4];
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float e = att_exp2(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
-            pv[kbk][r] = e;
-          }
+          for (int r = 0; r < 4; ++r) pv[kbk][r] = att_exp2(sacc[kbk][qb][r]);
         if constexpr (!MFMA_SUM) {
           float t0 = (pv[0][0] + pv[0][1]) + (pv[0][2] + pv[0][3]), t1 = (pv[1][0] + pv[1][1]) + (pv[1][2] + pv[1][3]);
           float t2 = (pv[2][0] + pv[2][1]) + (pv[2][2] + pv[2][3]), t3 = (pv[3][0] + pv[3][1]) + (pv[3][2] + pv[3][3]);
-          lsum[qb] = lsum[qb] * alpha[qb] + ((t0 + t1) + (t2 + t3));
+          lsum[qb] += (t0 + t1) + (t2 + t3);
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -380,20 +434,6 @@ __global__ __launch_bounds__(256, HD == 80 ? 3 : 2) void attn_prefill_kernel(Att
           pk[3] = pack2bf(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
           pf[ks][qb] = __builtin_bit_cast(bf16x8, pk);
         }
-      }
-
-      // ---- rescale O (rows 4h+r of each q-block) when any running max moved
-      const bool resc = !__all((alpha[0] == 1.0f) && (alpha[NQ - 1] == 1.0f));
-      if (resc) {
-        asm volatile("" : "+v"(alpha[0]));  // keep this a real (rarely taken) branch: no speculated multiplies
-#pragma unroll
-        for (int qb = 0; qb < NQ; ++qb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = __shfl(alpha[qb], 4 * h + r, 64);
-#pragma unroll
-            for (int nb = 0; nb < NACC; ++nb) oacc[qb][nb][r] *= a;
-          }
       }
 
       // ---- O += P * V  (B operand: chunk 4 ks + h of V^T row d, keys already in k-slot order)
@@ -528,7 +568,9 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
     const int qrow = min(wq0 + r31, p.q_row0 + p.Sq - 1) - p.q_row0;
     const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ks * 16));
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = att_scaled_q8(qp + ks * 16, p.scale_log2);
+    }
   }
 
   // LDS-DMA source offsets (loop constants): slot ps = i * 256 + tid; the third piece exists for ps < 640 only
@@ -586,7 +628,13 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
   for (int db = 0; db < NDB; ++db)
 #pragma unroll
     for (int i = 0; i < 16; ++i) oacc[db][i] = 0.f;
-  float mrow = ATT_NEG;
+  // Reference value m of the online softmax, kept as the MFMA's C operand: S^T = K * (scale Q)^T + (-m) leaves
+  // s - m in the accumulators, so a score costs v_exp + half a v_cvt_pk and nothing else.  m is set by the first tile
+  // and afterwards only moves when a tile's maximum exceeds it by more than ATT_LAZY (above): the common
+  // tile has no alpha, no rescale and no per-score subtraction; the rare one pays them for the whole wave.
+  f32x16 negm;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
 
   if (nt > 0) load_tile(kt_begin, 0);
   __syncthreads();
@@ -606,11 +654,9 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
         bf16x8 kf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) kf[ks] = *(const bf16x8*)(kb_ + k_lane + kb * (32 * HD * 2) + ks * 32);
-        f32x16 acc;
+        f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], negm, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+        for (int ks = 1; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
         sacc[kb] = acc;
       }
       // ---- mask the edge tiles: element (kb, i) is key kt + 4 hh + 32 kb + 8 (i >> 2) + (i & 3)
@@ -640,15 +686,31 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
         const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
         mx = att_max(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
       }
-      const float mnew = att_max(mrow, mx * p.scale_log2);
-      const float alpha = att_exp2(mrow - mnew);
-      mrow = mnew;
+      // mx = max(s - m) of this query over the tile.  delta = how far m moves: the whole maximum on the first tile,
+      // the excess when it is more than ATT_LAZY above m, else 0 (per lane = per query; the branch is per wave)
+      const float delta = (t == 0 || mx > ATT_LAZY) ? mx : 0.f;
+      if (!__all(delta == 0.f)) {
+        float d = delta;
+        asm volatile("" : "+v"(d));                 // a real (rarely taken) branch: nothing of it is speculated
+        const float nm = negm[0] - d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = nm;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sacc[kb][i] -= d;
+        const float a = att_exp2(-d);               // rescale O^T (the query is the lane: no cross-lane traffic)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) oacc[db][i] *= a;
+      }
       bf16x8 pf[2][2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
         float e[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) e[i] = att_exp2(__builtin_fmaf(sacc[kb][i], p.scale_log2, -mnew));
+        for (int i = 0; i < 16; ++i) e[i] = att_exp2(sacc[kb][i]);
 #pragma unroll
         for (int t2 = 0; t2 < 2; ++t2) {
           u32x4 pk;
@@ -658,15 +720,6 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
           pk[3] = pack2bf(e[4 * t2 + 10], e[4 * t2 + 11]);
           pf[kb][t2] = __builtin_bit_cast(bf16x8, pk);
         }
-      }
-      // ---- rescale O^T (the query is the lane: no cross-lane traffic) when any running max of the wave moved
-      if (!__all(alpha == 1.0f)) {
-        float a = alpha;
-        asm volatile("" : "+v"(a));                 // a real (rarely taken) branch: no speculated multiplies
-#pragma unroll
-        for (int db = 0; db < NDB; ++db)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) oacc[db][i] *= a;
       }
       // ---- O^T += V^T * P^T
 #pragma unroll
@@ -755,7 +808,7 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
     const int qrow = min(max(wrow0[qb] + l15, p.q_row0), p.q_row0 + p.Sq - 1) - p.q_row0;
     const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
 #pragma unroll
-    for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = __builtin_bit_cast(bf16x8, *(const u32x4*)(qp + ds * 32 + 8 * h));
+    for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = att_scaled_q8(qp + ds * 32 + 8 * h, p.scale_log2);
   }
 
   // staging: K tile 64 rows x 16 chunks, V^T tile 128 rows x 8 chunks = 1024 16-byte slots each, 2 per thread
@@ -794,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
     for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float mrow[2] = {ATT_NEG, ATT_NEG};
+  f32x4 negm[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // as in attn_prefill_kernel
   const uint32_t one2 = (l15 == 0) ? 0x3f803f80u : 0u;
   const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
 
@@ -818,7 +871,6 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
       const char* kb = lds + cur * BUF;
       const char* vb = kb + K_BYTES;
       f32x4 sacc[4][NQ];
-      const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ds = 0; ds < DKF; ++ds) {
         bf16x8 kf[4];
@@ -831,10 +883,9 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
           for (int qb = 0; qb < NQ; ++qb)
-            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], ds == 0 ? zero4 : sacc[kbk][qb], 0, 0, 0);
+            sacc[kbk][qb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kbk], qf[qb][ds], ds == 0 ? negm[qb] : sacc[kbk][qb], 0, 0, 0);
       }
-      float alpha[NQ];
-      bf16x8 pf[2][NQ];
+      float delta[NQ];
 #pragma unroll
       for (int qb = 0; qb < NQ; ++qb) {
         const int q = wrow0[qb] + l15;
@@ -857,14 +908,36 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
         mx = att_max3(mx, sacc[3][qb][1], sacc[3][qb][2]);
         mx = att_max3(mx, sacc[3][qb][3], sacc[3][qb][3]);
         mx = att_hmax4(mx);
-        const float mnew = att_max(mrow[qb], mx * p.scale_log2);
-        alpha[qb] = __builtin_amdgcn_exp2f(mrow[qb] - mnew);
-        mrow[qb] = mnew;
+        delta[qb] = (t == 0 || mx > ATT_LAZY) ? mx : 0.f;
+      }
+      if (!__all((delta[0] == 0.f) && (delta[NQ - 1] == 0.f))) {
+        asm volatile("" : "+v"(delta[0]));
+#pragma unroll
+        for (int qb = 0; qb < NQ; ++qb) {
+          const float d = delta[qb];
+          const float nm = negm[qb][0] - d;
+          negm[qb] = (f32x4){nm, nm, nm, nm};
+#pragma unroll
+          for (int kbk = 0; kbk < 4; ++kbk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc[kbk][qb][r] -= d;
+          const float alpha = att_exp2(-d);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(alpha, 4 * h + r, 64);
+#pragma unroll
+            for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb][r] *= a;
+          }
+        }
+      }
+      bf16x8 pf[2][NQ];
+#pragma unroll
+      for (int qb = 0; qb < NQ; ++qb) {
         float pv[4][4];
 #pragma unroll
         for (int kbk = 0; kbk < 4; ++kbk)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) pv[kbk][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(sacc[kbk][qb][r], p.scale_log2, -mnew));
+          for (int r = 0; r < 4; ++r) pv[kbk][r] = att_exp2(sacc[kbk][qb][r]);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           u32x4 pk;
@@ -874,18 +947,6 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
           pk[3] = pack2bf(pv[2 * ks + 1][2], pv[2 * ks + 1][3]);
           pf[ks][qb] = __builtin_bit_cast(bf16x8, pk);
         }
-      }
-      const bool resc = !__all((alpha[0] == 1.0f) && (alpha[NQ - 1] == 1.0f));
-      if (resc) {
-        asm volatile("" : "+v"(alpha[0]));
-#pragma unroll
-        for (int qb = 0; qb < NQ; ++qb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float a = __shfl(alpha[qb], 4 * h + r, 64);
-#pragma unroll
-            for (int nb = 0; nb <= ND; ++nb) oacc[qb][nb][r] *= a;
-          }
       }
       const int vsw = (l15 >> 1) & 7;
 #pragma unroll
@@ -995,7 +1056,6 @@ extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* V
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, stream, p);
   } else {
-    // non-causal head_dim 80 (the ViT): the 32x32x16 kernel; VIS_ATTN80=16 keeps the 16x16x32 kernel (A/B runs)
     // non-causal head_dim 80 (the ViT towers): the 32x32x16 kernel; VIS_ATTN80=16 keeps the 16x16x32 kernel (A/B runs)
     static const bool wide = [] { const char* e = getenv("VIS_ATTN80"); return !(e && atoi(e) == 16); }();
     if (causal) hipLaunchKernelGGL((attn_prefill_kernel<80, true>), grid, block, pad_lds, stream, p);
