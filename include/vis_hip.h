@@ -90,6 +90,18 @@ int vis_attn_prefill_pairs(const void* Q, const void* K, const void* Vt, void* O
                            int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, float scale,
                            int q_row0, vis_stream_t stream);
 
+/* K6, key-split form (HD = 80, non-causal: the ViT towers).  Work items as in vis_attn_prefill plus SPLIT items, whose
+ * y field is qn | (1 | part << 1 | pair << 2) << 8: parts 0 and 1 of pair `pair` cover the same query rows and the two
+ * halves of their key range (cut at a multiple of 64); the kernel merges them (the later workgroup adds the earlier
+ * one's partial, fixed operand order).  One 1024 x 1024 image at 16 heads leaves some SIMDs three 32-row blocks and
+ * others two; with 9 of its 39 row blocks split every CU holds two whole and one half workgroup.
+ * ws: vis_attn_split_ws_bytes(n_pairs, Hq) bytes, 256-byte aligned, zero before its first use (the kernel leaves it
+ * reusable); one launch at a time per workspace.  Same reference as vis_attn_prefill (TF modeling_qwen2_vl.py:349-421). */
+int vis_attn_split_ws_bytes(int n_pairs, int Hq);
+int vis_attn_prefill_split(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
+                           int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, float scale,
+                           int n_pairs, void* ws, long long ws_bytes, vis_stream_t stream);
+
 /* K10  y[N] = act(W[N,K] x[K] + bias) + R, optional fused RMSNorm of x (norm_w != NULL).
  * out_f32 != 0 writes float logits (lm_head).  One generated token streams every weight once. */
 int vis_gemv_bf16(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,

@@ -106,3 +106,44 @@ def test_attention_work_planner_partitions_rows():
     assert hip.ATTN_SLOTS - 32 < len(vit) * 16 <= hip.ATTN_SLOTS - 16      # as fine as one round allows, one item of slack
     assert hip.plan_attn_items([(0, 4900)], 0) == [(q, min(128, 4900 - q), 0, 4900) for q in range(0, 4864, 128)] + \
         [(4864, 36, 0, 4900)]
+
+
+def test_attention_key_split_planner():
+    """plan_attn_items_split (host): whole items cover their rows once with the segment as key range; a split pair covers
+    the same 128 rows twice with the two halves of the key range meeting at a multiple of 64; pair ids are 0..n-1; the
+    rule is per segment (a stacked launch splits the same blocks of each image); short segments are never split."""
+    from vision_inspection_system_amd import hip
+    items, n = hip.plan_attn_items_split([(0, 4900)], 16)
+    assert n == 9 and len(items) == 48 and len(items) * 16 == hip.ATTN_SLOTS
+    for segs, heads in [([(0, 4900)], 16), ([(0, 4900), (4928, 9828)], 16), ([(0, 3200)], 3), ([(0, 6404), (6404, 6432)], 16)]:
+        items, n = hip.plan_attn_items_split(segs, heads)
+        rows, pairs = {}, {}
+        seen_split = False
+        for (q0, y, k0, k1) in items:
+            qn, fl = y & 0xff, y >> 8
+            seg = [sg for sg in segs if sg[0] <= q0 < sg[1]][0]
+            assert 0 < qn <= 128 and q0 + qn <= seg[1]
+            if fl == 0:
+                assert not seen_split, "whole items come first"
+                assert (k0, k1) == seg
+                for r in range(q0, q0 + qn):
+                    assert r not in rows
+                    rows[r] = 1
+            else:
+                seen_split = True
+                assert fl & 1 and qn == 128
+                pairs.setdefault(fl >> 2, {})[(fl >> 1) & 1] = (q0, k0, k1, seg)
+        assert sorted(pairs) == list(range(n))
+        for parts in pairs.values():
+            (qa, a0, a1, seg), (qb, b0, b1, _) = parts[0], parts[1]
+            assert qa == qb and a0 == seg[0] and b1 == seg[1] and a1 == b0 and a1 % 64 == 0 and a0 < a1 < b1
+            for r in range(qa, qa + 128):
+                assert r not in rows
+                rows[r] = 1
+        assert len(rows) == sum(e - s for s, e in segs)
+    one, n1 = hip.plan_attn_items_split([(0, 4900)], 16)
+    two, n2 = hip.plan_attn_items_split([(0, 4900), (4928, 9828)], 16)
+    assert n2 == 2 * n1
+    assert {(q0, y & 0xff, y >> 8 & 3, k0, k1) for (q0, y, k0, k1) in one} <= {(q0, y & 0xff, y >> 8 & 3, k0, k1) for (q0, y, k0, k1) in two}
+    assert hip.plan_attn_items_split([(i * 64, (i + 1) * 64) for i in range(80)], 16)[1] == 0
+    assert hip.plan_attn_items_split([(0, 2000)], 16)[1] == 0

@@ -318,6 +318,66 @@ def test_attn_prefill_d80_wide_kernel_equals_narrow_kernel_inputs(hip, device, S
     _assert_close(got, ref, atol=2e-2, rtol=2e-2, what=f"d80 attention S={S}")
 
 
+def _vt_of(hip, v, S, device):
+    ld = ((S + 63) // 64) * 64
+    vt = torch.zeros((v.shape[0], v.shape[2], ld), dtype=torch.bfloat16, device=device)
+    vt[:, :, :S] = v.permute(0, 2, 1)
+    return vt[:, :, hip.vt_key_order(ld, device)].contiguous()
+
+
+@pytest.mark.parametrize("S,H", [(3200, 3), (4900, 16)])
+def test_attn_vit_key_split_plan(hip, device, S, H):
+    """Key-split items (vis_attn_prefill_split): two workgroups see half of the keys each and the later one merges.
+    Against the fp32 reference and the unsplit launch; launch-to-launch bit-identical (the merge does not depend on which
+    half arrives last); the workspace counters are left at zero; a spike in the second half moves the reference there."""
+    HD = 80
+    q = _randn((H, S, HD), device, 160)
+    k = _randn((H, S, HD), device, 161)
+    v = _randn((H, S, HD), device, 162)
+    k[:, S - 70] = q[:, S - 5] * 4.0                 # a dominating key in the second half for a row of a split block
+    vt = _vt_of(hip, v, S, device)
+    scale = HD ** -0.5
+    plan = hip.make_vit_attn_plan([(0, S)], device, H)
+    assert plan.n_pairs > 0 and plan.work.shape[0] * H <= 768
+    outs = []
+    for i in range(24):                  # back to back on one workspace: a visibility race would show as a differing launch
+        out = torch.full((S, H * HD), 3.0, dtype=torch.bfloat16, device=device)
+        hip.attn_prefill_plan(q, k, vt, out, plan, scale)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in outs[1:]), "key-split merge must be deterministic"
+    n_count = plan.n_pairs * H
+    assert int(plan.ws[:n_count * 4].view(torch.int32).abs().sum()) == 0, "counters must return to zero"
+    plain = torch.zeros_like(outs[0])
+    hip.attn_prefill(q, k, vt, plain, hip.make_attn_work([(0, S)], False, device, heads=H), False, scale)
+    whole_rows = S - plan.n_pairs * 128 - (S % 128)
+    assert torch.equal(outs[0][:whole_rows], plain[:whole_rows]), "unsplit blocks are untouched by the plan"
+    _assert_close(outs[0], plain.float(), atol=1e-2, rtol=1e-2, what="key-split vs one pass over all keys")
+    heads = [0, H - 1]
+    ref = torch.cat([_attn_ref(q[h:h + 1].float().cpu(), k[h:h + 1].float().cpu(), v[h:h + 1].float().cpu(), [(0, S)],
+                               False, scale) for h in heads], dim=1)
+    got = torch.cat([outs[0][:, h * HD:(h + 1) * HD] for h in heads], dim=1)
+    _assert_close(got, ref, atol=2e-2, rtol=2e-2, what=f"key-split attention S={S}")
+
+
+def test_attn_vit_key_split_is_per_segment(hip, device):
+    """The split rule looks at one segment only: an image's rows are bit-identical alone and stacked behind another."""
+    S, H, HD = 3136, 2, 80
+    scale = HD ** -0.5
+    q = _randn((H, 2 * S, HD), device, 170)
+    k = _randn((H, 2 * S, HD), device, 171)
+    v = _randn((H, 2 * S, HD), device, 172)
+    both = torch.zeros((2 * S, H * HD), dtype=torch.bfloat16, device=device)
+    plan2 = hip.make_vit_attn_plan([(0, S), (S, 2 * S)], device, H)
+    assert plan2.n_pairs == 2 * hip.make_vit_attn_plan([(0, S)], device, H).n_pairs > 0
+    hip.attn_prefill_plan(q, k, _vt_of(hip, v, 2 * S, device), both, plan2, scale)
+    for i in range(2):
+        qi, ki, vi = (t[:, i * S:(i + 1) * S].contiguous() for t in (q, k, v))
+        one = torch.zeros((S, H * HD), dtype=torch.bfloat16, device=device)
+        hip.attn_prefill_plan(qi, ki, _vt_of(hip, vi, S, device), one, hip.make_vit_attn_plan([(0, S)], device, H), scale)
+        assert torch.equal(one, both[i * S:(i + 1) * S]), f"segment {i}: stacked and single launches differ"
+
+
 def test_attn_prefill_d80_spiked_max_and_cross_keys(hip, device):
     """Rescale branch (a dominating key in a late tile) and keys that are not the queries' own rows (the mllama tower's
     second item group: queries n_real.. attend keys 0..n_real)."""

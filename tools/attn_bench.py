@@ -22,6 +22,14 @@ if os.environ.get("VIS_ATTN_FULLS") is not None and not causal:   # experiment: 
     nf = int(os.environ["VIS_ATTN_FULLS"])
     items = [(q0, 128, 0, S) for q0 in range(0, nf * 128, 128)] + [(q0, min(64, S - q0), 0, S) for q0 in range(nf * 128, S, 64)]
     work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
+if os.environ.get("VIS_ATTN_SPLIT") is not None and not causal:   # TIMING experiment (results of the split rows are wrong):
+    nf = int(os.environ["VIS_ATTN_SPLIT"])                           # nf full items per head, the rest as two half-key items
+    order = os.environ.get("VIS_ATTN_SPLIT_ORDER", "last")
+    half = ((S // 2) + 63) // 64 * 64
+    full = [(q0, min(128, S - q0), 0, S) for q0 in range(0, min(S, nf * 128), 128)]
+    split = [(q0, min(128, S - q0), a0, a1) for q0 in range(nf * 128, S, 128) for (a0, a1) in ((0, half), (half, S))]
+    items = full + split if order == "last" else split + full
+    work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
 if os.environ.get("VIS_ATTN_CAUSAL") is not None and causal:   # experiment: causal item orders / block sizes
     mode, bq = (int(x) for x in os.environ["VIS_ATTN_CAUSAL"].split(","))
     items = [(q0, min(bq, S - q0), 0, S) for q0 in range(0, S, bq)]

@@ -54,6 +54,10 @@ struct AttnArgs {
   int Sq, k_tokens, vt_ld, ldo, group;
   float scale_log2;
   int q_row0;        // work-list query rows are positions of the whole sequence; Q / O hold rows q_row0 .. q_row0 + Sq - 1
+  // key-split items of attn_vit32_kernel (vis_attn_prefill_split): counters [n_pairs * Hq] then partial blocks
+  int* ws_count;
+  float* ws_part;
+  int n_pairs;
 #ifdef VIT_VARIANTS_STAMPS
   unsigned long long* stamps;   // tools/probes/attn_vit_variants.hip only: s_memtime stamps of workgroup (0, 0)
 #endif
@@ -533,6 +537,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 // Work items, masks, output staging and the fixed key-tile grid (absolute 64-key tiles: results do not depend on what
 // shares the launch) are those of attn_prefill_kernel; items of <= 64 rows keep two of the four waves busy.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define ATT_SPLIT_ROW 84          // 128-float rows of a key-split partial ([d][query row]): O^T[0..79], l, m, 2 unused
 
 __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
   constexpr int HD = 80, KS = HD / 16, NDB = 3;
@@ -546,7 +551,8 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
   const int r31 = lane & 31, hh = lane >> 5;
   const int head = blockIdx.x, hkv = head / p.group;
   const int4 wk = p.work[blockIdx.y];
-  const int q0 = wk.x, qn = wk.y, k0 = wk.z, k1 = wk.w;
+  const int q0 = wk.x, qn = wk.y & 0xff, k0 = wk.z, k1 = wk.w;
+  const int split = wk.y >> 8;          // 0, or 1 | part << 1 | pair << 2 (ATT_SPLIT_* below)
   const int kt_begin = k0 & ~63;
   const int nt = (k1 - kt_begin + 63) >> 6;
   const int wq0 = q0 + wave * 32;
@@ -734,6 +740,77 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
     }
     __syncthreads();
     cur ^= 1;
+  }
+
+  // ---- key-split item: this workgroup saw only half of the keys.  It leaves its unnormalised O^T, l and m in the
+  //      pair's slot; the LATER of the two workgroups (an agent-scope counter tells which) adds the other half to its
+  //      own registers - a_self * x_self + a_other * x_other with separately rounded products, so the sum does not
+  //      depend on which half arrived last - and goes on to the ordinary epilogue.  Nobody waits for anybody.
+  if (split) {
+    const int part = (split >> 1) & 1, pair = min(split >> 2, p.n_pairs - 1);
+    const size_t slot = (size_t)pair * gridDim.x + head;
+    float* mine = p.ws_part + (slot * 2 + part) * (size_t)(128 * ATT_SPLIT_ROW);
+    const float* other = p.ws_part + (slot * 2 + (part ^ 1)) * (size_t)(128 * ATT_SPLIT_ROW);
+    const int row = wave * 32 + r31;
+    const float m_self = -negm[0];
+    // Visibility without flushing caches the kernel lives on: the partials travel as relaxed AGENT-scope atomic stores /
+    // loads (write-through / coherent reads of exactly these words), the writer orders them before its counter update
+    // with a release fence (L2 write-back of the few dirty lines there are), and the reader takes NO acquire fence - an
+    // acquire invalidates the whole L2 of the XCD, K / V tiles of every other workgroup included (measured: 576 of
+    // them per launch made the split launch slower than the unsplit one).
+    if (active) {
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (db == 2 && g >= 2) break;
+          const int d0 = 32 * db + 8 * g + 4 * hh;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)     // [d][row]: 32 lanes = 128 contiguous bytes per store
+            __hip_atomic_store(mine + (d0 + j) * 128 + row, oacc[db][4 * g + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      if (hh == 0) {
+        __hip_atomic_store(mine + 80 * 128 + row, oacc[2][8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 81 * 128 + row, m_self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+#ifdef ATT_SPLIT_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the sc1 stores above are acknowledged = written through
+#endif
+    __syncthreads();                       // every thread's partial is out before the counter moves
+    int* flag = (int*)lds;
+    if (tid == 0) *flag = __hip_atomic_fetch_add(p.ws_count + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int arrived = *flag;
+    if (arrived == 0) return;              // the partner has not finished: it will merge
+    asm volatile("" ::: "memory");
+    if (tid == 0) __hip_atomic_store(p.ws_count + slot, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    if (active) {
+#pragma clang fp contract(off)             // a_s * x_s + a_o * x_o must not become an FMA: the sum has to be symmetric
+      const float l_other = __hip_atomic_load(other + 80 * 128 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float m_other = __hip_atomic_load(other + 81 * 128 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float m = fmaxf(m_self, m_other);
+      const float a_s = att_exp2(m_self - m), a_o = att_exp2(m_other - m);
+#pragma unroll
+      for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (db == 2 && g >= 2) break;
+          const int d0 = 32 * db + 8 * g + 4 * hh;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float x = __hip_atomic_load(other + (d0 + j) * 128 + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float ts = a_s * oacc[db][4 * g + j];
+            const float to = a_o * x;
+            oacc[db][4 * g + j] = ts + to;
+          }
+        }
+      const float ls = a_s * oacc[2][8], lo = a_o * l_other;
+      oacc[2][8] = ls + lo;                // l (meaningful on the lower half)
+    }
+    __syncthreads();                       // the flag word is part of the O staging area
   }
 
   // ---- normalise (denominator = O^T row 80 = register 8 of block 2 on the lower lane half), stage the wave's
@@ -1014,6 +1091,7 @@ extern "C" int vis_attn_prefill_pairs(const void* Q, const void* K, const void* 
   p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.q_row0 = q_row0;
+  p.ws_count = nullptr; p.ws_part = nullptr; p.n_pairs = 0;
   vis_clear_error();
   hipLaunchKernelGGL(attn_prefill_pair_kernel, dim3(Hq, n_work), dim3(512), 0, stream, p);
   return vis_check_launch();
@@ -1045,6 +1123,7 @@ extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* V
   p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.q_row0 = q_row0;
+  p.ws_count = nullptr; p.ws_part = nullptr; p.n_pairs = 0;
   if (n_work > 65535) return VIS_ERR_ARG;
   const dim3 grid(Hq, n_work), block(256);
   // head_dim 80 is built for three workgroups per CU (768 slots, <= 168 VGPRs).  VIS_ATTN_OCC=2 caps residency at two
@@ -1062,5 +1141,44 @@ extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* V
     else if (wide) hipLaunchKernelGGL(attn_vit32_kernel, grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<80, false>), grid, block, pad_lds, stream, p);
   }
+  return vis_check_launch();
+}
+
+// Key-split ViT attention (head_dim 80, non-causal).  Work items as in vis_attn_prefill, plus SPLIT items whose y field
+// is qn | (1 | part << 1 | pair << 2) << 8: the two parts of pair `pair` cover the same query rows and the two halves
+// of their key range (cut at a multiple of 64), and their results are merged inside the kernel (attn_vit32_kernel).
+// One image at 16 heads is 2450 (32-row block x all keys) wave tasks for 1024 SIMDs - some get three, the launch lasts
+// as long as those; with 9 of its 39 row blocks split every CU can hold two whole and one half workgroup
+// (hip.plan_attn_items_split).  ws: vis_attn_split_ws_bytes(n_pairs, Hq) bytes, 256-byte aligned, ZERO before the first
+// use (the kernel leaves the counters at zero); one launch at a time per workspace.
+#define ATT_SPLIT_PART_BYTES ((size_t)2 * 128 * ATT_SPLIT_ROW * sizeof(float))
+static size_t att_split_count_bytes(int n_pairs, int Hq) { return (((size_t)n_pairs * Hq * sizeof(int)) + 255) & ~(size_t)255; }
+
+extern "C" int vis_attn_split_ws_bytes(int n_pairs, int Hq) {   // 0: bad arguments (or more than an int holds)
+  if (n_pairs <= 0 || Hq <= 0) return 0;
+  const size_t b = att_split_count_bytes(n_pairs, Hq) + (size_t)n_pairs * Hq * ATT_SPLIT_PART_BYTES;
+  return b > 0x7fffffffu ? 0 : (int)b;
+}
+
+extern "C" int vis_attn_prefill_split(const void* Q, const void* K, const void* Vt, void* O, const void* work,
+                                      int n_work, int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo,
+                                      float scale, int n_pairs, void* ws, long long ws_bytes, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  const int need = vis_attn_split_ws_bytes(n_pairs, Hq);
+  if (HD != 80 || n_pairs <= 0 || !ws || need == 0 || ws_bytes < need) return VIS_ERR_ARG;
+  if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * HD || n_work > 65535) return VIS_ERR_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
+  if ((uintptr_t)ws & 255) return VIS_ERR_ARG;
+  AttnArgs p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.work = (const int4*)work;
+  p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.q_row0 = 0;
+  p.ws_count = (int*)ws;
+  p.ws_part = (float*)((char*)ws + att_split_count_bytes(n_pairs, Hq));
+  p.n_pairs = n_pairs;
+  vis_clear_error();
+  hipLaunchKernelGGL(attn_vit32_kernel, dim3(Hq, n_work), dim3(256), 0, stream, p);
   return vis_check_launch();
 }

@@ -297,7 +297,9 @@ class Qwen2VLEngine:
         if work is None:
             if len(self._vis_work_cache) >= 16:
                 self._vis_work_cache.clear()
-            work = self._vis_work_cache[tuple(segs)] = hip.make_attn_work(segs, False, dev, heads=Hh)
+            # key-split plan for long segments (one 1024 x 1024 image: 9 of 39 row blocks); VIS_ATTN_SPLIT=0: plain items (A/B)
+            work = self._vis_work_cache[tuple(segs)] = hip.make_vit_attn_plan(
+                segs, dev, Hh, split=(D == 80 and os.environ.get("VIS_ATTN_SPLIT", "1") != "0"))
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
@@ -317,7 +319,7 @@ class Qwen2VLEngine:
                 hip.quant_rows_fp8(x, xq, sx, norm_w=b.ln1_w, norm_b=b.ln1_b, eps=1e-6)
                 hip.gemm_fp8(xq, sx, *q8["qkv_w"], bias=b.qkv_b, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
-                hip.attn_prefill(q, k, vt, att, work, False, scale)
+                hip.attn_prefill_plan(q, k, vt, att, work, scale)
                 hip.quant_rows_fp8(att, xq, sx)
                 hip.gemm_fp8(xq, sx, *q8["proj_w"], bias=b.proj_b, residual=x, out=x)
                 hip.quant_rows_fp8(x, xq, sx, norm_w=b.ln2_w, norm_b=b.ln2_b, eps=1e-6)
@@ -337,7 +339,7 @@ class Qwen2VLEngine:
             for bi, b in enumerate(w.vit):
                 hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
                 hip.qkv_rope_split(qkv, cos, sin, q, k, None, vt, Hh, Hh, D)
-                hip.attn_prefill(q, k, vt, att, work, False, scale)
+                hip.attn_prefill_plan(q, k, vt, att, work, scale)
                 hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
                 hip.layernorm(x, b.ln2_w, b.ln2_b, 1e-6, out=y)
                 hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_QUICKGELU, out=hmid)

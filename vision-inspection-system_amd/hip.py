@@ -34,6 +34,8 @@ _SIGS = {
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_attn_prefill_rows": "ppppp" + "iiiiiiiii" + "f" + "i" + "p",
     "vis_attn_prefill_pairs": "ppppp" + "iiiiiiii" + "f" + "i" + "p",
+    "vis_attn_split_ws_bytes": "ii",
+    "vis_attn_prefill_split": "ppppp" + "iiiiiiii" + "f" + "i" + "p" + "l" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_gemv_fp8w": "ppppppp" + "iiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
@@ -364,6 +366,81 @@ def plan_attn_items(segments, heads: int, block_q: int = 128, slots: int = ATTN_
         half.append((q0, h1, s, e))
         half.append((q0 + h1, qn - h1, s, e))
     return full[:k] + half
+
+
+ATTN_SPLIT_MIN_BLOCKS = 24      # segments shorter than this many 128-row blocks are never key-split
+
+
+def plan_attn_items_split(segments, heads: int, block_q: int = 128, slots: int = ATTN_SLOTS):
+    """Non-causal head_dim-80 work items with KEY-SPLIT blocks (vis_attn_prefill_split) -> (items, n_pairs).
+
+    A segment of nb >= ATTN_SPLIT_MIN_BLOCKS row blocks gets its last min(whole blocks, slots // heads - nb) whole
+    blocks cut in two along the keys (at the multiple of 64 nearest the middle of the segment): one 1024 x 1024 image at
+    16 heads becomes 30 whole + 2 x 9 half workgroups per head = exactly the 768 resident slots, two whole and one half
+    per CU, instead of 2450 wave tasks of which some SIMDs get three and others two (measured 171 -> 154 us).
+    The rule looks at ONE segment and the head count only - never at what else shares the launch - so an image's
+    features stay bit-identical whether it runs alone or stacked with others.  Whole items first, split ones last."""
+    whole, split, n_pairs = [], [], 0
+    budget = slots // max(heads, 1)
+    for (s, e) in segments:
+        blocks = [(q0, min(block_q, e - q0)) for q0 in range(s, e, block_q)]
+        nb = len(blocks)
+        n_whole = sum(1 for b in blocks if b[1] == block_q)
+        ns = min(n_whole, max(0, budget - nb)) if (heads > 0 and nb >= ATTN_SPLIT_MIN_BLOCKS) else 0
+        mid = ((s + e) // 2 + 32) // 64 * 64
+        if not (s < mid < e):
+            ns = 0
+        first_split = n_whole - ns
+        for i, (q0, qn) in enumerate(blocks):
+            if qn == block_q and i >= first_split and ns > 0:
+                for part, (k0, k1) in enumerate(((s, mid), (mid, e))):
+                    split.append((q0, qn | ((1 | part << 1 | n_pairs << 2) << 8), k0, k1))
+                n_pairs += 1
+            else:
+                whole.append((q0, qn, s, e))
+    return whole + split, n_pairs
+
+
+class AttnPlan:
+    """Work list of one ViT attention layout (+ the key-split workspace when the plan has split items)."""
+    __slots__ = ("work", "n_pairs", "ws", "heads")
+
+    def __init__(self, work, n_pairs, ws, heads):
+        self.work, self.n_pairs, self.ws, self.heads = work, n_pairs, ws, heads
+
+
+def make_vit_attn_plan(segments, device, heads: int, split: bool = True) -> AttnPlan:
+    """Plan for attn_prefill_plan over independent token ranges [(start, end)] (non-causal, head_dim 80)."""
+    n_pairs = 0
+    if split:
+        items, n_pairs = plan_attn_items_split(segments, heads)
+    if n_pairs == 0:
+        return AttnPlan(make_attn_work(segments, False, device, heads=heads), 0, None, heads)
+    work = torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+    nbytes = int(load().vis_attn_split_ws_bytes(n_pairs, heads))
+    if nbytes <= 0:
+        raise HipLibraryError("vis_attn_split_ws_bytes refused the plan")
+    return AttnPlan(work, n_pairs, torch.zeros(nbytes, dtype=torch.uint8, device=device), heads)
+
+
+def attn_prefill_plan(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, plan: AttnPlan,
+                      scale: float) -> torch.Tensor:
+    """Non-causal attention over plan's items; q [Hq,S,80], k [Hkv,T,80], vt [Hkv,80,ld] -> out [S, Hq*80].  One launch
+    at a time per plan (its workspace is shared by the launches that use it, in stream order)."""
+    if plan.n_pairs == 0:
+        return attn_prefill(q, k, vt, out, plan.work, False, scale)
+    _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
+    Hq, S, HD = q.shape
+    Hkv, T, _ = k.shape
+    if not (q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()):
+        raise HipLibraryError("attn_prefill_plan: contiguous tensors required")
+    if vt.shape[0] != Hkv or vt.shape[1] != HD or out.shape[0] != S or out.stride(1) != 1 or Hq != plan.heads:
+        raise HipLibraryError("attn_prefill_plan: bad shapes")
+    rc = load().vis_attn_prefill_split(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(plan.work), plan.work.shape[0], Hq, Hkv,
+                                       HD, S, T, vt.shape[2], out.stride(0), scale, plan.n_pairs, _ptr(plan.ws),
+                                       plan.ws.numel(), _stream())
+    _check(rc, "vis_attn_prefill_split")
+    return out
 
 
 def make_attn_work(segments, causal: bool, device, block_q: int = 128, heads: int = 0) -> torch.Tensor:
