@@ -22,8 +22,8 @@ if os.environ.get("VIS_ATTN_FULLS") is not None and not causal:   # experiment: 
     nf = int(os.environ["VIS_ATTN_FULLS"])
     items = [(q0, 128, 0, S) for q0 in range(0, nf * 128, 128)] + [(q0, min(64, S - q0), 0, S) for q0 in range(nf * 128, S, 64)]
     work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
-if os.environ.get("VIS_ATTN_SPLIT") is not None and not causal:   # TIMING experiment (results of the split rows are wrong):
-    nf = int(os.environ["VIS_ATTN_SPLIT"])                           # nf full items per head, the rest as two half-key items
+if os.environ.get("VIS_ATTN_FAKE_SPLIT") is not None and not causal:   # TIMING experiment (results of the split rows are wrong):
+    nf = int(os.environ["VIS_ATTN_FAKE_SPLIT"])                           # nf full items per head, the rest as two half-key items
     order = os.environ.get("VIS_ATTN_SPLIT_ORDER", "last")
     half = ((S // 2) + 63) // 64 * 64
     full = [(q0, min(128, S - q0), 0, S) for q0 in range(0, min(S, nf * 128), 128)]
@@ -42,13 +42,19 @@ if os.environ.get("VIS_ATTN_CAUSAL") is not None and causal:   # experiment: cau
         items = [x for pair in zip(hv, lt + [None] * (len(hv) - len(lt))) for x in pair if x is not None]
     work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
 print('items', work.shape[0], 'half', int((work[:, 1] <= 64).sum()))
+run = lambda: hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
+if (not causal and a.plan and os.environ.get("VIS_ATTN_SPLIT", "1") != "0" and os.environ.get("VIS_ATTN_FULLS") is None
+        and os.environ.get("VIS_ATTN_FAKE_SPLIT") is None):
+    vplan = hip.make_vit_attn_plan([(0, S)], dev, Hq)        # what the engine launches: key-split items merged in the kernel
+    print('key-split plan: items', vplan.work.shape[0], 'pairs', vplan.n_pairs)
+    run = lambda: hip.attn_prefill_plan(q, k, vt, o, vplan, HD ** -0.5)
 for _ in range(2):
-    hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
+    run()
 torch.cuda.synchronize()
 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 s.record()
 for _ in range(a.reps):
-    hip.attn_prefill(q, k, vt, o, work, causal, HD ** -0.5)
+    run()
 e.record()
 torch.cuda.synchronize()
 t = s.elapsed_time(e) / a.reps * 1e-3

@@ -394,7 +394,8 @@ class Qwen2VLEngine:
                 self._vis_work_cache.clear()
             lay = self._vis_work_cache[key] = (
                 torch.from_numpy(row_idx).to(dev), torch.from_numpy(rev).to(dev),
-                hip.make_attn_work(win_segs, False, dev, heads=Hh), hip.make_attn_work(full_segs, False, dev, heads=Hh),
+                hip.make_vit_attn_plan(win_segs, dev, Hh, split=False),
+                hip.make_vit_attn_plan(full_segs, dev, Hh, split=(D == 80 and os.environ.get("VIS_ATTN_SPLIT", "1") != "0")),
                 torch.from_numpy(cp[row_idx]).to(dev), torch.from_numpy(sp[row_idx]).to(dev))
         row_idx, rev, work_win, work_full, cw, sw = lay
         xw = torch.empty_like(x)
@@ -416,7 +417,7 @@ class Qwen2VLEngine:
         for bi, b in enumerate(w.vit):
             hip.gemm(y, b.qkv_w, bias=b.qkv_b, out=qkv)
             hip.qkv_rope_split(qkv, cw, sw, q, k, None, vt, Hh, Hh, D)
-            hip.attn_prefill(q, k, vt, att, work_full if bi in cfg.v_fullatt else work_win, False, scale)
+            hip.attn_prefill_plan(q, k, vt, att, work_full if bi in cfg.v_fullatt else work_win, scale)
             hip.gemm(att, b.proj_w, bias=b.proj_b, residual=x, out=x)
             hip.rmsnorm(x, b.ln2_w, 1e-6, out=y)
             hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_SWIGLU, out=hmid)
