@@ -11,7 +11,8 @@ dev = torch.device("cuda:0")
 hip.load()
 hog = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 side = torch.cuda.Stream()
-shapes = [(2249, 12288, 3584), (2304, 12288, 1152), (4900, 5120, 1280), (2049, 12296, 2176), (8192, 8192, 1024)]
+shapes = [(2249, 12288, 3584), (2304, 12288, 1152), (4900, 5120, 1280), (2049, 12296, 2176), (8192, 8192, 1024),
+          (2249, 3584, 3584), (4900, 1280, 1280), (2249, 1536, 3584), (1225, 5120, 5120)]   # the last four: 128 x 256 half-tiles
 bad = 0
 for (M, N, K) in shapes:
     g = torch.Generator(device="cpu").manual_seed(M + K)

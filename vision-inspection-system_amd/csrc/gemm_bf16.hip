@@ -978,6 +978,172 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_256x256_pp_kernel(GemmArgs p
 }
 
 // ---------------------------------------------------------------------------
+// 128 x 256 x 64 ping-pong tile: the half-height form of the kernel above, for grids whose 256 x 256 tiling is ragged
+// (LLM o: 9 x 14 = 126 tiles on 256 CUs; ViT proj: 20 x 5 = 100; the gate/up remainder columns) and which so far ran on
+// the 128 x 128 kernel at a quarter of the ping-pong tile's rate.  Same eight waves, same two-groups-half-a-phase-apart
+// pairing, same MFMA, operand order and K order (results are bit-identical to every other bf16 GEMM kernel here); a wave
+// owns 64 x 64 of the output, so a K-tile is TWO phases:
+//   phase 1: reads B-h0 (4 x ds_read_b128) + A (8) | s_barrier | 16 MFMAs (columns 0..31 of the wave) | s_barrier
+//   phase 2: reads B-h1 (4)                        | s_barrier | 16 MFMAs (columns 32..63)            | s_barrier
+// LDS: THREE K-tile buffers of three 16 KiB slots (B-h0, A, B-h1 = 144 KiB); tile t + 2 is staged while tile t is
+// consumed - B-h0 and A in phase 1, B-h1 in phase 2, each into the slot of tile t - 1 that was last read two phases
+// earlier (the WAR distance the kernel above needs between a read and the restage of its slot, with the groups half a
+// phase apart).  One counted wait per K-tile: vmcnt(6) at the end of phase 2 of tile t leaves only the six LDS-DMA
+// instructions of tile t + 2 in flight, so tile t + 1 is complete before its first read (next phase, after the barrier).
+// Bytes per flop are 1.5 x the 256 x 256 tile's (48 KiB of operands per K-tile for half the MFMAs), so this kernel sits
+// nearer the CU's LDS-DMA rate than the MFMA pipe; it is chosen only where whole rounds of 256 x 256 tiles do not exist.
+#define GEMM6_SLOT_BYTES 16384
+#define GEMM6_BUF_BYTES 49152
+#define GEMM6_LDS_BYTES 147456
+#define G6_B0 0
+#define G6_A 1
+#define G6_B1 2
+
+__global__ __launch_bounds__(512, 2) void gemm_bf16_128x256_pp_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char lds6[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, h = lane >> 4;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  const int id = xcd_remap(blockIdx.x, nwg);
+  const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
+  const int m0 = tm * 128, n0 = tn * 256;
+
+  // staging: slot row hr = c >> 3 (c = i*512 + tid), 16-byte chunk (c & 7) ^ (hr & 7); A slot row = tile row,
+  // B-h(q) slot row hr = column (hr >> 5) * 64 + q * 32 + (hr & 31) (the columns every wave reads in phase q + 1)
+  uint32_t a_off[2], w_off[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid;
+    const int hr = c >> 3;
+    const int ch = (c & 7) ^ (hr & 7);
+    a_off[i] = (uint32_t)(min(m0 + hr, p.M - 1) - m0) * (uint32_t)(p.lda * 2) + ch * 16;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int wrow = (hr >> 5) * 64 + q * 32 + (hr & 31);
+      w_off[q][i] = (uint32_t)(min(n0 + wrow, p.N - 1) - n0) * (uint32_t)(p.ldw * 2) + ch * 16;
+    }
+  }
+  const int nk = p.K / GEMM_BK;
+  const char* a_base = (const char*)(p.A + (size_t)m0 * p.lda);
+  const char* w_base = (const char*)(p.W + (size_t)n0 * p.ldw);
+  char* const wave_lds = lds6 + wave * 1024;
+
+  // one slot of buffer buf for K-tile kt; kt is clamped, a redundant stage refills a dead slot
+  auto stage = [&](int buf, int slot, int kt) {
+    kt = min(kt, nk - 1);
+    const char* src = (slot == G6_A ? a_base : w_base) + kt * (GEMM_BK * 2);
+    char* dst = wave_lds + buf * GEMM6_BUF_BYTES + slot * GEMM6_SLOT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const uint32_t off = (slot == G6_A) ? a_off[i] : (slot == G6_B0 ? w_off[0][i] : w_off[1][i]);
+      const __attribute__((address_space(1))) void* g = (const __attribute__((address_space(1))) void*)(src + off);
+      __attribute__((address_space(3))) void* l = (__attribute__((address_space(3))) void*)(dst + i * 8192);
+      __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int sw = l15 & 7;
+  const int rd_k0 = l15 * 128 + (((0 + h) ^ sw) << 4);
+  const int rd_k1 = l15 * 128 + (((4 + h) ^ sw) << 4);
+  const int a_rd = wr * (64 * 128);   // + ii * 2048
+  const int b_rd = wc * (32 * 128);   // + jj * 2048
+  bf16x8 af[4][2], bq0[2][2], bq1[2][2];
+  auto read_a = [&](int buf) {
+    const char* base = lds6 + buf * GEMM6_BUF_BYTES + G6_A * GEMM6_SLOT_BYTES + a_rd;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      af[ii][0] = *(const bf16x8*)(base + ii * 2048 + rd_k0);
+      af[ii][1] = *(const bf16x8*)(base + ii * 2048 + rd_k1);
+    }
+  };
+  auto read_b = [&](bf16x8 (&bq)[2][2], int buf, int qb) {
+    const char* base = lds6 + buf * GEMM6_BUF_BYTES + (qb ? G6_B1 : G6_B0) * GEMM6_SLOT_BYTES + b_rd;
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      bq[jj][0] = *(const bf16x8*)(base + jj * 2048 + rd_k0);
+      bq[jj][1] = *(const bf16x8*)(base + jj * 2048 + rd_k1);
+    }
+  };
+#define G6_BAR()                                  \
+  do {                                            \
+    __builtin_amdgcn_sched_barrier(0);            \
+    asm volatile("s_barrier" ::: "memory");       \
+    __builtin_amdgcn_sched_barrier(0);            \
+  } while (0)
+#define G6_MFMA(QB, BQ)                                                                                       \
+  do {                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                        \
+    __builtin_amdgcn_s_setprio(1);                                                                            \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                                          \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii)                                                          \
+    _Pragma("unroll") for (int jj = 0; jj < 2; ++jj)                                                          \
+      acc[ii][(QB) * 2 + jj] =                                                                                \
+          __builtin_amdgcn_mfma_f32_16x16x32_bf16(BQ[jj][kh], af[ii][kh], acc[ii][(QB) * 2 + jj], 0, 0, 0);   \
+    __builtin_amdgcn_s_setprio(0);                                                                            \
+  } while (0)
+  // the two phases of K-tile T in buffer B; tile T + 2 goes to buffer NB = (B + 2) % 3
+#define G6_TILE(B, NB, T)                                 \
+  do {                                                    \
+    read_b(bq0, B, 0);                                    \
+    __builtin_amdgcn_sched_barrier(0);                    \
+    read_a(B);                                            \
+    stage(NB, G6_B0, (T) + 2);                            \
+    stage(NB, G6_A, (T) + 2);                             \
+    G6_BAR();                                             \
+    G6_MFMA(0, bq0);                                      \
+    G6_BAR();                                             \
+    read_b(bq1, B, 1);                                    \
+    stage(NB, G6_B1, (T) + 2);                            \
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      \
+    G6_BAR();                                             \
+    G6_MFMA(1, bq1);                                      \
+    G6_BAR();                                             \
+  } while (0)
+
+  // prologue: tiles 0 and 1 complete (buffers 0, 1): 12 instructions, vmcnt(6) = tile 0 has landed
+  stage(0, G6_B0, 0); stage(0, G6_A, 0); stage(0, G6_B1, 0);
+  stage(1, G6_B0, 1); stage(1, G6_A, 1); stage(1, G6_B1, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  G6_BAR();
+  if (wr == 1) G6_BAR();   // stagger: group 1 runs one barrier behind group 0
+
+  int t = 0;
+  for (; t + 2 < nk; t += 3) {
+    G6_TILE(0, 2, t);
+    G6_TILE(1, 0, t + 1);
+    G6_TILE(2, 1, t + 2);
+  }
+  if (t < nk) {
+    G6_TILE(0, 2, t);
+    if (t + 1 < nk) G6_TILE(1, 0, t + 1);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // redundant trailing stages
+  if (wr == 0) G6_BAR();   // pay the stagger back: every wave has now executed the same number of barriers
+#undef G6_TILE
+#undef G6_MFMA
+#undef G6_BAR
+
+  if (p.wide) {
+    // as in the kernel above: one more barrier for everyone, then the buffers are staging space
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_wide_dispatch<4, 4>(p, acc, m0 + wr * 64, n0 + wc * 64, lane, lds6 + wave * 16384);
+    return;
+  }
+  gemm_epilogue_n(p, acc, m0 + wr * 64, n0 + wc * 64, l15, h, 4);
+}
+
+// ---------------------------------------------------------------------------
 // Batched decode projection (M = in-flight sequences <= 16): a pure weight-streaming problem, so the kernel is
 // built around BYTES IN FLIGHT, not around the MFMA.
 //  * The (128-column tile, 64-wide K-step) pairs of the whole projection form ONE sequence of
@@ -1388,6 +1554,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_finalize_kernel(GemmArgs p) {
 //  * 256x192 / 256x128 forms of the same pipelined kernel (NT = 3 / 2): problems whose grid is then one (nearly) full
 //    round - LLM qkv 9 x 24 = 216 tiles (0.095 -> 0.071 ms against 1.27 rounds of 128x128 tiles), LLM o 9 x 28 = 252,
 //    ViT fc2 20 x 10 = 200; the older 3-stage 256x128 kernel (VIS_GEMM_TILE=2) is 3-5 % slower and kept for A/B;
+//  * 128x256 ping-pong half-tiles (1 WG/CU): what would otherwise go to 128x128 tiles, when the half-tile grid needs
+//    no more rounds (LLM o, ViT proj, the gate/up remainder columns, the merger);
 //  * 128x128 (2 WG/CU): everything else.
 static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
   static const int forced = [] { const char* e = getenv("VIS_GEMM_TILE"); return e ? atoi(e) : 0; }();
@@ -1435,6 +1603,26 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
       p.tiles_n = tn1;
       hipLaunchKernelGGL(gemm_bf16_256xN_kernel<2>, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM4_LDS_BYTES, stream, p);
     }
+    return VIS_OK;
+  }
+  // 128 x 256 ping-pong half-tiles wherever the 128 x 128 kernel would run and the half-tile grid needs no more rounds
+  // than its grid does (LLM o: 252 half-tiles = one round, 74.9 -> 68.0 us; ViT proj 195: 36.4 -> 33.6; the gate/up
+  // remainder 108: 62.0 -> 56.6 - tools/gemm_tiles_ab.py, cold caches).  Its K-tile costs 1.14 us against the 128 x 128
+  // tile's 1.2 us for HALF the work: both sit at the CU's LDS bandwidth (176 KiB of fragment reads + LDS-DMA writes per
+  // K-tile here), which is why the gain is 9 % and not the 40 % the MFMA count alone would give.  VIS_GEMM_HALF=0: off.
+  static const bool half_ok = [] { const char* e = getenv("VIS_GEMM_HALF"); return !(e && atoi(e) == 0); }();
+  const int t6 = ((M + 127) / 128) * tn4;
+  const bool half = forced == 8 || (!forced && half_ok && !huge && M > 128 && N >= 256 && K >= 512 &&
+                                    (t6 + 255) / 256 <= (t1 + 511) / 512);
+  if (half) {
+    static const bool attr6_ok = [] {
+      return hipFuncSetAttribute((const void*)gemm_bf16_128x256_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 GEMM6_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr6_ok) return VIS_ERR_LAUNCH;
+    p.tiles_m = (M + 127) / 128;
+    p.tiles_n = tn4;
+    hipLaunchKernelGGL(gemm_bf16_128x256_pp_kernel, dim3(p.tiles_m * p.tiles_n), dim3(512), GEMM6_LDS_BYTES, stream, p);
     return VIS_OK;
   }
   if (huge) {
