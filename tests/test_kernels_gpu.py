@@ -348,6 +348,19 @@ def test_attn_vit_key_split_plan(hip, device, S, H):
     assert all(torch.equal(outs[0], o) for o in outs[1:]), "key-split merge must be deterministic"
     n_count = plan.n_pairs * H
     assert int(plan.ws[:n_count * 4].view(torch.int32).abs().sum()) == 0, "counters must return to zero"
+    # two streams launching the same plan at the same time: each has its own workspace
+    cur = torch.cuda.current_stream(device)
+    side = [torch.cuda.Stream(device=device) for _ in range(2)]
+    side_out = [torch.full((S, H * HD), 5.0, dtype=torch.bfloat16, device=device) for _ in side]
+    for st, o in zip(side, side_out):
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            for _ in range(6):
+                hip.attn_prefill_plan(q, k, vt, o, plan, scale)
+    for st in side:
+        cur.wait_stream(st)
+    torch.cuda.synchronize()
+    assert all(torch.equal(outs[0], o) for o in side_out), "concurrent launches of one plan on two streams"
     plain = torch.zeros_like(outs[0])
     hip.attn_prefill(q, k, vt, plain, hip.make_attn_work([(0, S)], False, device, heads=H), False, scale)
     whole_rows = S - plan.n_pairs * 128 - (S % 128)

@@ -402,11 +402,22 @@ def plan_attn_items_split(segments, heads: int, block_q: int = 128, slots: int =
 
 
 class AttnPlan:
-    """Work list of one ViT attention layout (+ the key-split workspace when the plan has split items)."""
-    __slots__ = ("work", "n_pairs", "ws", "heads")
+    """Work list of one ViT attention layout (+ the key-split workspaces when the plan has split items: one per stream
+    that launches it - launches of one stream are ordered, two streams must not share counters and partial slots)."""
+    __slots__ = ("work", "n_pairs", "ws_bytes", "heads", "_ws")
 
-    def __init__(self, work, n_pairs, ws, heads):
-        self.work, self.n_pairs, self.ws, self.heads = work, n_pairs, ws, heads
+    def __init__(self, work, n_pairs, ws_bytes, heads):
+        self.work, self.n_pairs, self.ws_bytes, self.heads = work, n_pairs, ws_bytes, heads
+        self._ws = {}
+
+    @property
+    def ws(self) -> "torch.Tensor":
+        """The workspace of the CURRENT stream (zeroed on that stream when first used)."""
+        key = torch.cuda.current_stream(self.work.device).cuda_stream
+        w = self._ws.get(key)
+        if w is None:
+            w = self._ws[key] = torch.zeros(self.ws_bytes, dtype=torch.uint8, device=self.work.device)
+        return w
 
 
 def make_vit_attn_plan(segments, device, heads: int, split: bool = True) -> AttnPlan:
@@ -415,18 +426,18 @@ def make_vit_attn_plan(segments, device, heads: int, split: bool = True) -> Attn
     if split:
         items, n_pairs = plan_attn_items_split(segments, heads)
     if n_pairs == 0:
-        return AttnPlan(make_attn_work(segments, False, device, heads=heads), 0, None, heads)
+        return AttnPlan(make_attn_work(segments, False, device, heads=heads), 0, 0, heads)
     work = torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
     nbytes = int(load().vis_attn_split_ws_bytes(n_pairs, heads))
     if nbytes <= 0:
         raise HipLibraryError("vis_attn_split_ws_bytes refused the plan")
-    return AttnPlan(work, n_pairs, torch.zeros(nbytes, dtype=torch.uint8, device=device), heads)
+    return AttnPlan(work, n_pairs, nbytes, heads)
 
 
 def attn_prefill_plan(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, plan: AttnPlan,
                       scale: float) -> torch.Tensor:
-    """Non-causal attention over plan's items; q [Hq,S,80], k [Hkv,T,80], vt [Hkv,80,ld] -> out [S, Hq*80].  One launch
-    at a time per plan (its workspace is shared by the launches that use it, in stream order)."""
+    """Non-causal attention over plan's items; q [Hq,S,80], k [Hkv,T,80], vt [Hkv,80,ld] -> out [S, Hq*80].  Launches of
+    one stream are ordered on that stream's workspace; different streams get their own."""
     if plan.n_pairs == 0:
         return attn_prefill(q, k, vt, out, plan.work, False, scale)
     _bf16(q, "q"); _bf16(k, "k"); _bf16(vt, "vt"); _bf16(out, "out")
@@ -436,9 +447,10 @@ def attn_prefill_plan(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: t
         raise HipLibraryError("attn_prefill_plan: contiguous tensors required")
     if vt.shape[0] != Hkv or vt.shape[1] != HD or out.shape[0] != S or out.stride(1) != 1 or Hq != plan.heads:
         raise HipLibraryError("attn_prefill_plan: bad shapes")
+    ws = plan.ws
     rc = load().vis_attn_prefill_split(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(plan.work), plan.work.shape[0], Hq, Hkv,
-                                       HD, S, T, vt.shape[2], out.stride(0), scale, plan.n_pairs, _ptr(plan.ws),
-                                       plan.ws.numel(), _stream())
+                                       HD, S, T, vt.shape[2], out.stride(0), scale, plan.n_pairs, _ptr(ws), ws.numel(),
+                                       _stream())
     _check(rc, "vis_attn_prefill_split")
     return out
 
