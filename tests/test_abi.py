@@ -147,3 +147,22 @@ def test_attention_key_split_planner():
     assert {(q0, y & 0xff, y >> 8 & 3, k0, k1) for (q0, y, k0, k1) in one} <= {(q0, y & 0xff, y >> 8 & 3, k0, k1) for (q0, y, k0, k1) in two}
     assert hip.plan_attn_items_split([(i * 64, (i + 1) * 64) for i in range(80)], 16)[1] == 0
     assert hip.plan_attn_items_split([(0, 2000)], 16)[1] == 0
+
+
+def test_attention_key_split_entry_refuses_bad_arguments_without_gpu(lib_path):
+    """vis_attn_split_ws_bytes is host arithmetic; vis_attn_prefill_split checks head_dim, workspace pointer, alignment and
+    size before any HIP call."""
+    from vision_inspection_system_amd import hip
+    lib = hip.load()
+    need = lib.vis_attn_split_ws_bytes(9, 16)
+    assert need == 256 * ((9 * 16 * 4 + 255) // 256) + 9 * 16 * 2 * 128 * 84 * 4
+    assert lib.vis_attn_split_ws_bytes(0, 16) == 0 and lib.vis_attn_split_ws_bytes(9, 0) == 0
+    assert lib.vis_attn_split_ws_bytes(1 << 20, 64) == 0            # more than an int holds
+    P = 4096                                                        # never dereferenced: every call below fails a check first
+    args = lambda HD=80, n_pairs=9, ws=P, ws_bytes=need: (P, P, P, P, P, 48, 16, 16, HD, 4900, 4900, 4928, 1280, 0.11,
+                                                            n_pairs, ws, ws_bytes, None)
+    assert lib.vis_attn_prefill_split(*args(HD=128)) == 1
+    assert lib.vis_attn_prefill_split(*args(n_pairs=0)) == 1
+    assert lib.vis_attn_prefill_split(*args(ws=None)) == 1
+    assert lib.vis_attn_prefill_split(*args(ws=P + 16)) == 1        # 256-byte alignment
+    assert lib.vis_attn_prefill_split(*args(ws_bytes=need - 1)) == 1
