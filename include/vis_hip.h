@@ -207,6 +207,17 @@ int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* 
                   const void* norm_w, void* y, int N, int K, int ldw, int act, int out_f32, float eps,
                   vis_stream_t stream);
 
+/* K10 for a handful of in-flight sequences (1 <= B <= 4): vis_gemv_bf16 / vis_gemv_fp8w over B input rows
+ * (x [B][ldx], y [B][ldy], R [B][ldr]; bias and norm_w shared).  The weights are streamed ONCE for all rows, each row's
+ * arithmetic is the single-row kernel's (bit-identical results), and - unlike vis_gemm_decode_* + vis_skinny_finalize* -
+ * there is no partial buffer and no finalisation launch.  B * K * 2 bytes of LDS (<= 152 KiB). */
+int vis_gemv_bf16_rows(const void* x, const void* W, const void* bias, const void* R, const void* norm_w, void* y,
+                       int B, int N, int K, int ldw, int ldx, int ldy, int ldr, int act, int out_f32, float eps,
+                       vis_stream_t stream);
+int vis_gemv_fp8w_rows(const void* x, const void* Wq, const void* scale, const void* bias, const void* R,
+                       const void* norm_w, void* y, int B, int N, int K, int ldw, int ldx, int ldy, int ldr, int act,
+                       int out_f32, float eps, vis_stream_t stream);
+
 /* BASELINE configs[4]: GEMM on the CDNA4 block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales).
  * C[M, N(/2)] = act((Aq Wq^T) * sa[m] * sw[n] + bias) + R with Aq [M][lda] / Wq [N][ldw] OCP e4m3 bytes, per-row f32
  * scales sa [M] (per token, vis_quant_rows_fp8) and sw [N] (per output channel); act as vis_gemm_bf16; K % 128 == 0.

@@ -208,6 +208,31 @@ def test_batched_generation_matches_single(device):
 
 
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
+def test_rows_gemv_decode_equals_single_sequence_decode(device, monkeypatch, weights):
+    """VIS_ROWS_GEMV=2 (opt-in): two in-flight sequences decode on vis_gemv_*_rows - per-row arithmetic of the
+    single-sequence step, so tokens AND logits are exactly the single-sequence ones."""
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    monkeypatch.setenv("VIS_ROWS_GEMV", "2")
+    cfg = Qwen2VLConfig.tiny()
+    eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, synth_state_dict(cfg, seed=0), device), device, max_ctx=256, max_batch=4,
+                        decode_weights=weights)
+    g = load_golden()
+    fa = [torch.from_numpy(g["frame_a"]).to(device)]
+    reqs = [(g["ids_a"].tolist(), fa), ([256, 72, 105, 33, 90, 41], [])]
+    singles, logits = [], []
+    for ids, fr in reqs:
+        singles.append(eng.generate(ids, fr, max_new_tokens=10, ignore_eos=True))
+        logits.append(eng.logits.clone())
+    for use_graph in (False, True):
+        pair = eng.generate_batch(reqs, max_new_tokens=10, ignore_eos=True, use_graph=use_graph)
+        assert pair == singles
+        for b in range(2):
+            assert torch.equal(eng.logits_b[b], logits[b].view(-1)), f"sequence {b}: logits differ from the single-sequence step"
+
+
+@pytest.mark.parametrize("weights", ["bf16", "fp8"])
 def test_batched_generation_more_than_16_sequences(device, weights):
     """17..32 (33..64) in-flight sequences use two (four) 16-row MFMA blocks in the batched projection: the tokens of a
     request are the same as in a batch of <= 16 (rows are independent; the stream-K slot order depends on (N, K) only)."""

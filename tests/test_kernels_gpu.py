@@ -1064,3 +1064,37 @@ def test_sampling_limits_and_stream_independence(hip, device):
     big = torch.full((152064,), -30.0); big[777] = 0.0
     draws = _sample_many(hip, device, big, 1.0, 2000, 3)
     assert (draws == 777).all(), f"{(draws != 777).sum()} draws left the support"
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K,act,fused", [(4608, 3584, 0, "norm+bias"), (3584, 18944, 0, "residual"),
+                                           (37888, 3584, 3, "norm"), (1000, 704, 0, "f32")])
+def test_gemv_rows_bit_identical_to_single_row(hip, device, B, N, K, act, fused):
+    """vis_gemv_bf16_rows / vis_gemv_fp8w_rows: 1..4 input rows share one pass over the weights, and every row equals the
+    single-row kernel on it bit for bit (same per-row arithmetic) - so a handful of in-flight sequences decode exactly as
+    one would alone.  Shapes: the 7B qkv / down / gate-up projections (down: 4 x 37 KiB of LDS rows) and a ragged one."""
+    g = torch.Generator(device="cpu").manual_seed(N + K + B)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(torch.bfloat16).to(device)
+    x = torch.randn((B, K), generator=g).to(torch.bfloat16).to(device)
+    n_out = N // 2 if act == 3 else N
+    bias = torch.randn((N,), generator=g).to(torch.bfloat16).to(device) if "bias" in fused else None
+    nw = (1 + 0.1 * torch.randn((K,), generator=g)).to(torch.bfloat16).to(device) if "norm" in fused else None
+    res = torch.randn((B, n_out), generator=g).to(torch.bfloat16).to(device) if "residual" in fused else None
+    odt = torch.float32 if fused == "f32" else torch.bfloat16
+    for fp8 in (False, True):
+        if fp8 and (K % 16 or (act == 3 and N % 64)):
+            continue
+        wq, sw = hip.quantize_fp8_rows(w) if fp8 else (None, None)
+        many = torch.full((B, n_out), 9.0, dtype=odt, device=device)
+        if fp8:
+            hip.gemv_fp8_rows(x, wq, sw, many, bias=bias, residual=res, norm_w=nw, act=act)
+        else:
+            hip.gemv_rows(x, w, many, bias=bias, residual=res, norm_w=nw, act=act)
+        for b in range(B):
+            one = torch.empty((n_out,), dtype=odt, device=device)
+            r = res[b] if res is not None else None
+            if fp8:
+                hip.gemv_fp8(x[b], wq, sw, one, bias=bias, residual=r, norm_w=nw, act=act)
+            else:
+                hip.gemv(x[b], w, one, bias=bias, residual=r, norm_w=nw, act=act)
+            assert torch.equal(many[b], one), f"row {b} of {B} differs from the single-row kernel (fp8={fp8})"

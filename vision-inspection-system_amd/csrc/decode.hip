@@ -31,6 +31,8 @@ struct GemvArgs {
   int act, out_f32;
   int outs_per_block;
   float eps;
+  // vis_gemv_bf16_rows: nb input rows (<= the kernel's NB) share every weight read; element strides between rows
+  int nb, ldx, ldy, ldr;
 };
 
 // NB: __builtin_bit_cast(bf16x2, v[i]) on a vector ELEMENT is miscompiled by hipcc 7.2 (always
@@ -80,37 +82,50 @@ __device__ __forceinline__ void gv_load(GvBuf& b, const GemvArgs& p, bool swiglu
   }
 }
 
-__device__ __forceinline__ void gv_consume(const GvBuf& b, const bf16_t* xs, int seg, int lane, int nch, float& a0,
-                                           float& a1) {
+// NB rows of x (xs[b * K ...]) against the task's two weight rows: the weight registers are used NB times
+template <int NB>
+__device__ __forceinline__ void gv_consume(const GvBuf& b, const bf16_t* xs, int K, int seg, int lane, int nch, float (&a0)[NB],
+                                           float (&a1)[NB]) {
 #pragma unroll
   for (int u = 0; u < GV_SEG; ++u) {
     const int c = lane + 64 * (seg * GV_SEG + u);
-    u32x4 xv = *(const u32x4*)(xs + min(c, nch - 1) * 8);
-    if (c >= nch) xv = (u32x4){0u, 0u, 0u, 0u};  // clamped duplicate chunk contributes nothing
-    a0 = dot8(b.w0[u], xv, a0);
-    a1 = dot8(b.w1[u], xv, a1);
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      u32x4 xv = *(const u32x4*)(xs + (size_t)r * K + min(c, nch - 1) * 8);
+      if (c >= nch) xv = (u32x4){0u, 0u, 0u, 0u};  // clamped duplicate chunk contributes nothing
+      a0[r] = dot8(b.w0[u], xv, a0[r]);
+      a1[r] = dot8(b.w1[u], xv, a1[r]);
+    }
   }
 }
 
-__device__ __forceinline__ void gv_finish(const GemvArgs& p, bool swiglu, int pair, int lane, float a0, float a1) {
-  a0 = wave_sum(a0);
-  a1 = wave_sum(a1);
-  if (lane != 0) return;
-  if (swiglu) {
-    ((bf16_t*)p.y)[pair] = f2bf(silu_fast(a0) * a1);
-    return;
+template <int NB>
+__device__ __forceinline__ void gv_finish(const GemvArgs& p, bool swiglu, int pair, int lane, float (&a0)[NB], float (&a1)[NB]) {
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    a0[r] = wave_sum(a0[r]);
+    a1[r] = wave_sum(a1[r]);
   }
-  const int o = 2 * pair;
-  const bool two = (o + 1 < p.N);
-  float v0 = a0, v1 = a1;
-  if (p.bias) { v0 += bf2f(p.bias[o]); if (two) v1 += bf2f(p.bias[o + 1]); }
-  if (p.R) { v0 += bf2f(p.R[o]); if (two) v1 += bf2f(p.R[o + 1]); }
-  if (p.out_f32) {
-    ((float*)p.y)[o] = v0;
-    if (two) ((float*)p.y)[o + 1] = v1;
-  } else {
-    ((bf16_t*)p.y)[o] = f2bf(v0);
-    if (two) ((bf16_t*)p.y)[o + 1] = f2bf(v1);
+  if (lane != 0) return;
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    if (r >= p.nb) break;
+    if (swiglu) {
+      ((bf16_t*)p.y)[(size_t)r * p.ldy + pair] = f2bf(silu_fast(a0[r]) * a1[r]);
+      continue;
+    }
+    const int o = 2 * pair;
+    const bool two = (o + 1 < p.N);
+    float v0 = a0[r], v1 = a1[r];
+    if (p.bias) { v0 += bf2f(p.bias[o]); if (two) v1 += bf2f(p.bias[o + 1]); }
+    if (p.R) { v0 += bf2f(p.R[(size_t)r * p.ldr + o]); if (two) v1 += bf2f(p.R[(size_t)r * p.ldr + o + 1]); }
+    if (p.out_f32) {
+      ((float*)p.y)[(size_t)r * p.ldy + o] = v0;
+      if (two) ((float*)p.y)[(size_t)r * p.ldy + o + 1] = v1;
+    } else {
+      ((bf16_t*)p.y)[(size_t)r * p.ldy + o] = f2bf(v0);
+      if (two) ((bf16_t*)p.y)[(size_t)r * p.ldy + o + 1] = f2bf(v1);
+    }
   }
 }
 
@@ -183,6 +198,25 @@ __device__ __forceinline__ void gv_stage_x(const bf16_t* __restrict__ x, bf16_t*
   }
 }
 
+// stage one row of x (optionally RMS-normalised) into LDS; called once per input row
+__device__ __forceinline__ void gv_stage_row(const bf16_t* __restrict__ x, const bf16_t* __restrict__ norm_w, bf16_t* xs, int nch,
+                                             int K, float eps, int tid, int lane, int wave) {
+  if (norm_w) {
+    gv_stage_x_rmsnorm(x, norm_w, xs, nch, K, eps, tid, lane, wave);
+  } else if (nch > 1024) {
+    gv_stage_x(x, xs, nch, tid);
+  } else if (nch <= 512) {   // both loads in flight before the first store (one L2 round trip, not two)
+    const u32x4 r0 = *(const u32x4*)(x + min(tid, nch - 1) * 8), r1 = *(const u32x4*)(x + min(tid + 256, nch - 1) * 8);
+    if (tid < nch) *(u32x4*)(xs + tid * 8) = r0;
+    if (tid + 256 < nch) *(u32x4*)(xs + (tid + 256) * 8) = r1;
+  } else {
+    for (int c = tid; c < nch; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(x + c * 8);
+  }
+}
+
+// NB = input rows sharing the weight stream (1: the single-sequence decode step; 2 / 4: vis_gemv_bf16_rows, a handful of
+// in-flight sequences - each row's arithmetic is exactly the NB = 1 kernel's, so its result is bit-identical to it)
+template <int NB>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;
@@ -201,39 +235,67 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   GvBuf A, B;
   if (n_tasks > 0) gv_load(A, p, swiglu, p_begin, 0, lane, nch);  // in flight while x is staged
 
-  // ---- stage x (optionally RMS-normalised) into LDS
-  if (p.norm_w) {
-    gv_stage_x_rmsnorm(p.x, p.norm_w, xs, nch, p.K, p.eps, tid, lane, wave);
-  } else if (nch > 1024) {
-    gv_stage_x(p.x, xs, nch, tid);
-  } else if (nch <= 512) {   // both loads in flight before the first store (one L2 round trip, not two)
-    const u32x4 r0 = *(const u32x4*)(p.x + min(tid, nch - 1) * 8), r1 = *(const u32x4*)(p.x + min(tid + 256, nch - 1) * 8);
-    if (tid < nch) *(u32x4*)(xs + tid * 8) = r0;
-    if (tid + 256 < nch) *(u32x4*)(xs + (tid + 256) * 8) = r1;
-  } else {
-    for (int c = tid; c < nch; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(p.x + c * 8);
+  // ---- stage x (optionally RMS-normalised) into LDS; rows past nb repeat the last one (computed, never stored)
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    if (r > 0) __syncthreads();   // the norm's reduction scratch is reused
+    gv_stage_row(p.x + (size_t)min(r, p.nb - 1) * p.ldx, p.norm_w, xs + (size_t)r * p.K, nch, p.K, p.eps, tid, lane, wave);
   }
   __syncthreads();
 
-  float a0 = 0.f, a1 = 0.f;
+  float a0[NB], a1[NB];
+#pragma unroll
+  for (int r = 0; r < NB; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
   int pair = p_begin, seg = 0;  // task being consumed
   for (int t = 0; t < n_tasks; t += 2) {
     // next task (t+1) -> B
     int pair1 = pair, seg1 = seg + 1;
     if (seg1 == nseg) { seg1 = 0; ++pair1; }
     if (t + 1 < n_tasks) gv_load(B, p, swiglu, pair1, seg1, lane, nch);
-    gv_consume(A, xs, seg, lane, nch, a0, a1);
-    if (seg == nseg - 1) { gv_finish(p, swiglu, pair, lane, a0, a1); a0 = 0.f; a1 = 0.f; }
+    gv_consume<NB>(A, xs, p.K, seg, lane, nch, a0, a1);
+    if (seg == nseg - 1) {
+      gv_finish<NB>(p, swiglu, pair, lane, a0, a1);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    }
     if (t + 1 >= n_tasks) break;
     // task t+2 -> A
     int pair2 = pair1, seg2 = seg1 + 1;
     if (seg2 == nseg) { seg2 = 0; ++pair2; }
     if (t + 2 < n_tasks) gv_load(A, p, swiglu, pair2, seg2, lane, nch);
-    gv_consume(B, xs, seg1, lane, nch, a0, a1);
-    if (seg1 == nseg - 1) { gv_finish(p, swiglu, pair1, lane, a0, a1); a0 = 0.f; a1 = 0.f; }
+    gv_consume<NB>(B, xs, p.K, seg1, lane, nch, a0, a1);
+    if (seg1 == nseg - 1) {
+      gv_finish<NB>(p, swiglu, pair1, lane, a0, a1);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    }
     pair = pair2;
     seg = seg2;
   }
+}
+
+// LDS of a multi-row launch: nb rows of K bf16 (the attribute is raised once per kernel instance)
+#define GV_ROWS_LDS_MAX (152 * 1024)
+
+static int gemv_bf16_launch(GemvArgs p, hipStream_t stream) {
+  const int n_pairs = (p.act == GV_ACT_SWIGLU) ? p.N / 2 : (p.N + 1) / 2;
+  // one row pair per wave until the grid reaches ~4096 waves, then several pairs per wave
+  int blocks = (n_pairs + 3) / 4;
+  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
+  if (blocks > 2048) blocks = 2048;
+  vis_clear_error();
+  if (p.nb == 1) {
+    hipLaunchKernelGGL(gemv_bf16_kernel<1>, dim3(blocks), dim3(256), (size_t)p.K * 2, stream, p);
+  } else {
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute((const void*)gemv_bf16_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, GV_ROWS_LDS_MAX) == hipSuccess &&
+             hipFuncSetAttribute((const void*)gemv_bf16_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, GV_ROWS_LDS_MAX) == hipSuccess;
+    }();
+    if (!attr_ok) return VIS_ERR_LAUNCH;
+    if (p.nb == 2) hipLaunchKernelGGL(gemv_bf16_kernel<2>, dim3(blocks), dim3(256), (size_t)p.K * 4, stream, p);
+    else hipLaunchKernelGGL(gemv_bf16_kernel<4>, dim3(blocks), dim3(256), (size_t)p.K * 8, stream, p);
+  }
+  return vis_check_launch();
 }
 
 extern "C" int vis_gemv_bf16(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,
@@ -249,14 +311,31 @@ extern "C" int vis_gemv_bf16(const void* x, const void* W, const void* bias, con
   p.norm_w = (const bf16_t*)norm_w; p.y = y;
   p.N = N; p.K = K; p.ldw = ldw; p.act = act; p.out_f32 = out_f32; p.eps = eps;
   p.outs_per_block = 0;
-  const int n_pairs = (act == GV_ACT_SWIGLU) ? N / 2 : (N + 1) / 2;
-  // one row pair per wave until the grid reaches ~4096 waves, then several pairs per wave
-  int blocks = (n_pairs + 3) / 4;
-  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
-  if (blocks > 2048) blocks = 2048;
-  vis_clear_error();
-  hipLaunchKernelGGL(gemv_bf16_kernel, dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
-  return vis_check_launch();
+  p.nb = 1; p.ldx = 0; p.ldy = 0; p.ldr = 0;
+  return gemv_bf16_launch(p, stream);
+}
+
+// K10 for a handful of in-flight sequences (B <= 4): y[b] = act(W x[b] + bias) + R[b], optional fused RMSNorm of every
+// x row - the weights are streamed ONCE for all rows, each row's arithmetic is vis_gemv_bf16's (bit-identical results),
+// and there is no partial buffer and no finalisation launch (vis_gemm_decode_bf16 + vis_skinny_finalize need both).
+extern "C" int vis_gemv_bf16_rows(const void* x, const void* W, const void* bias, const void* R, const void* norm_w,
+                                  void* y, int B, int N, int K, int ldw, int ldx, int ldy, int ldr, int act, int out_f32,
+                                  float eps, hipStream_t stream) {
+  if (!x || !W || !y || N <= 0 || K <= 0 || B < 1 || B > 4) return VIS_ERR_ARG;
+  if (K % 8 != 0 || ldw % 8 != 0 || ldx % 8 != 0 || ldx < K) return VIS_ERR_ARG;
+  const int nbk = (B == 1) ? 1 : (B == 2 ? 2 : 4);
+  if ((size_t)K * 2 * nbk > (size_t)(nbk == 1 ? 60 * 1024 : GV_ROWS_LDS_MAX)) return VIS_ERR_ARG;
+  if (act != GV_ACT_NONE && act != GV_ACT_SWIGLU) return VIS_ERR_ARG;
+  if (act == GV_ACT_SWIGLU && (N % 32 != 0 || bias || R || out_f32)) return VIS_ERR_ARG;
+  if (ldy < ((act == GV_ACT_SWIGLU) ? N / 2 : N) || (R && ldr < N)) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)norm_w) & 15) return VIS_ERR_ARG;
+  GemvArgs p;
+  p.x = (const bf16_t*)x; p.W = (const bf16_t*)W; p.bias = (const bf16_t*)bias; p.R = (const bf16_t*)R;
+  p.norm_w = (const bf16_t*)norm_w; p.y = y;
+  p.N = N; p.K = K; p.ldw = ldw; p.act = act; p.out_f32 = out_f32; p.eps = eps;
+  p.outs_per_block = 0;
+  p.nb = B; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
+  return gemv_bf16_launch(p, stream);   // three rows run on the four-row kernel (the fourth repeats the third, not stored)
 }
 
 // ---------------------------------------------------------------------------
@@ -283,6 +362,7 @@ struct GemvF8Args {
   int N, K, ldw;
   int act, out_f32;
   float eps;
+  int nb, ldx, ldy, ldr;   // vis_gemv_fp8w_rows: as in GemvArgs
 };
 
 template <int ROWS, int SEG>
@@ -319,63 +399,90 @@ __device__ __forceinline__ void gf_load(GfBuf<ROWS, SEG>& b, const GemvF8Args& p
   }
 }
 
-__device__ __forceinline__ float dot16_f8(const u32x4& w, const u32x4& xlo, const u32x4& xhi, float acc) {
-  const bf16x8 xa = __builtin_bit_cast(bf16x8, xlo), xb = __builtin_bit_cast(bf16x8, xhi);
+// the 16 weights of a 16-byte load as eight EXACT bf16 pairs (converted once, used for every input row)
+struct Gf16 {
+  bf16x2 v[8];
+};
+__device__ __forceinline__ Gf16 cvt16_f8(const u32x4& w) {
+  Gf16 r;
   // word i of w holds weights 4i..4i+3: low half -> k = 4i, 4i+1; high half -> k = 4i+2, 4i+3
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[0], 1.0f, false), __builtin_shufflevector(xa, xa, 0, 1), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[0], 1.0f, true), __builtin_shufflevector(xa, xa, 2, 3), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[1], 1.0f, false), __builtin_shufflevector(xa, xa, 4, 5), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[1], 1.0f, true), __builtin_shufflevector(xa, xa, 6, 7), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[2], 1.0f, false), __builtin_shufflevector(xb, xb, 0, 1), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[2], 1.0f, true), __builtin_shufflevector(xb, xb, 2, 3), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[3], 1.0f, false), __builtin_shufflevector(xb, xb, 4, 5), acc, false);
-  acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[3], 1.0f, true), __builtin_shufflevector(xb, xb, 6, 7), acc, false);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r.v[2 * i] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[i], 1.0f, false);
+    r.v[2 * i + 1] = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(w[i], 1.0f, true);
+  }
+  return r;
+}
+__device__ __forceinline__ float dot16_f8(const Gf16& w, const u32x4& xlo, const u32x4& xhi, float acc) {
+  const bf16x8 xa = __builtin_bit_cast(bf16x8, xlo), xb = __builtin_bit_cast(bf16x8, xhi);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[0], __builtin_shufflevector(xa, xa, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[1], __builtin_shufflevector(xa, xa, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[2], __builtin_shufflevector(xa, xa, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[3], __builtin_shufflevector(xa, xa, 6, 7), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[4], __builtin_shufflevector(xb, xb, 0, 1), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[5], __builtin_shufflevector(xb, xb, 2, 3), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[6], __builtin_shufflevector(xb, xb, 4, 5), acc, false);
+  acc = __builtin_amdgcn_fdot2_f32_bf16(w.v[7], __builtin_shufflevector(xb, xb, 6, 7), acc, false);
   return acc;
 }
 
-template <int ROWS, int SEG>
-__device__ __forceinline__ void gf_consume(const GfBuf<ROWS, SEG>& b, const bf16_t* xs, int seg, int lane, int nch,
-                                           float* a) {
+template <int ROWS, int SEG, int NB>
+__device__ __forceinline__ void gf_consume(const GfBuf<ROWS, SEG>& b, const bf16_t* xs, int K, int seg, int lane, int nch,
+                                           float (&a)[NB][ROWS]) {
 #pragma unroll
   for (int u = 0; u < SEG; ++u) {
     const int c = lane + 64 * (seg * SEG + u);
     const int cc = min(c, nch - 1);
-    u32x4 xlo = *(const u32x4*)(xs + cc * 16);
-    u32x4 xhi = *(const u32x4*)(xs + cc * 16 + 8);
-    if (c >= nch) { xlo = (u32x4){0u, 0u, 0u, 0u}; xhi = xlo; }  // clamped duplicate chunk contributes nothing
+    u32x4 xlo[NB], xhi[NB];
 #pragma unroll
-    for (int i = 0; i < ROWS; ++i) a[i] = dot16_f8(b.w[i][u], xlo, xhi, a[i]);
-  }
-}
-
-template <int ROWS>
-__device__ __forceinline__ void gf_finish(const GemvF8Args& p, bool swiglu, int quad, int lane, float* a) {
-#pragma unroll
-  for (int i = 0; i < ROWS; ++i) a[i] = wave_sum(a[i]);
-  if (lane != 0) return;
-  int r[ROWS];
-  gf_rows<ROWS>(p, swiglu, quad, r);
-  if (swiglu) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 2; ++i) {
-      const float g = a[2 * i] * p.scale[r[2 * i]], u = a[2 * i + 1] * p.scale[r[2 * i + 1]];
-      ((bf16_t*)p.y)[(ROWS / 2) * quad + i] = f2bf(silu_fast(g) * u);
+    for (int r = 0; r < NB; ++r) {
+      xlo[r] = *(const u32x4*)(xs + (size_t)r * K + cc * 16);
+      xhi[r] = *(const u32x4*)(xs + (size_t)r * K + cc * 16 + 8);
+      if (c >= nch) { xlo[r] = (u32x4){0u, 0u, 0u, 0u}; xhi[r] = xlo[r]; }  // clamped duplicate chunk contributes nothing
     }
-    return;
-  }
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) {
-    const int o = ROWS * quad + i;
-    if (o >= p.N) break;
-    float v = a[i] * p.scale[o];
-    if (p.bias) v += bf2f(p.bias[o]);
-    if (p.R) v += bf2f(p.R[o]);
-    if (p.out_f32) ((float*)p.y)[o] = v;
-    else ((bf16_t*)p.y)[o] = f2bf(v);
+    for (int i = 0; i < ROWS; ++i) {
+      const Gf16 wv = cvt16_f8(b.w[i][u]);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) a[r][i] = dot16_f8(wv, xlo[r], xhi[r], a[r][i]);
+    }
   }
 }
 
-template <int ROWS, int SEG>
+template <int ROWS, int NB>
+__device__ __forceinline__ void gf_finish(const GemvF8Args& p, bool swiglu, int quad, int lane, float (&a)[NB][ROWS]) {
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) a[r][i] = wave_sum(a[r][i]);
+  if (lane != 0) return;
+  int rw[ROWS];
+  gf_rows<ROWS>(p, swiglu, quad, rw);
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    if (r >= p.nb) break;
+    if (swiglu) {
+#pragma unroll
+      for (int i = 0; i < ROWS / 2; ++i) {
+        const float g = a[r][2 * i] * p.scale[rw[2 * i]], u = a[r][2 * i + 1] * p.scale[rw[2 * i + 1]];
+        ((bf16_t*)p.y)[(size_t)r * p.ldy + (ROWS / 2) * quad + i] = f2bf(silu_fast(g) * u);
+      }
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+      const int o = ROWS * quad + i;
+      if (o >= p.N) break;
+      float v = a[r][i] * p.scale[o];
+      if (p.bias) v += bf2f(p.bias[o]);
+      if (p.R) v += bf2f(p.R[(size_t)r * p.ldr + o]);
+      if (p.out_f32) ((float*)p.y)[(size_t)r * p.ldy + o] = v;
+      else ((bf16_t*)p.y)[(size_t)r * p.ldy + o] = f2bf(v);
+    }
+  }
+}
+
+template <int ROWS, int SEG, int NB>
 __global__ __launch_bounds__(256) void gemv_fp8w_kernel(GemvF8Args p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;
@@ -395,46 +502,80 @@ __global__ __launch_bounds__(256) void gemv_fp8w_kernel(GemvF8Args p) {
   GfBuf<ROWS, SEG> A, B;
   if (n_tasks > 0) gf_load(A, p, swiglu, q_begin, 0, lane, nch);  // in flight while x is staged
 
-  if (p.norm_w) {
-    gv_stage_x_rmsnorm(p.x, p.norm_w, xs, nch8, p.K, p.eps, tid, lane, wave);
-  } else if (nch8 > 1024) {
-    gv_stage_x(p.x, xs, nch8, tid);
-  } else if (nch8 <= 512) {   // both loads in flight before the first store (one L2 round trip, not two)
-    const u32x4 r0 = *(const u32x4*)(p.x + min(tid, nch8 - 1) * 8), r1 = *(const u32x4*)(p.x + min(tid + 256, nch8 - 1) * 8);
-    if (tid < nch8) *(u32x4*)(xs + tid * 8) = r0;
-    if (tid + 256 < nch8) *(u32x4*)(xs + (tid + 256) * 8) = r1;
-  } else {
-    for (int c = tid; c < nch8; c += 256) *(u32x4*)(xs + c * 8) = *(const u32x4*)(p.x + c * 8);
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    if (r > 0) __syncthreads();   // the norm's reduction scratch is reused
+    gv_stage_row(p.x + (size_t)min(r, p.nb - 1) * p.ldx, p.norm_w, xs + (size_t)r * p.K, nch8, p.K, p.eps, tid, lane, wave);
   }
   __syncthreads();
 
-  float acc[ROWS];
+  float acc[NB][ROWS];
 #pragma unroll
-  for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) acc[r][i] = 0.f;
   int quad = q_begin, seg = 0;
   for (int t = 0; t < n_tasks; t += 2) {
     int quad1 = quad, seg1 = seg + 1;
     if (seg1 == nseg) { seg1 = 0; ++quad1; }
     if (t + 1 < n_tasks) gf_load(B, p, swiglu, quad1, seg1, lane, nch);
-    gf_consume(A, xs, seg, lane, nch, acc);
+    gf_consume<ROWS, SEG, NB>(A, xs, p.K, seg, lane, nch, acc);
     if (seg == nseg - 1) {
-      gf_finish<ROWS>(p, swiglu, quad, lane, acc);
+      gf_finish<ROWS, NB>(p, swiglu, quad, lane, acc);
 #pragma unroll
-      for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+      for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) acc[r][i] = 0.f;
     }
     if (t + 1 >= n_tasks) break;
     int quad2 = quad1, seg2 = seg1 + 1;
     if (seg2 == nseg) { seg2 = 0; ++quad2; }
     if (t + 2 < n_tasks) gf_load(A, p, swiglu, quad2, seg2, lane, nch);
-    gf_consume(B, xs, seg1, lane, nch, acc);
+    gf_consume<ROWS, SEG, NB>(B, xs, p.K, seg1, lane, nch, acc);
     if (seg1 == nseg - 1) {
-      gf_finish<ROWS>(p, swiglu, quad1, lane, acc);
+      gf_finish<ROWS, NB>(p, swiglu, quad1, lane, acc);
 #pragma unroll
-      for (int i = 0; i < ROWS; ++i) acc[i] = 0.f;
+      for (int r = 0; r < NB; ++r)
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) acc[r][i] = 0.f;
     }
     quad = quad2;
     seg = seg2;
   }
+}
+
+static int gemv_fp8w_launch(GemvF8Args p, hipStream_t stream) {
+  const int n_out = (p.act == GV_ACT_SWIGLU) ? p.N / 2 : p.N;
+  static const int forced = [] { const char* e = getenv("VIS_GEMV8_SHAPE"); return e ? atoi(e) : 0; }();
+  // long rows and few of them -> 2 rows x 8 chunks per task (more waves); otherwise 4 rows x 4 chunks
+  const bool two = forced ? (forced == 2) : (p.K >= 8192 || n_out <= 8192);
+  const int rows = two ? 2 : 4;
+  const int n_quads = (p.act == GV_ACT_SWIGLU) ? n_out / (rows / 2) : (n_out + rows - 1) / rows;
+  int blocks = (n_quads + 3) / 4;   // one task row-group per wave until ~4096 waves, then several per wave
+  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
+  if (blocks > 2048) blocks = 2048;
+  vis_clear_error();
+  const dim3 g(blocks), b(256);
+  if (p.nb == 1) {
+    if (two) hipLaunchKernelGGL((gemv_fp8w_kernel<2, 8, 1>), g, b, (size_t)p.K * 2, stream, p);
+    else hipLaunchKernelGGL((gemv_fp8w_kernel<4, 4, 1>), g, b, (size_t)p.K * 2, stream, p);
+    return vis_check_launch();
+  }
+  static const bool attr_ok = [] {
+    return hipFuncSetAttribute((const void*)gemv_fp8w_kernel<2, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GV_ROWS_LDS_MAX) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemv_fp8w_kernel<4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, GV_ROWS_LDS_MAX) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemv_fp8w_kernel<2, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GV_ROWS_LDS_MAX) == hipSuccess &&
+           hipFuncSetAttribute((const void*)gemv_fp8w_kernel<4, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, GV_ROWS_LDS_MAX) == hipSuccess;
+  }();
+  if (!attr_ok) return VIS_ERR_LAUNCH;
+  if (p.nb == 2) {
+    if (two) hipLaunchKernelGGL((gemv_fp8w_kernel<2, 8, 2>), g, b, (size_t)p.K * 4, stream, p);
+    else hipLaunchKernelGGL((gemv_fp8w_kernel<4, 4, 2>), g, b, (size_t)p.K * 4, stream, p);
+  } else {
+    if (two) hipLaunchKernelGGL((gemv_fp8w_kernel<2, 8, 4>), g, b, (size_t)p.K * 8, stream, p);
+    else hipLaunchKernelGGL((gemv_fp8w_kernel<4, 4, 4>), g, b, (size_t)p.K * 8, stream, p);
+  }
+  return vis_check_launch();
 }
 
 extern "C" int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* bias, const void* R,
@@ -450,19 +591,30 @@ extern "C" int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, c
   p.x = (const bf16_t*)x; p.W = (const uint8_t*)Wq; p.scale = (const float*)scale; p.bias = (const bf16_t*)bias;
   p.R = (const bf16_t*)R; p.norm_w = (const bf16_t*)norm_w; p.y = y;
   p.N = N; p.K = K; p.ldw = ldw; p.act = act; p.out_f32 = out_f32; p.eps = eps;
-  const int n_out = (act == GV_ACT_SWIGLU) ? N / 2 : N;
-  static const int forced = [] { const char* e = getenv("VIS_GEMV8_SHAPE"); return e ? atoi(e) : 0; }();
-  // long rows and few of them -> 2 rows x 8 chunks per task (more waves); otherwise 4 rows x 4 chunks
-  const bool two = forced ? (forced == 2) : (K >= 8192 || n_out <= 8192);
-  const int rows = two ? 2 : 4;
-  const int n_quads = (act == GV_ACT_SWIGLU) ? n_out / (rows / 2) : (n_out + rows - 1) / rows;
-  int blocks = (n_quads + 3) / 4;   // one task row-group per wave until ~4096 waves, then several per wave
-  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
-  if (blocks > 2048) blocks = 2048;
-  vis_clear_error();
-  if (two) hipLaunchKernelGGL((gemv_fp8w_kernel<2, 8>), dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
-  else hipLaunchKernelGGL((gemv_fp8w_kernel<4, 4>), dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
-  return vis_check_launch();
+  p.nb = 1; p.ldx = 0; p.ldy = 0; p.ldr = 0;
+  return gemv_fp8w_launch(p, stream);
+}
+
+// vis_gemv_fp8w for B <= 4 input rows (W8A16: bf16 activations, e4m3 weights streamed once for all rows); each row's
+// arithmetic is vis_gemv_fp8w's, so a handful of in-flight sequences decode bit-identically to one.
+extern "C" int vis_gemv_fp8w_rows(const void* x, const void* Wq, const void* scale, const void* bias, const void* R,
+                                  const void* norm_w, void* y, int B, int N, int K, int ldw, int ldx, int ldy, int ldr,
+                                  int act, int out_f32, float eps, hipStream_t stream) {
+  if (!x || !Wq || !scale || !y || N <= 0 || K <= 0 || B < 1 || B > 4) return VIS_ERR_ARG;
+  if (K % 16 != 0 || ldw % 16 != 0 || ldw < K || ldx % 8 != 0 || ldx < K) return VIS_ERR_ARG;
+  const int nbk = (B == 1) ? 1 : (B == 2 ? 2 : 4);
+  if ((size_t)K * 2 * nbk > (size_t)(nbk == 1 ? 60 * 1024 : GV_ROWS_LDS_MAX)) return VIS_ERR_ARG;
+  if (act != GV_ACT_NONE && act != GV_ACT_SWIGLU) return VIS_ERR_ARG;
+  if (act == GV_ACT_SWIGLU && (N % 64 != 0 || bias || R || out_f32)) return VIS_ERR_ARG;
+  if (ldy < ((act == GV_ACT_SWIGLU) ? N / 2 : N) || (R && ldr < N)) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)Wq | (uintptr_t)norm_w) & 15) return VIS_ERR_ARG;
+  if ((uintptr_t)scale & 3) return VIS_ERR_ARG;
+  GemvF8Args p;
+  p.x = (const bf16_t*)x; p.W = (const uint8_t*)Wq; p.scale = (const float*)scale; p.bias = (const bf16_t*)bias;
+  p.R = (const bf16_t*)R; p.norm_w = (const bf16_t*)norm_w; p.y = y;
+  p.N = N; p.K = K; p.ldw = ldw; p.act = act; p.out_f32 = out_f32; p.eps = eps;
+  p.nb = B; p.ldx = ldx; p.ldy = ldy; p.ldr = ldr;
+  return gemv_fp8w_launch(p, stream);
 }
 
 // ---------------------------------------------------------------------------

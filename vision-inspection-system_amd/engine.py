@@ -988,6 +988,16 @@ class Qwen2VLEngine:
     def _decode_step_batched(self, B: int) -> None:
         """Every projection = gemm_decode (weights streamed once for all B sequences, split-K f32 partials) +
         skinny_finalize (row-wise: sum, bias/residual/SwiGLU, and the RMSNorm of the NEXT projection)."""
+        # VIS_ROWS_GEMV=<n> (default 0 = off): batches of 2..n (<= 4) sequences decode on the multi-row GEMV instead.  Measured
+        # at exact 7B shapes (tools/probes/rows_ab.sh): 2 sequences 3.66 -> 3.20 ms per step (bf16), 2.83 -> 2.65 (e4m3
+        # weights); at 3 and 4 the four-row kernel LOSES to the stream-K projection (4.2-4.3 vs 3.7-3.8 ms; fp8 3.8-4.0 vs
+        # 2.9: four LDS reads + four dot products per weight chunk, one workgroup per CU on the down projection).  Off by
+        # default because it trades an invariant for those 6-13 %: a sequence decoded in a batch of 2 would then follow the
+        # single-sequence arithmetic and in a batch of 3+ the stream-K arithmetic - its tokens could depend on the batch size
+        # at near-ties (tests/test_fullsize_gpu.py::test_7b_batch_invariance_and_reproducibility).
+        rows_max = int(os.environ.get("VIS_ROWS_GEMV", "0"))
+        if 2 <= B <= min(rows_max, 4) and max(self.cfg.intermediate, self.cfg.hidden) * 2 * (2 if B <= 2 else 4) <= 152 * 1024:
+            return self._decode_step_rows(B)
         if self.decode_weights == "fp8" and self.fp8_batched:
             return self._decode_step_batched_fp8(B)
         cfg, w = self.cfg, self.w
@@ -1012,6 +1022,37 @@ class Qwen2VLEngine:
             next_norm = w.llm[li + 1].ln1_w if li + 1 < n_layers else w.final_norm_w
             hip.skinny_finalize(part, ks, x, cfg.hidden, residual=x2, norm_w=next_norm, yn=xn, eps=eps)
         hip.decode_gemm(xn, w.lm_head, out=self.logits_b[:B])
+        hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
+                   self.temperature, self.seed)
+
+    def _decode_step_rows(self, B: int) -> None:
+        """A couple of in-flight sequences: the single-sequence step with the multi-row GEMV (vis_gemv_*_rows) - one pass
+        over the weights for all rows, norm / bias / residual / SwiGLU fused as at B = 1, no partial buffers and no
+        finalisation launches (the stream-K projection pays four of those per layer); bf16 or e4m3 weights with bf16
+        activations, every sequence bit-identical to decoding alone.  Chosen by _decode_step_batched (VIS_ROWS_GEMV)."""
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
+        scale, eps = D ** -0.5, cfg.rms_eps
+        x, x2, qkv, att, act = self.b_x[:B], self.b_x2[:B], self.b_qkv[:B], self.b_attn[:B], self.b_act[:B]
+        fp8 = self.decode_weights == "fp8"
+
+        def proj(inp, wt, out, **kw):
+            if fp8:
+                hip.gemv_fp8_rows(inp, *wt, out, **kw)
+            else:
+                hip.gemv_rows(inp, wt, out, **kw)
+
+        hip.gather_rows(w.embed, self.cur_b[:B], x)
+        for li, lw in enumerate(w.llm):
+            q8 = self.q8[li] if fp8 else None
+            pick = (lambda n: q8[n]) if fp8 else (lambda n: getattr(lw, n))
+            proj(x, pick("qkv_w"), qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=eps)
+            hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+            proj(att, pick("o_w"), x2, residual=x)
+            proj(x2, pick("gateup_w"), act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=eps)
+            proj(act, pick("down_w"), x, residual=x2)
+        proj(x, self.q8_lm_head if fp8 else w.lm_head, self.logits_b[:B], norm_w=w.final_norm_w, eps=eps)
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
 

@@ -38,6 +38,8 @@ _SIGS = {
     "vis_attn_prefill_split": "ppppp" + "iiiiiiii" + "f" + "i" + "p" + "l" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
     "vis_gemv_fp8w": "ppppppp" + "iiiii" + "f" + "p",
+    "vis_gemv_bf16_rows": "pppppp" + "iiiiiiiii" + "f" + "p",
+    "vis_gemv_fp8w_rows": "ppppppp" + "iiiiiiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
     "vis_gemm_decode_ksplit": "ii",
@@ -577,6 +579,51 @@ def gemv_fp8(x: torch.Tensor, wq: torch.Tensor, scale: torch.Tensor, out: torch.
     rc = load().vis_gemv_fp8w(_ptr(x), _ptr(wq), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(out), N, K,
                               wq.stride(0), act, 1 if out.dtype == torch.float32 else 0, eps, _stream())
     _check(rc, "vis_gemv_fp8w")
+    return out
+
+
+def _rows_check(name, x, K, out, n_out, residual):
+    if x.dim() != 2 or not (1 <= x.shape[0] <= 4) or x.shape[1] != K or x.stride(1) != 1:
+        raise HipLibraryError(f"{name}: x must be [1..4, K] with unit column stride")
+    B = x.shape[0]
+    if out.dim() != 2 or out.shape != (B, n_out) or out.stride(1) != 1 or out.dtype not in (torch.bfloat16, torch.float32):
+        raise HipLibraryError(f"{name}: bad output")
+    if residual is not None and (residual.shape != (B, n_out) or residual.stride(1) != 1):
+        raise HipLibraryError(f"{name}: bad residual")
+    return B
+
+
+def gemv_rows(x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias: Optional[torch.Tensor] = None,
+              residual: Optional[torch.Tensor] = None, norm_w: Optional[torch.Tensor] = None,
+              act: int = ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
+    """gemv for 1..4 input rows x [B, K] -> out [B, n_out]: one pass over the weights for all rows, every row bit-identical
+    to ``gemv`` on it (no partial buffer, no finalisation launch)."""
+    _bf16(x, "gemv_rows x"); _bf16(w, "gemv_rows w")
+    N, K = w.shape
+    if w.stride(1) != 1:
+        raise HipLibraryError("gemv_rows: bad weight")
+    B = _rows_check("gemv_rows", x, K, out, N // 2 if act == ACT_SWIGLU else N, residual)
+    rc = load().vis_gemv_bf16_rows(_ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(out), B, N, K,
+                                   w.stride(0), x.stride(0), out.stride(0), residual.stride(0) if residual is not None else 0,
+                                   act, 1 if out.dtype == torch.float32 else 0, eps, _stream())
+    _check(rc, "vis_gemv_bf16_rows")
+    return out
+
+
+def gemv_fp8_rows(x: torch.Tensor, wq: torch.Tensor, scale: torch.Tensor, out: torch.Tensor,
+                  bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                  norm_w: Optional[torch.Tensor] = None, act: int = ACT_NONE, eps: float = 1e-6) -> torch.Tensor:
+    """gemv_fp8 for 1..4 input rows (W8A16), every row bit-identical to ``gemv_fp8`` on it."""
+    _bf16(x, "gemv_fp8_rows x")
+    N, K = wq.shape
+    if wq.dtype != torch.uint8 or scale.dtype != torch.float32 or scale.numel() != N or wq.stride(1) != 1:
+        raise HipLibraryError("gemv_fp8_rows: bad shapes / dtypes")
+    B = _rows_check("gemv_fp8_rows", x, K, out, N // 2 if act == ACT_SWIGLU else N, residual)
+    rc = load().vis_gemv_fp8w_rows(_ptr(x), _ptr(wq), _ptr(scale), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(out), B,
+                                   N, K, wq.stride(0), x.stride(0), out.stride(0),
+                                   residual.stride(0) if residual is not None else 0, act,
+                                   1 if out.dtype == torch.float32 else 0, eps, _stream())
+    _check(rc, "vis_gemv_fp8w_rows")
     return out
 
 
