@@ -1109,7 +1109,7 @@ class Qwen2VLEngine:
         self.step_b.copy_(saved[0])
         self.cur_b.copy_(saved[1])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # another agent's thread may be allocating
             step_fn()
         # capture does not execute; state is unchanged
         if len(self._graphs) >= 8:

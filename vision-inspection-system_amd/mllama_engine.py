@@ -577,7 +577,7 @@ class MllamaEngine:
         torch.cuda.current_stream().wait_stream(s)
         self.step.copy_(snap[0]); self.cur_token.copy_(snap[1])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # another agent's thread may be allocating
             self._decode_step()
         self.step.copy_(snap[0]); self.cur_token.copy_(snap[1])
         self._graph, self._graph_key = g, key
@@ -649,7 +649,7 @@ class MllamaEngine:
         torch.cuda.current_stream().wait_stream(s)
         self.step_b.copy_(snap[0]); self.cur_b.copy_(snap[1])
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # another agent's thread may be allocating
             self._decode_step_batched(B)
         self.step_b.copy_(snap[0]); self.cur_b.copy_(snap[1])
         if len(self._graphs_b) >= 4:
