@@ -835,6 +835,25 @@ def test_decode_gemm_swiglu_and_direct_logits(hip, device):
     _assert_close(yb, x.float() @ wl[:1000].float().t(), atol=3e-2, rtol=1e-2, what="decode gemm direct bf16")
 
 
+@pytest.mark.parametrize("B,N,K,direct", [(5, 524288, 64, False), (40, 262144, 128, True), (20, 300032, 64, False)])
+def test_decode_gemm_many_short_tiles_per_workgroup(hip, device, B, N, K, direct):
+    """A workgroup's range over more tiles than it has accumulator sets (small K, huge N: 16 / 8 / 9 tiles per workgroup
+    against 8 / 6 / 8 sets): the sets past the last one are stored on the spot and reused."""
+    x = _randn((B, K), device, 120)
+    w = _randn((N, K), device, 121, 1.0 / math.sqrt(K))
+    ref = x.float() @ w.float().t()
+    if direct:
+        out = torch.empty((B, N), dtype=torch.float32, device=device)
+        hip.decode_gemm(x, w, out=out)
+        _assert_close(out, ref, atol=2e-2, rtol=1e-2, what="direct output over many tiles per workgroup")
+        return
+    ks = hip.load().vis_gemm_decode_ksplit(N, K)
+    part = torch.full((ks * hip.part_rows(B) * N,), float("nan"), dtype=torch.float32, device=device)
+    assert hip.decode_gemm(x, w, part=part) == ks
+    got = part.view(ks, hip.part_rows(B), N)[:, :B].sum(0)
+    _assert_close(got, ref, atol=2e-2, rtol=1e-2, what="partials over many tiles per workgroup")
+
+
 def test_batched_decode_attention_and_argmax(hip, device):
     """B sequences with different context lengths in one launch == B single-sequence launches."""
     Hq, Hkv, HD, T, B = 28, 4, 128, 512, 3

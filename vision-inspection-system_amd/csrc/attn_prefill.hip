@@ -746,7 +746,7 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
   //      pair's slot; the LATER of the two workgroups (an agent-scope counter tells which) adds the other half to its
   //      own registers - a_self * x_self + a_other * x_other with separately rounded products, so the sum does not
   //      depend on which half arrived last - and goes on to the ordinary epilogue.  Nobody waits for anybody.
-  if (split) {
+  if (split && p.ws_part) {   // (flagged items through an entry point without a workspace are treated as whole items)
     const int part = (split >> 1) & 1, pair = min(split >> 2, p.n_pairs - 1);
     const size_t slot = (size_t)pair * gridDim.x + head;
     float* mine = p.ws_part + (slot * 2 + part) * (size_t)(128 * ATT_SPLIT_ROW);
