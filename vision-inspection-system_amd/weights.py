@@ -246,24 +246,35 @@ def pack_device_weights(cfg: Qwen2VLConfig, sd: Dict[str, torch.Tensor], device)
                          embed, llm, dv("model.norm.weight"), lm_head)
 
 
-def random_device_weights(cfg: Qwen2VLConfig, device, seed: int = 0, std: float = 0.02) -> DeviceWeights:
+def random_device_weights(cfg: Qwen2VLConfig, device, seed: int = 0, std: float = 0.02, scaled: bool = False,
+                          branch_gain: float = 1.0) -> DeviceWeights:
     """Seeded normal(0, std) bf16 weights generated ON the device at the exact shapes of ``cfg``.
 
     This is what the throughput benchmark uses (no checkpoint exists offline):
     timing and roofline numbers are valid, generated text is noise.  Norm weights are 1.
-    """
+
+    ``scaled=True``: variance-preserving values instead (every matrix normal(0, 1 / fan_in), unit-variance embedding
+    rows, norm weights 1 +- 0.1, biases +- 0.1 - the distribution family of ``synth_state_dict``), generated without a CPU
+    copy: for the FULL-depth precision tests, where activations and logits must stay O(1) through 28 + 32 layers.
+    ``branch_gain`` scales the matrices that write into the residual stream (attention output and MLP down / fc2
+    projections) - 1 / sqrt(2 L) is the usual initialisation of trained transformers (GPT-2 style)."""
     g = torch.Generator(device=device)
     g.manual_seed(seed)
 
-    def rn(*shape, s=std):
-        return (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * s).to(torch.bfloat16)
+    def rn(*shape, s=None, gain=1.0):
+        if s is None:
+            s = std if not scaled else (0.1 if len(shape) == 1 else float(shape[-1]) ** -0.5)
+        return (torch.randn(shape, generator=g, device=device, dtype=torch.float32) * (s * gain)).to(torch.bfloat16)
 
     def ones(n):
+        if scaled:
+            return (1.0 + 0.1 * (2.0 * torch.rand(n, generator=g, device=device, dtype=torch.float32) - 1.0)).to(torch.bfloat16)
         return torch.ones(n, dtype=torch.bfloat16, device=device)
 
     def zeros(n):
-        return torch.zeros(n, dtype=torch.bfloat16, device=device)
+        return rn(n) if scaled else torch.zeros(n, dtype=torch.bfloat16, device=device)
 
+    bg = branch_gain
     E, H, D = cfg.v_embed, cfg.hidden, cfg.head_dim
     M = E * cfg.merge ** 2
     patch_w = pad_cols(rn(E, cfg.patch_dim), PATCH_K_PAD)
@@ -280,20 +291,21 @@ def random_device_weights(cfg: Qwen2VLConfig, device, seed: int = 0, std: float 
         for _ in range(cfg.v_depth):
             g_w, u_w = padded(rn(pad, E), 0), padded(rn(pad, E), 0)
             g_b, u_b = padded(rn(pad), 0), padded(rn(pad), 0)
-            vit.append(VitBlockWeights(ones(E), None, ones(E), None, rn(3 * E, E), rn(3 * E), rn(E, E), rn(E),
+            vit.append(VitBlockWeights(ones(E), None, ones(E), None, rn(3 * E, E), rn(3 * E), rn(E, E, gain=bg), rn(E),
                                        interleave_gate_up(g_w, u_w),
                                        interleave_gate_up(g_b.view(-1, 1), u_b.view(-1, 1)).view(-1).contiguous(),
-                                       padded(rn(E, pad), 1), rn(E)))
+                                       padded(rn(E, pad, gain=bg), 1), rn(E)))
     else:
-        vit = [VitBlockWeights(ones(E), zeros(E), ones(E), zeros(E), rn(3 * E, E), rn(3 * E), rn(E, E), rn(E),
-                               rn(cfg.v_mlp, E), rn(cfg.v_mlp), rn(E, cfg.v_mlp), rn(E)) for _ in range(cfg.v_depth)]
+        vit = [VitBlockWeights(ones(E), zeros(E), ones(E), zeros(E), rn(3 * E, E), rn(3 * E), rn(E, E, gain=bg), rn(E),
+                               rn(cfg.v_mlp, E), rn(cfg.v_mlp), rn(E, cfg.v_mlp, gain=bg), rn(E))
+               for _ in range(cfg.v_depth)]
     llm = []
     for _ in range(cfg.layers):
         nq = (cfg.heads + 2 * cfg.kv_heads) * D
-        llm.append(LlmLayerWeights(ones(H), ones(H), rn(nq, H), rn(nq), rn(H, cfg.heads * D),
-                                   rn(2 * cfg.intermediate, H), rn(H, cfg.intermediate)))
+        llm.append(LlmLayerWeights(ones(H), ones(H), rn(nq, H), rn(nq), rn(H, cfg.heads * D, gain=bg),
+                                   rn(2 * cfg.intermediate, H), rn(H, cfg.intermediate, gain=bg)))
     return DeviceWeights(patch_w, vit, ones(E), None if cfg.vision_arch == "qwen2_5_vl" else zeros(E), rn(M, M), rn(M), rn(H, M), rn(H),
-                         rn(cfg.vocab, H), llm, ones(H), rn(cfg.vocab, H))
+                         rn(cfg.vocab, H, s=1.0 if scaled else None), llm, ones(H), rn(cfg.vocab, H))
 
 
 def load_safetensors_dir(cfg: Qwen2VLConfig, path: str, device) -> DeviceWeights:
