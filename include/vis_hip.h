@@ -120,6 +120,26 @@ int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void*
 /* batch > 1: sequence b uses qkv + b*qkv_bs, caches + b*cache_bs, tables + b*tab_bs (element strides),
  * step_ptr[b], part_o/part_ml/out blocks of Hq*nsplit*128 / Hq*nsplit*2 / Hq*128 elements. */
 
+/* K10 + K4 + K11 + K10 (single-sequence decode)  the head of a decoder layer as ONE launch:
+ *   qkv = W_qkv rmsnorm(x) + b ; attn = attention(rope(q), cache + rope(k), v) ; y = x + W_o attn
+ * i.e. vis_gemv_bf16 (norm fused) + vis_decode_attn (split + combine launches) + vis_gemv_bf16 (residual), bit-identical to
+ * those four launches (csrc/decode_chain.hip: the stages are workgroup roles of one resident grid that hand their results
+ * over as tagged 8-byte granules).  Replaces TF modeling_qwen2_vl.py:501-556 (+ :96-110 input norm) for q_len == 1 with a
+ * KV cache.  x [K] bf16 layer input, Wqkv [(Hq + 2 Hkv) * 128][ldw_qkv], bqkv or NULL, norm_w [K], Wo [K][ldw_o], y [K];
+ * tables, caches, step_ptr as vis_decode_attn.
+ * ws: vis_decode_chain_ws_bytes(Hq, Hkv, nsplit) bytes and sync: vis_decode_chain_sync_ints() ints, both zeroed once by the
+ * caller and owned by one stream; sync[0] counts completed launches, sync[32] is a status word: non-zero after a launch = a
+ * bounded wait gave up (results invalid; zero ws and sync before the next launch).  The packed projection row and the merged
+ * attention row live in ws as granules (low 32 bits = two bf16): ws[0 .. (Hq + 2 Hkv) * 64) and the next Hq * 64 words.
+ * VIS_ERR_ARG for shapes outside the chained form (HD != 128, K or Hq * 128 > 4096, Hq > 64, a grid above what the device
+ * holds resident): the caller then issues the four launches. */
+int vis_decode_chain_sync_ints(void);
+long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit);
+int vis_decode_chain(const void* x, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
+                     const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr, void* ws,
+                     void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o, int cache_tokens, int nsplit,
+                     float scale, float eps, vis_stream_t stream);
+
 /* K12  next-token pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
  * torch.argmax), then *step += 1.  inv_temp > 0 samples at temperature 1/inv_temp by Gumbel-max with a
  * counter hash of (seed, *step, index); inv_temp == 0 is greedy (the reference request passes

@@ -1117,3 +1117,81 @@ def test_gemv_rows_bit_identical_to_single_row(hip, device, B, N, K, act, fused)
             else:
                 hip.gemv(x[b], w, one, bias=bias, residual=r, norm_w=nw, act=act)
             assert torch.equal(many[b], one), f"row {b} of {B} differs from the single-row kernel (fp8={fp8})"
+
+
+@pytest.mark.parametrize("Hq,Hkv,K,T", [(28, 4, 3584, 4096), (28, 4, 3584, 2560), (2, 1, 256, 1024), (32, 8, 4096, 1024),
+                                        (16, 16, 2048, 512)])
+def test_decode_chain_equals_unchained(hip, device, Hq, Hkv, K, T):
+    """vis_decode_chain (qkv projection + RMSNorm + bias -> rope / KV append / split attention + merge -> o projection +
+    residual as ONE launch with in-grid hand-offs) against the four launches it replaces (vis_gemv_bf16, vis_decode_attn =
+    split + combine, vis_gemv_bf16): y, the merged attention row, the packed projection row and both caches bit for bit,
+    at the 7B / 11B / tiny head shapes, at context lengths on and off the 64-key split boundaries up to the last cache row;
+    launches repeated back to back on one workspace (granule tags are launch numbers: no reset between launches), status clean."""
+    HD = 128
+    nq = (Hq + 2 * Hkv) * HD
+    g = torch.Generator(device="cpu").manual_seed(Hq * 1000 + K + T)
+    wqkv = (torch.randn((nq, K), generator=g) / K ** 0.5).to(torch.bfloat16).to(device)
+    bq = torch.randn((nq,), generator=g).mul(0.1).to(torch.bfloat16).to(device)
+    nw = (1 + 0.1 * torch.randn((K,), generator=g)).to(torch.bfloat16).to(device)
+    wo = (torch.randn((K, Hq * HD), generator=g) / (Hq * HD) ** 0.5).to(torch.bfloat16).to(device)
+    kc0, vc0 = _randn((Hkv, T, HD), device, 301), _randn((Hkv, T, HD), device, 302)
+    ang = torch.rand((T, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos_t, sin_t = emb.cos().to(device).contiguous(), emb.sin().to(device).contiguous()
+    ns = -(-T // hip.DECODE_KEYS_PER_SPLIT)
+    po = torch.empty(Hq * ns * HD, dtype=torch.float32, device=device)
+    pml = torch.empty(Hq * ns * 2, dtype=torch.float32, device=device)
+    ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
+    assert hip.decode_chain_supported(Hq, Hkv, HD, K)
+    launches = 0
+    for ctx in sorted({c for c in (0, 1, 62, 63, 64, 65, 127, 128, 700, T // 2 + 3, T - 2, T - 1) if c < T}):
+        x = _randn((K,), device, 400 + ctx)
+        step = torch.tensor([ctx], dtype=torch.int32, device=device)
+        # ---- the four launches
+        k1, v1 = kc0.clone(), vc0.clone()
+        qkv1 = torch.empty(nq, dtype=torch.bfloat16, device=device)
+        att1 = torch.empty(Hq * HD, dtype=torch.bfloat16, device=device)
+        y1 = torch.empty(K, dtype=torch.bfloat16, device=device)
+        hip.gemv(x, wqkv, qkv1, bias=bq, norm_w=nw, eps=1e-6)
+        hip.decode_attn(qkv1, cos_t, sin_t, k1, v1, step, po, pml, att1, Hq, Hkv, HD, ns, HD ** -0.5)
+        hip.gemv(att1, wo, y1, residual=x)
+        # ---- one launch (twice: the second must not depend on anything the first left behind)
+        for rep in range(2):
+            k2, v2 = kc0.clone(), vc0.clone()
+            y2 = torch.full((K,), 3.0, dtype=torch.bfloat16, device=device)
+            hip.decode_chain(x, wqkv, bq, nw, wo, y2, cos_t, sin_t, k2, v2, step, ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
+            launches += 1
+            torch.cuda.synchronize()
+            qkv2, att2 = hip.decode_chain_rows(ws, Hq, Hkv)
+            assert int(sync[hip.CHAIN_STATUS_WORD]) == 0, f"ctx {ctx}: a wait inside the chained launch timed out"
+            assert int(sync[0]) == launches, "the launch counter of the sync block must advance once per launch"
+            assert torch.equal(qkv2, qkv1), f"ctx {ctx}: projection row differs"
+            assert torch.equal(k2, k1) and torch.equal(v2, v1), f"ctx {ctx}: KV append differs"
+            assert torch.equal(att2, att1), f"ctx {ctx}: merged attention differs " \
+                                            f"(max {float((att2.float() - att1.float()).abs().max())})"
+            assert torch.equal(y2, y1), f"ctx {ctx}: o projection differs"
+    # fp32 reference of the whole head at the last context (the unchained kernels are tested against it elsewhere too)
+    xf = x.float().cpu()
+    xn = (xf * torch.rsqrt(xf.pow(2).mean() + 1e-6)).to(torch.bfloat16).float() * nw.float().cpu()
+    qkv_ref = (wqkv.float().cpu() @ xn + bq.float().cpu())
+    _assert_close(qkv2, qkv_ref, atol=3e-2, rtol=2e-2, what="chained qkv projection vs fp32")
+
+
+def test_decode_chain_refuses_unsupported_shapes(hip, device):
+    """Shapes outside the chained form are refused by the launcher before any launch (the engine then issues four launches)."""
+    assert not hip.decode_chain_supported(28, 4, 64, 3584)       # head_dim
+    assert not hip.decode_chain_supported(64, 8, 128, 8192)      # hidden above one K-segment per row
+    assert not hip.decode_chain_supported(28, 3, 128, 3584)      # heads not a multiple of kv heads
+    # a supported head shape whose grid (projection + Hkv x splits + merge workgroups) exceeds what the device holds resident:
+    # Llama-3.2-11B text shape at a 16 k context = 768 + 8 * 256 + 32 workgroups
+    Hq, Hkv, K, T, HD = 32, 8, 4096, 16384, 128
+    ns = T // hip.DECODE_KEYS_PER_SPLIT
+    nq = (Hq + 2 * Hkv) * HD
+    z = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
+    ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
+    tab = torch.zeros((T, HD), dtype=torch.float32, device=device)
+    with pytest.raises(hip.HipLibraryError):
+        hip.decode_chain(z(K), z(nq, K), None, z(K), z(K, Hq * HD), z(K), tab, tab, z(Hkv, T, HD), z(Hkv, T, HD),
+                         torch.zeros(1, dtype=torch.int32, device=device), ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
+    torch.cuda.synchronize()
+    assert int(sync[0]) == 0 and int(sync[hip.CHAIN_STATUS_WORD]) == 0        # nothing was launched

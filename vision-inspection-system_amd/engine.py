@@ -189,6 +189,13 @@ class Qwen2VLEngine:
         self.decode_weights = decode_weights
         if decode_weights not in ("bf16", "fp8"):
             raise ValueError("decode_weights must be 'bf16' or 'fp8'")
+        # Single-sequence decode: the head of every layer (qkv projection -> rope / append / attention -> o projection) as ONE
+        # launch whose stages hand over inside the grid (csrc/decode_chain.hip; bit-identical to the four launches it
+        # replaces).  VIS_DECODE_CHAIN=0 keeps the four launches (A/B).
+        self.chain_sync: Optional[torch.Tensor] = None
+        if decode_weights == "bf16" and os.environ.get("VIS_DECODE_CHAIN", "1") != "0" \
+                and hip.decode_chain_supported(Hq, Hkv, D, H):
+            self.chain_ws, self.chain_sync = hip.decode_chain_state(dev, Hq, Hkv, self.nsplit)
         self.q8: List[dict] = []
         self.prefill_dtype = prefill_dtype
         if prefill_dtype not in ("bf16", "fp8"):
@@ -974,10 +981,20 @@ class Qwen2VLEngine:
                        self.temperature, self.seed)
             return
         for li, lw in enumerate(w.llm):
-            hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
-            hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
-                            self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
-            hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
+            if self.chain_sync is not None:
+                try:
+                    hip.decode_chain(x[0], lw.qkv_w, lw.qkv_b, lw.ln1_w, lw.o_w, x2[0], self.cos_t, self.sin_t,
+                                     self.kcache[li], self.vcache[li], self.step, self.chain_ws, self.chain_sync, Hq, Hkv, D,
+                                     self.nsplit, scale, cfg.rms_eps)
+                except hip.HipLibraryError:
+                    if li:
+                        raise
+                    self.chain_sync = None          # the launcher refused the grid (not resident on this device): four launches
+            if self.chain_sync is None:
+                hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+                hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
+                                self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
+                hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
             hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])
         hip.gemv(x[0], w.lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
@@ -1134,7 +1151,17 @@ class Qwen2VLEngine:
 
     def generated(self, n: int) -> List[int]:
         s = self.prompt_len - 1
-        return self.tokens[s:s + n].cpu().tolist()
+        toks = self.tokens[s:s + n].cpu().tolist()
+        self.check_chain()
+        return toks
+
+    def check_chain(self) -> None:
+        """Raise if a bounded wait inside a chained layer-head launch gave up (its results are invalid); the sync block is
+        zeroed so that the engine stays usable.  Called after the token D2H, i.e. when the stream has drained."""
+        if self.chain_sync is not None and int(self.chain_sync[hip.CHAIN_STATUS_WORD].item()) != 0:
+            self.chain_sync.zero_()
+            self.chain_ws.zero_()
+            raise hip.HipLibraryError("vis_decode_chain: a hand-off wait inside the launch timed out (decode results invalid)")
 
     def generate(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (), max_new_tokens: int = 128,
                  ignore_eos: bool = False, use_graph: bool = True, check_every: int = 16,

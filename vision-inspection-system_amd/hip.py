@@ -41,6 +41,9 @@ _SIGS = {
     "vis_gemv_bf16_rows": "pppppp" + "iiiiiiiii" + "f" + "p",
     "vis_gemv_fp8w_rows": "ppppppp" + "iiiiiiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
+    "vis_decode_chain_sync_ints": "",
+    "vis_decode_chain_ws_bytes": "iii",
+    "vis_decode_chain": "p" * 13 + "i" * 8 + "ff" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
     "vis_gemm_decode_ksplit": "ii",
     "vis_gemm_decode_bf16": "pppp" + "iiiiiiii" + "p",
@@ -112,6 +115,7 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here means header and library disagree
         fn.restype = ctypes.c_int
         fn.argtypes = [_CT[c] for c in sig]
+    lib.vis_decode_chain_ws_bytes.restype = ctypes.c_longlong
     _lib = lib
     return lib
 
@@ -663,6 +667,64 @@ def decode_attn(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_c
                                 B, qkv_bs, cache_bs, tab_bs, _stream())
     _check(rc, "vis_decode_attn")
     return out
+
+
+CHAIN_STATUS_WORD = 32     # int index of the status word inside a decode-chain sync block (csrc/decode_chain.hip: CH_STATUS)
+
+
+def decode_chain_state(device, n_q: int, n_kv: int, nsplit: int):
+    """(granule workspace, sync block) of vis_decode_chain, zeroed - one pair per engine / stream."""
+    lib = load()
+    nbytes = int(lib.vis_decode_chain_ws_bytes(n_q, n_kv, nsplit))
+    return (torch.zeros(nbytes // 8, dtype=torch.int64, device=device),
+            torch.zeros(lib.vis_decode_chain_sync_ints(), dtype=torch.int32, device=device))
+
+
+def decode_chain_supported(n_q: int, n_kv: int, head_dim: int, hidden: int) -> bool:
+    """Shapes the chained layer head covers (the launcher additionally checks that its grid is resident)."""
+    return head_dim == 128 and n_q <= 64 and n_q % n_kv == 0 and (n_q // n_kv) in (1, 2, 4, 7, 8) \
+        and hidden % 8 == 0 and hidden <= 4096 and n_q * head_dim <= 4096 and hidden // 2 <= (n_q + 2 * n_kv) * head_dim // 2
+
+
+def decode_chain(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: Optional[torch.Tensor], norm_w: torch.Tensor,
+                 o_w: torch.Tensor, y: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
+                 v_cache: torch.Tensor, step: torch.Tensor, ws: torch.Tensor, sync: torch.Tensor, n_q: int, n_kv: int,
+                 head_dim: int, nsplit: int, scale: float, eps: float) -> None:
+    """qkv projection (+ RMSNorm, bias) -> rope / KV append / split attention + merge -> o projection (+ residual x) in ONE
+    launch, bit-identical to gemv + decode_attn + gemv.  Single sequence: x [K], caches [Hkv, T, D], tables [T, D], step [1];
+    ws / sync from decode_chain_state."""
+    for t, n in ((x, "x"), (qkv_w, "qkv_w"), (norm_w, "norm_w"), (o_w, "o_w"), (y, "y"), (k_cache, "k_cache"),
+                 (v_cache, "v_cache")):
+        _bf16(t, "decode_chain " + n)
+    K = x.numel()
+    nq = (n_q + 2 * n_kv) * head_dim
+    if qkv_w.shape != (nq, K) or qkv_w.stride(1) != 1 or o_w.shape != (K, n_q * head_dim) or o_w.stride(1) != 1 \
+            or norm_w.numel() != K or y.numel() != K or (qkv_b is not None and qkv_b.numel() != nq):
+        raise HipLibraryError("decode_chain: bad projection shapes")
+    if k_cache.dim() != 3 or k_cache.shape[0] != n_kv or k_cache.shape[2] != head_dim or v_cache.shape != k_cache.shape \
+            or not k_cache.is_contiguous() or not v_cache.is_contiguous():
+        raise HipLibraryError("decode_chain: bad cache shape")
+    T = k_cache.shape[1]
+    if cos_t.shape != (T, head_dim) or sin_t.shape != cos_t.shape or cos_t.dtype != torch.float32 or not cos_t.is_contiguous() \
+            or not sin_t.is_contiguous() or step.dtype != torch.int32 or step.numel() != 1:
+        raise HipLibraryError("decode_chain: bad tables / step")
+    lib = load()
+    if ws.dtype != torch.int64 or ws.numel() * 8 < lib.vis_decode_chain_ws_bytes(n_q, n_kv, nsplit) \
+            or sync.dtype != torch.int32 or sync.numel() < lib.vis_decode_chain_sync_ints():
+        raise HipLibraryError("decode_chain: workspace too small")
+    rc = lib.vis_decode_chain(_ptr(x), _ptr(qkv_w), _ptr(qkv_b), _ptr(norm_w), _ptr(o_w), _ptr(y), _ptr(cos_t), _ptr(sin_t),
+                              _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(ws), _ptr(sync), n_q, n_kv, head_dim, K,
+                              qkv_w.stride(0), o_w.stride(0), T, nsplit, scale, eps, _stream())
+    _check(rc, "vis_decode_chain")
+
+
+def decode_chain_rows(ws: torch.Tensor, n_q: int, n_kv: int):
+    """(packed projection row [(n_q + 2 n_kv) * 128], merged attention row [n_q * 128]) bf16 of the last chained launch, read
+    back from the granule workspace (tests / taps)."""
+    nq = (n_q + 2 * n_kv) * 64
+    g = ws[:nq + n_q * 64] & 0xFFFFFFFF
+    rows = g.to(torch.int32).view(torch.bfloat16)
+    return rows[:2 * nq], rows[2 * nq:]
 
 
 def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tokens: torch.Tensor,
