@@ -105,8 +105,9 @@ def gemv_bytes_per_step(cfg) -> float:
 def measure_gemv(engine, reps: int = 5):
     """Average duration of one gemv_bf16_kernel launch, measured live with HIP events on the launch stream.
 
-    The 113 GEMV launches of one decode step (same weights, same buffers, same arguments as the real step)
-    are captured alone into a hipGraph and the replay is bracketed by two events, so the figure is
+    The GEMV launches of one decode step (same weights, same buffers, same arguments as the real step: 113 in the
+    unchained step; 56 - gate/up and down - when the head of every layer runs as the chained launch: its qkv / o
+    projections are not this kernel, and the lm_head then runs as the kernel's argmax-epilogue instance) are captured alone into a hipGraph and the replay is bracketed by two events, so the figure is
     (sum of kernel durations + in-graph kernel boundaries) / launches.  Bracketing every tiny kernel with its
     own event pair instead adds ~5 us of event overhead per launch and over-reads by ~20 %; rocprofv3's
     per-kernel average (profiles/) is the cross-check."""
@@ -126,14 +127,18 @@ def measure_gemv(engine, reps: int = 5):
             hip.gemv_fp8(x[0], *engine.q8_lm_head, engine.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
             n[0] += 1
             return
+        chained = engine.chain_sync is not None
         for lw in w.llm:
-            hip.gemv(x[0], lw.qkv_w, engine.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
-            hip.gemv(engine.d_attn, lw.o_w, x2[0], residual=x[0])
+            if not chained:
+                hip.gemv(x[0], lw.qkv_w, engine.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
+                hip.gemv(engine.d_attn, lw.o_w, x2[0], residual=x[0])
+                n[0] += 2
             hip.gemv(x2[0], lw.gateup_w, engine.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(engine.d_act, lw.down_w, x[0], residual=x2[0])
-            n[0] += 4
-        hip.gemv(x[0], w.lm_head, engine.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
-        n[0] += 1
+            n[0] += 2
+        if not chained:     # (chained step: the lm_head runs as the kernel's argmax-epilogue instance, a row of its own in rocprof)
+            hip.gemv(x[0], w.lm_head, engine.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+            n[0] += 1
 
     side = torch.cuda.Stream(device=engine.device)
     side.wait_stream(torch.cuda.current_stream())
@@ -774,7 +779,14 @@ def main():
         step_bytes = gemv_bytes_per_step(cfg) / (2 if fp8 else 1)
         if B > 1 and fp8 and engine.fp8_batched:      # the o projection stays bf16 in the batched fp8 step
             step_bytes += cfg.layers * cfg.heads * cfg.head_dim * cfg.hidden
-        bytes_per_launch = step_bytes / k_launches
+        kernel_bytes = step_bytes
+        if B == 1 and engine.chain_sync is not None:  # qkv / o weights stream inside the chained layer-head launch
+            D_ = cfg.head_dim
+            kernel_bytes -= 2.0 * cfg.layers * (cfg.hidden * (cfg.heads + 2 * cfg.kv_heads) * D_ + cfg.heads * D_ * cfg.hidden)
+            kernel_bytes -= 2.0 * cfg.hidden * cfg.vocab
+            kernel = "gemv_bf16_kernel<1, false> (decode weight streaming: the gate/up and down projections, 81 % of a token's " \
+                     "weight bytes; qkv / o run inside decode_chain_kernel, the lm_head as gemv_bf16_kernel<1, true>)"
+        bytes_per_launch = kernel_bytes / k_launches
         achieved = bytes_per_launch / k_avg / 1e9
         flops = prefill_flops(cfg, n_patches, S) * B          # B full prompt passes' worth of arithmetic per step
         out = {

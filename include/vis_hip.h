@@ -125,7 +125,8 @@ int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void*
  * i.e. vis_gemv_bf16 (norm fused) + vis_decode_attn (split + combine launches) + vis_gemv_bf16 (residual), bit-identical to
  * those four launches (csrc/decode_chain.hip: the stages are workgroup roles of one resident grid that hand their results
  * over as tagged 8-byte granules).  Replaces TF modeling_qwen2_vl.py:501-556 (+ :96-110 input norm) for q_len == 1 with a
- * KV cache.  x [K] bf16 layer input, Wqkv [(Hq + 2 Hkv) * 128][ldw_qkv], bqkv or NULL, norm_w [K], Wo [K][ldw_o], y [K];
+ * KV cache.  x [K] bf16 layer input - or, with x_idx != NULL, an [x_rows][K] table whose row *x_idx (a device int, clamped
+ * like vis_gather_rows) is the input: the first layer reads the new token's embedding row itself -, Wqkv [(Hq + 2 Hkv) * 128][ldw_qkv], bqkv or NULL, norm_w [K], Wo [K][ldw_o], y [K];
  * tables, caches, step_ptr as vis_decode_attn.
  * ws: vis_decode_chain_ws_bytes(Hq, Hkv, nsplit) bytes and sync: vis_decode_chain_sync_ints() ints, both zeroed once by the
  * caller and owned by one stream; sync[0] counts completed launches, sync[32] is a status word: non-zero after a launch = a
@@ -135,10 +136,17 @@ int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void*
  * holds resident): the caller then issues the four launches. */
 int vis_decode_chain_sync_ints(void);
 long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit);
-int vis_decode_chain(const void* x, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
+int vis_decode_chain(const void* x, const void* x_idx, int x_rows, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
                      const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr, void* ws,
                      void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o, int cache_tokens, int nsplit,
                      float scale, float eps, vis_stream_t stream);
+
+/* K10 + K12  lm_head of the single-sequence step with the pick's first stage in its epilogue, then the merging launch:
+ * logits[N] f32 = W rmsnorm(x); tokens[*step] = cur_token = pick; *step += 1 - the pick vis_gemv_bf16 + vis_argmax_f32 make
+ * (same comparison, same Gumbel noise), one launch fewer.  ws_val / ws_idx: 2048 floats / ints. */
+int vis_gemv_bf16_argmax(const void* x, const void* W, const void* norm_w, void* logits, int N, int K, int ldw, float eps,
+                         void* ws_val, void* ws_idx, void* tokens, int max_tokens, void* cur_token, void* step_ptr,
+                         float inv_temp, unsigned seed, vis_stream_t stream);
 
 /* K12  next-token pick: tokens[*step] = cur_token = argmax(logits) (first index on ties, like
  * torch.argmax), then *step += 1.  inv_temp > 0 samples at temperature 1/inv_temp by Gumbel-max with a

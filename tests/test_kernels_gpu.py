@@ -1159,7 +1159,12 @@ def test_decode_chain_equals_unchained(hip, device, Hq, Hkv, K, T):
         for rep in range(2):
             k2, v2 = kc0.clone(), vc0.clone()
             y2 = torch.full((K,), 3.0, dtype=torch.bfloat16, device=device)
-            hip.decode_chain(x, wqkv, bq, nw, wo, y2, cos_t, sin_t, k2, v2, step, ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
+            if rep == 0:
+                hip.decode_chain(x, wqkv, bq, nw, wo, y2, cos_t, sin_t, k2, v2, step, ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
+            else:       # the layer input as a row of a table picked by a device index (the first layer: embedding lookup inside)
+                table = torch.stack([_randn((K,), device, 77), x, _randn((K,), device, 78)])
+                hip.decode_chain(table, wqkv, bq, nw, wo, y2, cos_t, sin_t, k2, v2, step, ws, sync, Hq, Hkv, HD, ns, HD ** -0.5,
+                                 1e-6, x_index=torch.tensor([1], dtype=torch.int32, device=device))
             launches += 1
             torch.cuda.synchronize()
             qkv2, att2 = hip.decode_chain_rows(ws, Hq, Hkv)
@@ -1195,3 +1200,40 @@ def test_decode_chain_refuses_unsupported_shapes(hip, device):
                          torch.zeros(1, dtype=torch.int32, device=device), ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
     torch.cuda.synchronize()
     assert int(sync[0]) == 0 and int(sync[hip.CHAIN_STATUS_WORD]) == 0        # nothing was launched
+
+
+@pytest.mark.parametrize("N,K,temperature", [(152064, 3584, 0.0), (152064, 3584, 0.7), (512, 256, 0.0), (1001, 704, 0.3)])
+def test_gemv_argmax_equals_two_stage(hip, device, N, K, temperature):
+    """vis_gemv_bf16_argmax (lm_head with the pick's first stage in its epilogue + the merging launch) against vis_gemv_bf16 +
+    vis_argmax_f32: the same f32 logits bit for bit, the same pick (greedy with ties, and Gumbel-max sampled with the same
+    seed / step), the same device-side bookkeeping (tokens[step], cur_token, step + 1)."""
+    g = torch.Generator(device="cpu").manual_seed(N + K)
+    w = (torch.randn((N, K), generator=g) / K ** 0.5).to(torch.bfloat16).to(device)
+    if temperature == 0.0:
+        w[N // 3] = w[N // 2]                    # an exact tie: the lower index must win in both forms
+    nw = (1 + 0.1 * torch.randn((K,), generator=g)).to(torch.bfloat16).to(device)
+    for trial in range(3):
+        x = _randn((K,), device, 900 + trial)
+        if temperature == 0.0 and trial == 0:
+            x = (w[N // 2].float() * 4).to(torch.bfloat16)          # make the tied rows the maximum
+        out = {}
+        for fused in (False, True):
+            logits = torch.zeros(N, dtype=torch.float32, device=device)
+            wv = torch.empty(2048, dtype=torch.float32, device=device)
+            wi = torch.empty(2048, dtype=torch.int32, device=device)
+            tokens = torch.zeros(64, dtype=torch.int32, device=device)
+            cur = torch.zeros(1, dtype=torch.int32, device=device)
+            step = torch.tensor([5 + trial], dtype=torch.int32, device=device)
+            if fused:
+                hip.gemv_argmax(x, w, logits, wv, wi, tokens, cur, step, norm_w=nw, temperature=temperature, seed=1234)
+            else:
+                hip.gemv(x, w, logits, norm_w=nw)
+                hip.argmax(logits, wv, wi, tokens, cur, step, temperature, 1234)
+            out[fused] = (logits.clone(), tokens.clone(), int(cur), int(step))
+        assert torch.equal(out[True][0], out[False][0]), "logits differ"
+        assert out[True][2] == out[False][2] and out[True][3] == out[False][3] == 6 + trial
+        assert torch.equal(out[True][1], out[False][1])
+        if temperature == 0.0:
+            assert out[True][2] == int(out[True][0].argmax())        # torch.argmax: first index on ties
+            if trial == 0:
+                assert out[True][2] == N // 3

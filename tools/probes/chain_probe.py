@@ -10,7 +10,7 @@ torch.zeros(1, device=dev)
 here = os.path.dirname(os.path.abspath(__file__))
 lib = ctypes.CDLL(os.path.join(here, "libchain_probe.so"))
 fn = lib.vis_decode_chain
-fn.argtypes = [ctypes.c_void_p] * 13 + [ctypes.c_int] * 8 + [ctypes.c_float] * 2 + [ctypes.c_void_p]
+fn.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int] + [ctypes.c_void_p] * 12 + [ctypes.c_int] * 8 + [ctypes.c_float] * 2 + [ctypes.c_void_p]
 fn.restype = ctypes.c_int
 lib.vis_decode_chain_ws_bytes.restype = ctypes.c_longlong
 lib.vis_decode_chain_set_probe.argtypes = [ctypes.c_void_p]
@@ -35,7 +35,7 @@ hog = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 
 def launch(i):
     wq, bq, nw, wo, kc, vc = W[i % L]
-    rc = fn(x.data_ptr(), wq.data_ptr(), bq.data_ptr(), nw.data_ptr(), wo.data_ptr(), y.data_ptr(), tab.data_ptr(), tab.data_ptr(),
+    rc = fn(x.data_ptr(), None, 0, wq.data_ptr(), bq.data_ptr(), nw.data_ptr(), wo.data_ptr(), y.data_ptr(), tab.data_ptr(), tab.data_ptr(),
             kc.data_ptr(), vc.data_ptr(), step.data_ptr(), ws.data_ptr(), sync.data_ptr(), Hq, Hkv, HD, K, K, Hq * HD, T, ns,
             HD ** -0.5, 1e-6, torch.cuda.current_stream().cuda_stream)
     assert rc == 0, rc
@@ -82,6 +82,6 @@ table("projection", Rz[:, :n_gv], [(0, "start"), (1, "x normalised (weights in f
                                    (4, "attention row staged"), (5, "y stored")])
 att = Rz[:, n_gv:n_gv + Hkv * active]
 table("attention (active splits)", att, [(0, "start"), (1, "K / V requested, position known"), (2, "q / k / v collected"),
-                                         (3, "scores, softmax, P V done"), (5, "partials stored")])
+                                         (6, "rope, append, scores done"), (7, "softmax done"), (3, "P V done"), (5, "partials stored")])
 table("merge", Rz[:, n_gv + n_att:], [(0, "start"), (1, "partials + statistics collected"), (2, "weights exchanged"),
                                       (3, "head stored")])

@@ -18,7 +18,10 @@
 
 // NB = input rows sharing the weight stream (1: the single-sequence decode step; 2 / 4: vis_gemv_bf16_rows, a handful of
 // in-flight sequences - each row's arithmetic is exactly the NB = 1 kernel's, so its result is bit-identical to it)
-template <int NB>
+// AMAX (lm_head of the single-sequence step): the greedy / Gumbel-max pick's first stage rides in the epilogue - every
+// workgroup leaves the (value, first index) maximum of ITS rows in amax_val / amax_idx[blockIdx.x] (argmax_stage1_kernel's
+// comparison, so the pick is the one the two-stage form makes), saving a launch per token.
+template <int NB, bool AMAX = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* xs = (bf16_t*)smem;
@@ -48,6 +51,20 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
   float a0[NB], a1[NB];
 #pragma unroll
   for (int r = 0; r < NB; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+  float best = -INFINITY;       // AMAX: lane 0's running maximum over this wave's rows
+  int bi = 0x7fffffff;
+  const unsigned am_step = AMAX ? (unsigned)*p.am_step : 0u;
+  auto amax_rows = [&](int pr) {      // after gv_finish: a0[0] / a1[0] hold the two rows' sums (= the stored logits)
+    if (lane != 0) return;
+    const int o = 2 * pr;
+    float v0 = a0[0], v1 = a1[0];
+    if (p.am_inv_temp > 0.f) {
+      v0 = v0 * p.am_inv_temp + gumbel_noise(p.am_seed, am_step, (unsigned)o);
+      v1 = v1 * p.am_inv_temp + gumbel_noise(p.am_seed, am_step, (unsigned)(o + 1));
+    }
+    if (v0 > best || (v0 == best && o < bi)) { best = v0; bi = o; }
+    if (o + 1 < p.N && (v1 > best || (v1 == best && o + 1 < bi))) { best = v1; bi = o + 1; }
+  };
   int pair = p_begin, seg = 0;  // task being consumed
   for (int t = 0; t < n_tasks; t += 2) {
     // next task (t+1) -> B
@@ -57,6 +74,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     gv_consume<NB>(A, xs, p.K, seg, lane, nch, a0, a1);
     if (seg == nseg - 1) {
       gv_finish<NB>(p, swiglu, pair, lane, a0, a1);
+      if constexpr (AMAX) amax_rows(pair);
 #pragma unroll
       for (int r = 0; r < NB; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     }
@@ -68,11 +86,24 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(GemvArgs p) {
     gv_consume<NB>(B, xs, p.K, seg1, lane, nch, a0, a1);
     if (seg1 == nseg - 1) {
       gv_finish<NB>(p, swiglu, pair1, lane, a0, a1);
+      if constexpr (AMAX) amax_rows(pair1);
 #pragma unroll
       for (int r = 0; r < NB; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
     }
     pair = pair2;
     seg = seg2;
+  }
+  if constexpr (AMAX) {
+    __shared__ float am_v[4];
+    __shared__ int am_i[4];
+    if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (am_v[w] > best || (am_v[w] == best && am_i[w] < bi)) { best = am_v[w]; bi = am_i[w]; }
+      p.am_val[blockIdx.x] = best;
+      p.am_idx[blockIdx.x] = bi;
+    }
   }
 }
 
@@ -777,21 +808,6 @@ extern "C" int vis_decode_cross_attn_batch(const void* q, const void* q_norm_w, 
 // writes tokens[*step] = argmax, cur_token = argmax and then *step += 1.
 // temperature sampling = Gumbel-max: argmax(logit/T + g_i), g_i = -log(-log(u_i)), u_i from a counter hash of
 // (seed, step, i).  Exact categorical sampling, no softmax pass, no host round trip, graph-replayable.
-__device__ __forceinline__ float gumbel_noise(unsigned seed, unsigned step, unsigned i) {
-  unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^ i;
-  z += 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  // 23 random bits + 0.5: every value k + 0.5 (k < 2^23) is exact in f32, so u lies in [2^-24, 1 - 2^-24] - never 0 or 1.
-  // (24 bits + 0.5f rounds 16777215.5 up to 2^24, i.e. u = 1 and +inf noise once in 2^24 draws: at V = 152 064 logits
-  // that is a garbage token in ~1 % of the sampled steps.)
-  const float u = ((float)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);
-  // inner log in full precision: for u near 1 (the upper Gumbel tail, the draws that decide rare picks) -log u is
-  // tiny and the fast log's absolute error would be a large relative one; the outer log has no such problem
-  return -__logf(-logf(u));
-}
-
 __global__ __launch_bounds__(256) void argmax_stage1_kernel(const float* __restrict__ logits, int V,
                                                             float* __restrict__ bval, int* __restrict__ bidx,
                                                             float inv_temp, unsigned seed,
@@ -869,5 +885,33 @@ extern "C" int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_
                      (float*)ws_val, (int*)ws_idx, inv_temp, seed, (const int*)step_ptr, ld_logits);
   hipLaunchKernelGGL(argmax_stage2_kernel, dim3(batch), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx,
                      nb, (int*)tokens, max_tokens, (int*)cur_token, (int*)step_ptr);
+  return vis_check_launch();
+}
+
+// K10 + K12 of the single-sequence step in two launches instead of three: logits = W rmsnorm(x) (f32, all N written, as
+// vis_gemv_bf16 with out_f32) with the pick's first stage in the epilogue, then the merging launch of vis_argmax_f32
+// (tokens[*step] = cur_token = pick, *step += 1).  Same comparison rule and the same Gumbel noise as vis_argmax_f32, so the
+// pick is the one vis_gemv_bf16 + vis_argmax_f32 make (tests/test_kernels_gpu.py::test_gemv_argmax_equals_two_stage).
+// ws_val / ws_idx: 2048 floats / ints.
+extern "C" int vis_gemv_bf16_argmax(const void* x, const void* W, const void* norm_w, void* logits, int N, int K, int ldw,
+                                    float eps, void* ws_val, void* ws_idx, void* tokens, int max_tokens, void* cur_token,
+                                    void* step_ptr, float inv_temp, unsigned seed, hipStream_t stream) {
+  if (!x || !W || !logits || !ws_val || !ws_idx || !tokens || !cur_token || !step_ptr || N <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (K % 8 != 0 || ldw % 8 != 0 || K * 2 > 60 * 1024 || !(inv_temp >= 0.f)) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)norm_w) & 15) return VIS_ERR_ARG;
+  GemvArgs p;
+  p.x = (const bf16_t*)x; p.W = (const bf16_t*)W; p.bias = nullptr; p.R = nullptr; p.norm_w = (const bf16_t*)norm_w;
+  p.y = logits; p.N = N; p.K = K; p.ldw = ldw; p.act = GV_ACT_NONE; p.out_f32 = 1; p.eps = eps; p.outs_per_block = 0;
+  p.nb = 1; p.ldx = 0; p.ldy = 0; p.ldr = 0;
+  p.am_val = (float*)ws_val; p.am_idx = (int*)ws_idx; p.am_step = (const int*)step_ptr; p.am_inv_temp = inv_temp;
+  p.am_seed = seed;
+  const int n_pairs = (N + 1) / 2;
+  int blocks = (n_pairs + 3) / 4;                     // the grid rule of gemv_bf16_launch
+  if (blocks > 1024) blocks = 1024 + (blocks - 1024) / 8;
+  if (blocks > 2048) blocks = 2048;
+  vis_clear_error();
+  hipLaunchKernelGGL((gemv_bf16_kernel<1, true>), dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
+  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx, blocks,
+                     (int*)tokens, max_tokens, (int*)cur_token, (int*)step_ptr);
   return vis_check_launch();
 }

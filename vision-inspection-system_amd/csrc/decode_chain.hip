@@ -27,12 +27,17 @@
 #include "decode_common.hip.h"
 
 // sync block (ints): [0] launches completed on this block (the granule tag of a launch is this + 1), [32] status
+#ifndef CH_CUE_ALL
+#define CH_CUE_ALL 0       // 1: the o projection waits for every head's cue before its first full read of the row (A/B)
+#endif
 #define CH_EPOCH 0
 #define CH_STATUS 32
 #define CH_INTS 64
 
 struct ChainArgs {
-  const bf16_t* x;        // [K] layer input (also the residual of the o projection)
+  const bf16_t* x;        // [K] layer input (also the residual of the o projection); with x_idx: the table's row 0
+  const int* x_idx;       // null, or a device int: the layer input is row *x_idx of x (embedding lookup of the new token)
+  int x_rows;
   const bf16_t* Wqkv;     // [Nqkv][ldw_qkv]
   const bf16_t* bqkv;     // [Nqkv] or null
   const bf16_t* norm_w;   // [K] input RMSNorm weight
@@ -171,6 +176,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs p) {
     // ------------------------------------------------------------------ projection role
     bf16_t* xs = (bf16_t*)smem;
     const int wid = b * 4 + wave;
+    if (p.x_idx) p.x += (size_t)min(max(*p.x_idx, 0), p.x_rows - 1) * p.K;   // (vis_gather_rows' clamp)
     GemvArgs ga;
     ga.W = p.Wqkv; ga.ldw = p.ldw_qkv; ga.N = p.Nqkv;
     const int nch = p.K >> 3, n_pairs_q = p.Nqkv >> 1;
@@ -205,12 +211,13 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs p) {
     go.W = p.Wo; go.ldw = p.ldw_o; go.N = p.No;
     const int nch_o = p.Ko >> 3;
     gv_load(A, go, false, min(wid, n_pairs_o - 1), 0, lane, nch_o);
-    // cue: the LAST granule of every head (cheap to poll: Hq words); then the whole row, every granule checked
+    // cue: the last granule of every head (cheap to poll: Hq words) until the FIRST head is out - the heads finish within
+    // ~2 us of each other -; from then on the whole row is polled, every granule checked
     if (wave == 0) {
       const gran_t* cue = p.attn_g + min(lane, Hq - 1) * 64 + 63;
       for (int it = 0; it < GV_CHAIN_SPIN_MAX; ++it) {
         const bool ok = gr_ok(gr_ld(cue), tag);
-        if (__all(ok)) break;
+        if (CH_CUE_ALL ? __all(ok) : __any(ok)) break;
         __builtin_amdgcn_s_sleep(8);
       }
     }
@@ -317,7 +324,7 @@ extern "C" long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit) {
 // bytes; both owned by the caller's stream (one pair per engine; zero both again after a non-zero status word).
 // Returns VIS_ERR_ARG for shapes the chained form does not cover (the caller then uses the four launches): head_dim != 128,
 // K or Hq * 128 above 4096, more than 64 query heads, a grid larger than the device holds resident.
-extern "C" int vis_decode_chain(const void* x, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
+extern "C" int vis_decode_chain(const void* x, const void* x_idx, int x_rows, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
                                 const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr,
                                 void* ws, void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o,
                                 int cache_tokens, int nsplit, float scale, float eps, hipStream_t stream) {
@@ -334,6 +341,8 @@ extern "C" int vis_decode_chain(const void* x, const void* Wqkv, const void* bqk
     return VIS_ERR_ARG;
   if (((uintptr_t)y | (uintptr_t)sync) & 3 || ((uintptr_t)ws & 7)) return VIS_ERR_ARG;
   ChainArgs p;
+  if (x_idx && x_rows <= 0) return VIS_ERR_ARG;
+  p.x_idx = (const int*)x_idx; p.x_rows = x_rows;
   p.x = (const bf16_t*)x; p.Wqkv = (const bf16_t*)Wqkv; p.bqkv = (const bf16_t*)bqkv; p.norm_w = (const bf16_t*)norm_w;
   p.Wo = (const bf16_t*)Wo; p.y = (bf16_t*)y;
   p.Nqkv = Nqkv; p.K = K; p.ldw_qkv = ldw_qkv; p.No = No; p.Ko = Ko; p.ldw_o = ldw_o; p.eps = eps;

@@ -20,7 +20,30 @@ struct GemvArgs {
   float eps;
   // vis_gemv_bf16_rows: nb input rows (<= the kernel's NB) share every weight read; element strides between rows
   int nb, ldx, ldy, ldr;
+  // vis_gemv_bf16_argmax (AMAX kernel instance only): per-workgroup (value, index) maxima of the pick's first stage
+  float* am_val;
+  int* am_idx;
+  const int* am_step;
+  float am_inv_temp;
+  unsigned am_seed;
 };
+
+__device__ __forceinline__ float gumbel_noise(unsigned seed, unsigned step, unsigned i) {
+  unsigned long long z = ((unsigned long long)seed << 32) ^ ((unsigned long long)step * 0x9E3779B97F4A7C15ull) ^ i;
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  // 23 random bits + 0.5: every value k + 0.5 (k < 2^23) is exact in f32, so u lies in [2^-24, 1 - 2^-24] - never 0 or 1.
+  // (24 bits + 0.5f rounds 16777215.5 up to 2^24, i.e. u = 1 and +inf noise once in 2^24 draws: at V = 152 064 logits
+  // that is a garbage token in ~1 % of the sampled steps.)
+  const float u = ((float)(z >> 41) + 0.5f) * (1.0f / 8388608.0f);
+  // inner log in full precision: for u near 1 (the upper Gumbel tail, the draws that decide rare picks) -log u is
+  // tiny and the fast log's absolute error would be a large relative one; the outer log has no such problem
+  return -__logf(-logf(u));
+}
+
+
 
 // NB: __builtin_bit_cast(bf16x2, v[i]) on a vector ELEMENT is miscompiled by hipcc 7.2 (always
 // element 0); extract the bf16 pairs with shufflevector from a whole-vector bit_cast instead.
@@ -262,6 +285,9 @@ struct DecAttnArgs {
 //   softmax: statistics per head over the <= 128 keys of the split (LDS).
 //   P * V  : each lane owns two output dims for all G heads and walks its wave's keys; V rows are read as
 //            256-byte coalesced rows, p[head][key] is an LDS broadcast; waves are merged through LDS.
+// LDS slot of key k of a split inside a head's score row: the keys one wave owns in P * V (k = wave + 4 i) are contiguous
+__device__ __forceinline__ int da_pos(int k) { return (k & 3) * (DA_MAXKEYS / 4) + (k >> 2); }
+
 template <int G>
 struct DecAttnLds {
   __attribute__((aligned(16))) bf16_t q_s[16][128];   // heads >= G are zero
@@ -448,51 +474,65 @@ __device__ __forceinline__ int decode_attn_split_body(DecAttnArgs p, DecAttnLds<
       // acc[r] = S^T[key = kbase + 4h + r][head = l15]
       if (l15 < G) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sc[l15][kbase + 4 * h + r] = acc[r] * p.scale_log2;
+        for (int r = 0; r < 4; ++r) sc[l15][da_pos(kbase + 4 * h + r)] = acc[r] * p.scale_log2;
       }
     }
   }
   __syncthreads();
+  CC_STAMP(6);
 
   // ---- per-head softmax statistics over this split (one wave per head)
   for (int g = wave; g < G; g += 4) {
     float mx = -1.0e30f;
-    for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, sc[g][i]);
+    for (int i = lane; i < nk; i += 64) mx = fmaxf(mx, sc[g][da_pos(i)]);
     mx = wave_max(mx);
     float ls = 0.f;
-    for (int i = lane; i < nk; i += 64) {
-      const float e = exp2f(sc[g][i] - mx);
-      sc[g][i] = e;
-      ls += e;
+    for (int i = lane; i < DA_MAXKEYS; i += 64) {      // slots past the split's end get p = 0: P * V runs branch-free
+      const float e = (i < nk) ? exp2f(sc[g][da_pos(i)] - mx) : 0.f;
+      sc[g][da_pos(i)] = e;
+      if (i < nk) ls += e;
     }
     ls = wave_sum(ls);
     if (lane == 0) { ml[g][0] = mx; ml[g][1] = ls; }
   }
   __syncthreads();
+  CC_STAMP(7);
 
   // ---- O[g][d] += p[g][key] * V[key][d]; lane owns d = 2*lane, 2*lane+1
   float acc0[G], acc1[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
   const uint32_t vnew = *(const uint32_t*)(&vnew_s[2 * lane]);
+  // this wave's keys (wave + 4 i) sit at 16 consecutive floats of a head's row (da_pos): four ds_read_b128 per head instead
+  // of 16 dependent broadcast reads (the one-read-per-key form took 3.5 us of the split's 7: tools/probes/chain_probe.py);
+  // every accumulator still adds its keys in ascending order - same bits
+  float v0[VROWS], v1[VROWS];
 #pragma unroll
   for (int i = 0; i < VROWS; ++i) {
-    const int kk = wave + 4 * i;
-    if (kk < nk) {  // wave-uniform
-      const uint32_t raw = (ks + kk == new_row) ? vnew : vreg[i];
-      const float v0 = __uint_as_float(raw << 16), v1 = __uint_as_float(raw & 0xffff0000u);
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float pw = sc[g][kk];
-        acc0[g] += pw * v0;
-        acc1[g] += pw * v1;
-      }
-    }
+    uint32_t raw = (ks + wave + 4 * i == new_row) ? vnew : vreg[i];
+    if (wave + 4 * i >= nk) raw = 0u;      // (a clamped duplicate row: whatever it holds, 0 x 0 adds nothing)
+    v0[i] = __uint_as_float(raw << 16);
+    v1[i] = __uint_as_float(raw & 0xffff0000u);
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    red[wave][g][2 * lane] = acc0[g];
-    red[wave][g][2 * lane + 1] = acc1[g];
+    f32x4 pq[VROWS / 4];
+#pragma unroll
+    for (int q = 0; q < VROWS / 4; ++q) pq[q] = *(const f32x4*)(&sc[g][wave * VROWS + 4 * q]);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VROWS; ++i) {      // keys past the split's end: p = 0 and v = 0, fma(0, 0, a) = a exactly
+      const float pw = pq[i >> 2][i & 3];
+      a0 += pw * v0[i];
+      a1 += pw * v1[i];
+    }
+    acc0[g] = a0;
+    acc1[g] = a1;
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    *(f32x2_*)(&red[wave][g][2 * lane]) = (f32x2_){acc0[g], acc1[g]};
   }
   __syncthreads();
   CC_STAMP(3);

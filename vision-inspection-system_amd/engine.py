@@ -161,8 +161,8 @@ class Qwen2VLEngine:
         self.step_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
         self.cur_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
         self.tokens_b = torch.zeros((Bm, self.max_ctx), dtype=torch.int32, device=dev)
-        self.ws_val = torch.empty(256 * Bm, dtype=torch.float32, device=dev)
-        self.ws_idx = torch.empty(256 * Bm, dtype=torch.int32, device=dev)
+        self.ws_val = torch.empty(max(256 * Bm, 2048), dtype=torch.float32, device=dev)
+        self.ws_idx = torch.empty(max(256 * Bm, 2048), dtype=torch.int32, device=dev)
         self.logits_b = torch.empty((Bm, cfg.vocab), dtype=torch.float32, device=dev)
         self.kcache, self.vcache = self.kcache_b[0], self.vcache_b[0]
         self.cos_t, self.sin_t = self.cos_b[0], self.sin_b[0]
@@ -965,7 +965,9 @@ class Qwen2VLEngine:
         cfg, w = self.cfg, self.w
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         scale = D ** -0.5
-        hip.gather_rows(w.embed, self.cur_token, self.d_x)
+        chained = self.chain_sync is not None
+        if not chained:
+            hip.gather_rows(w.embed, self.cur_token, self.d_x)
         x, x2 = self.d_x, self.d_x2
         if self.decode_weights == "fp8":
             for li, lw in enumerate(w.llm):
@@ -982,14 +984,15 @@ class Qwen2VLEngine:
             return
         for li, lw in enumerate(w.llm):
             if self.chain_sync is not None:
-                try:
-                    hip.decode_chain(x[0], lw.qkv_w, lw.qkv_b, lw.ln1_w, lw.o_w, x2[0], self.cos_t, self.sin_t,
-                                     self.kcache[li], self.vcache[li], self.step, self.chain_ws, self.chain_sync, Hq, Hkv, D,
-                                     self.nsplit, scale, cfg.rms_eps)
+                try:   # layer 0 reads the new token's embedding row itself (x_index): no gather launch
+                    hip.decode_chain(w.embed if li == 0 else x[0], lw.qkv_w, lw.qkv_b, lw.ln1_w, lw.o_w, x2[0], self.cos_t,
+                                     self.sin_t, self.kcache[li], self.vcache[li], self.step, self.chain_ws, self.chain_sync,
+                                     Hq, Hkv, D, self.nsplit, scale, cfg.rms_eps, x_index=self.cur_token if li == 0 else None)
                 except hip.HipLibraryError:
                     if li:
                         raise
-                    self.chain_sync = None          # the launcher refused the grid (not resident on this device): four launches
+                    self.chain_sync, chained = None, False     # the launcher refused the grid (not resident here): four launches
+                    hip.gather_rows(w.embed, self.cur_token, self.d_x)
             if self.chain_sync is None:
                 hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
                 hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
@@ -997,6 +1000,10 @@ class Qwen2VLEngine:
                 hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
             hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])
+        if chained:     # the pick's first stage rides in the lm_head epilogue
+            hip.gemv_argmax(x[0], w.lm_head, self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
+                            norm_w=w.final_norm_w, eps=cfg.rms_eps, temperature=self.temperature, seed=self.seed)
+            return
         hip.gemv(x[0], w.lm_head, self.logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
         hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
                    self.temperature, self.seed)

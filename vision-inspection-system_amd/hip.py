@@ -43,7 +43,8 @@ _SIGS = {
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
     "vis_decode_chain_sync_ints": "",
     "vis_decode_chain_ws_bytes": "iii",
-    "vis_decode_chain": "p" * 13 + "i" * 8 + "ff" + "p",
+    "vis_decode_chain": "ppi" + "p" * 12 + "i" * 8 + "ff" + "p",
+    "vis_gemv_bf16_argmax": "pppp" + "iii" + "f" + "ppp" + "i" + "pp" + "fu" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
     "vis_gemm_decode_ksplit": "ii",
     "vis_gemm_decode_bf16": "pppp" + "iiiiiiii" + "p",
@@ -689,14 +690,20 @@ def decode_chain_supported(n_q: int, n_kv: int, head_dim: int, hidden: int) -> b
 def decode_chain(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: Optional[torch.Tensor], norm_w: torch.Tensor,
                  o_w: torch.Tensor, y: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
                  v_cache: torch.Tensor, step: torch.Tensor, ws: torch.Tensor, sync: torch.Tensor, n_q: int, n_kv: int,
-                 head_dim: int, nsplit: int, scale: float, eps: float) -> None:
+                 head_dim: int, nsplit: int, scale: float, eps: float, x_index: Optional[torch.Tensor] = None) -> None:
     """qkv projection (+ RMSNorm, bias) -> rope / KV append / split attention + merge -> o projection (+ residual x) in ONE
     launch, bit-identical to gemv + decode_attn + gemv.  Single sequence: x [K], caches [Hkv, T, D], tables [T, D], step [1];
-    ws / sync from decode_chain_state."""
+    ws / sync from decode_chain_state.  With ``x_index`` (device int32 [1]) ``x`` is an [rows, K] table and the layer input is
+    its row x_index[0] (the new token's embedding: no separate gather launch)."""
     for t, n in ((x, "x"), (qkv_w, "qkv_w"), (norm_w, "norm_w"), (o_w, "o_w"), (y, "y"), (k_cache, "k_cache"),
                  (v_cache, "v_cache")):
         _bf16(t, "decode_chain " + n)
-    K = x.numel()
+    if x_index is not None:
+        if x.dim() != 2 or not x.is_contiguous() or x_index.dtype != torch.int32 or x_index.numel() != 1:
+            raise HipLibraryError("decode_chain: x_index needs a contiguous [rows, K] table and one int32")
+        K, x_rows = x.shape[1], x.shape[0]
+    else:
+        K, x_rows = x.numel(), 0
     nq = (n_q + 2 * n_kv) * head_dim
     if qkv_w.shape != (nq, K) or qkv_w.stride(1) != 1 or o_w.shape != (K, n_q * head_dim) or o_w.stride(1) != 1 \
             or norm_w.numel() != K or y.numel() != K or (qkv_b is not None and qkv_b.numel() != nq):
@@ -712,7 +719,7 @@ def decode_chain(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: Optional[torch.Ten
     if ws.dtype != torch.int64 or ws.numel() * 8 < lib.vis_decode_chain_ws_bytes(n_q, n_kv, nsplit) \
             or sync.dtype != torch.int32 or sync.numel() < lib.vis_decode_chain_sync_ints():
         raise HipLibraryError("decode_chain: workspace too small")
-    rc = lib.vis_decode_chain(_ptr(x), _ptr(qkv_w), _ptr(qkv_b), _ptr(norm_w), _ptr(o_w), _ptr(y), _ptr(cos_t), _ptr(sin_t),
+    rc = lib.vis_decode_chain(_ptr(x), _ptr(x_index), x_rows, _ptr(qkv_w), _ptr(qkv_b), _ptr(norm_w), _ptr(o_w), _ptr(y), _ptr(cos_t), _ptr(sin_t),
                               _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(ws), _ptr(sync), n_q, n_kv, head_dim, K,
                               qkv_w.stride(0), o_w.stride(0), T, nsplit, scale, eps, _stream())
     _check(rc, "vis_decode_chain")
@@ -725,6 +732,24 @@ def decode_chain_rows(ws: torch.Tensor, n_q: int, n_kv: int):
     g = ws[:nq + n_q * 64] & 0xFFFFFFFF
     rows = g.to(torch.int32).view(torch.bfloat16)
     return rows[:2 * nq], rows[2 * nq:]
+
+
+def gemv_argmax(x: torch.Tensor, w: torch.Tensor, logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor,
+                tokens: torch.Tensor, cur_token: torch.Tensor, step: torch.Tensor, norm_w: Optional[torch.Tensor] = None,
+                eps: float = 1e-6, temperature: float = 0.0, seed: int = 0) -> None:
+    """lm_head GEMV (f32 logits, optional fused RMSNorm) + next-token pick in two launches: gemv(out f32) + argmax with the
+    pick's first stage in the GEMV epilogue.  Single sequence."""
+    _bf16(x, "gemv_argmax x"); _bf16(w, "gemv_argmax w")
+    N, K = w.shape
+    if x.numel() != K or w.stride(1) != 1 or logits.dtype != torch.float32 or logits.numel() != N:
+        raise HipLibraryError("gemv_argmax: bad shapes")
+    if ws_val.dtype != torch.float32 or ws_idx.dtype != torch.int32 or ws_val.numel() < 2048 or ws_idx.numel() < 2048 \
+            or tokens.dtype != torch.int32 or cur_token.numel() != 1 or step.numel() != 1 or not tokens.is_contiguous():
+        raise HipLibraryError("gemv_argmax: workspace too small / bad state shapes")
+    rc = load().vis_gemv_bf16_argmax(_ptr(x), _ptr(w), _ptr(norm_w), _ptr(logits), N, K, w.stride(0), eps, _ptr(ws_val),
+                                     _ptr(ws_idx), _ptr(tokens), tokens.numel(), _ptr(cur_token), _ptr(step),
+                                     (1.0 / temperature) if temperature > 0 else 0.0, seed & 0xFFFFFFFF, _stream())
+    _check(rc, "vis_gemv_bf16_argmax")
 
 
 def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tokens: torch.Tensor,
