@@ -5,8 +5,8 @@ import numpy as np
 import pytest
 from PIL import Image
 
-from vision_inspection_system_amd.image_quality import (ImageQualityAssessment, check_image_quality, gray_u8,
-                                                        laplacian_reflect101)
+from oracle.image_quality_ref import gray_u8, laplacian_reflect101
+from vision_inspection_system_amd.image_quality import ImageQualityAssessment, check_image_quality
 
 
 def test_numpy_statement_basics():

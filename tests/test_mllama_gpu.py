@@ -166,3 +166,26 @@ def test_stacked_prompt_passes_equal_one_pass_per_request(device, monkeypatch):
     assert stacked[0] == stacked[3] and stacked[1] == stacked[4]
     for b in range(3):
         assert eng.generate(ids, frames[b], max_new_tokens=10, stop_on_eos=False)[0] == stacked[b][0]
+
+
+def test_max_batch_one_engine_serves_callable_requests(device):
+    """with VIS_MAX_BATCH = 1 the batched buffers do not exist, yet the batch seam still hands every verify_many
+    group over as callables (Futures).  A one-request lazy batch must take the single-sequence path - same tokens as
+    generate() - and a callable that raises must come back as that exception in its slot, not as an AttributeError."""
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    from vision_inspection_system_amd.mllama_weights import MllamaConfig, pack_device_weights, synth_state_dict
+    cfg = MllamaConfig.tiny()
+    eng = MllamaEngine(cfg, pack_device_weights(cfg, synth_state_dict(cfg, seed=0), device), device, max_ctx=256, max_batch=1)
+    assert not hasattr(eng, "b_x")                       # no batched-decode buffers at max_batch == 1
+    g = np.load(os.path.join(HERE, "golden", "mllama_tiny.npz"))
+    ids, fr = g["a_ids"].tolist(), torch.from_numpy(g["a_image"]).to(device)
+    direct = eng.generate(ids, fr, max_new_tokens=8, stop_on_eos=False)
+    assert eng.generate_batch([lambda: (ids, fr)], max_new_tokens=8, stop_on_eos=False) == [direct]
+    assert eng.generate_batch([(ids, fr)], max_new_tokens=8, stop_on_eos=False) == [direct]
+
+    def broken():
+        raise OSError("image file is truncated")
+    out = eng.generate_batch([broken], max_new_tokens=8, stop_on_eos=False)
+    assert len(out) == 1 and isinstance(out[0], OSError)
+    with pytest.raises(ValueError):
+        eng.generate_batch([(ids, fr), (ids, fr)], max_new_tokens=4)      # two requests do not fit max_batch = 1
