@@ -95,6 +95,21 @@ def prefill_flops(cfg, n_patches: int, S: int) -> float:
     return vit_gemm + vit_attn + llm_gemm + llm_attn
 
 
+def prefill_flops_executed(cfg, n_patches: int, S: int, P: int, B: int) -> float:
+    """FLOPs actually executed per image when B images share a text prefix of P tokens (computed once per batch): the whole
+    vision tower, the LLM projections over the S - P suffix rows + 1 / B of the prefix rows, causal attention of those rows."""
+    full = prefill_flops(cfg, n_patches, S)
+    if P <= 0 or B <= 1:
+        return full
+    D = cfg.head_dim
+    per_layer = cfg.hidden * (cfg.heads + 2 * cfg.kv_heads) * D + cfg.heads * D * cfg.hidden + 3 * cfg.hidden * cfg.intermediate
+    llm_gemm_full = 2.0 * S * cfg.layers * per_layer
+    llm_attn_full = cfg.layers * 2.0 * S * S * cfg.heads * D
+    rows = (S - P) + P / B
+    sq = (S * S - P * P) + P * P / B
+    return full - llm_gemm_full - llm_attn_full + 2.0 * rows * cfg.layers * per_layer + cfg.layers * 2.0 * sq * cfg.heads * D
+
+
 def gemv_bytes_per_step(cfg) -> float:
     D = cfg.head_dim
     per_layer = cfg.hidden * (cfg.heads + 2 * cfg.kv_heads) * D + cfg.heads * D * cfg.hidden \

@@ -67,25 +67,48 @@ def batch_block(engine, frame, n_patches, n_img_tok, B, new, prompt_tokens, step
         step_bytes += cfg.layers * cfg.heads * cfg.head_dim * cfg.hidden
     bpl = step_bytes / k_launches
     flops = bn.prefill_flops(cfg, n_patches, S) * B
+    P = engine.shared_prefix_len([ids] * B) if (B > 1 and os.environ.get("VIS_SHARE_PREFIX", "1") != "0") else 0
+    flops_ex = bn.prefill_flops_executed(cfg, n_patches, S, P, B) * B
     peak_tf = bn.MFMA_BF16_PEAK_TF * (2 if engine.prefill_dtype == "fp8" else 1)
     return {
         "images_per_s": B / wall, "ms_per_step": wall * 1e3, "batch": B, "steps": steps, "prompt_tokens": S,
         "new_tokens": new, "prompt_pass_ms_per_image": t_pre * 1e3 / B, "decode_ms_per_step": t_dec * 1e3 / (new - 1),
         "prefill_mfma": {"achieved": flops / t_pre / 1e12, "peak": peak_tf, "unit": "TFLOP/s",
                          "frac": flops / t_pre / 1e12 / peak_tf,
-                         "note": "FLOPs of B full prompt passes / time of the B passes (the shared text prefix runs once per "
-                                 "batch, so this is an effective rate)"
+                         "executed_achieved": flops_ex / t_pre / 1e12, "executed_frac": flops_ex / t_pre / 1e12 / peak_tf,
+                         "shared_prefix_tokens": P,
+                         "note": "achieved / frac: FLOPs of B full prompt passes / time of the B passes (the shared text prefix "
+                                 "runs once per batch, so this is an EFFECTIVE rate); executed_*: only the arithmetic that ran "
+                                 "(vision tower + suffix rows + the prefix once per batch)"
                                  + ("; LLM + ViT projections on the fp8 MFMA, attention bf16: priced against the fp8 dense peak"
                                     if engine.prefill_dtype == "fp8" else "")},
         "roofline": {"bound": "hbm", "kernel": "gemm_decode_stream_kernel" + ("<fp8>" if fp8 else ""),
                      "achieved": bpl / k_avg / 1e9, "peak": bn.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bpl / k_avg / 1e9 / bn.HBM_PEAK_GBS,
-                     # PMC passes exist for the bf16 kernel at 64 rows only (profiles/*_decode_stream_traffic.json)
-                     "traffic": bn.measured_traffic("decode_stream") if (B == 64 and not fp8) else None,
+                     # PMC passes exist for the bf16 kernel at 64 rows and for the fp8 kernel at 4 rows (profiles/*_traffic.json)
+                     "traffic": bn.measured_traffic("decode_stream") if (B == 64 and not fp8) else
+                     (bn.measured_traffic("decode_stream_fp8") if (B == 4 and fp8) else None),
                      "bytes_per_launch": bpl, "avg_launch_us": k_avg * 1e6, "launches_per_step": k_launches},
         "dtype": ("fp8-e4m3 prompt-pass projections / " if engine.prefill_dtype == "fp8" else "bf16 prompt pass / ")
         + ("fp8-e4m3 decode weights" if engine.decode_weights == "fp8" else "bf16 decode weights"),
     }
+
+
+def mllama_prefill_flops(mc, n_rows: int, n_present: int, S: int) -> float:
+    """Arithmetic of one Llama-3.2-11B-Vision prompt pass: the vision tower over the n_rows-token tile canvas (32 local + 8
+    global layers, attention inside the present tiles' tokens), the projector, the 32 self-attention + 8 cross-attention
+    decoder layers over S prompt rows (cross keys / values projected from the n_present vision tokens), lm_head of one row."""
+    E, H, D = mc.v_hidden, mc.hidden, mc.head_dim
+    vl = mc.v_layers + mc.v_global_layers
+    vit = 2.0 * n_rows * (3 * mc.patch * mc.patch * E + vl * (4 * E * E + 2 * E * mc.v_mlp)) + vl * 4.0 * n_present * n_present * E
+    vit += 2.0 * n_present * mc.v_out * H
+    n_cross = len(mc.cross_layers)
+    n_self = mc.layers - n_cross
+    kvw = mc.kv_heads * D
+    mlp = 3 * H * mc.intermediate
+    self_l = 2.0 * S * (H * (H + 2 * kvw) + H * H + mlp) + 2.0 * S * S * mc.heads * D
+    cross_l = 2.0 * S * (2 * H * H + mlp) + 2.0 * n_present * 2 * H * kvw + 4.0 * S * n_present * mc.heads * D
+    return vit + n_self * self_l + n_cross * cross_l + 2.0 * H * mc.vocab
 
 
 def dual_block(insp, aud, B, new, prompt_tokens=700, steps=2):
@@ -135,9 +158,44 @@ def dual_block(insp, aud, B, new, prompt_tokens=700, steps=2):
         if it:
             rows.append((t1 - t0, t2 - t1, ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])))
     gpu, host, t_i, t_a = (float(np.mean([r[i] for r in rows])) for i in range(4))
-    return {"batch": B, "images_per_s": B / (gpu + host), "ms_per_image": (gpu + host) * 1e3 / B,
-            "inspector_ms_per_image": t_i / B, "auditor_ms_per_image": t_a / B, "postprocess_ms_per_image": host * 1e3 / B,
-            "new_tokens_per_model": new, "verdict": verdict.verdict, "resident_GB": torch.cuda.memory_allocated() / 1e9}
+    out = {"batch": B, "images_per_s": B / (gpu + host), "ms_per_image": (gpu + host) * 1e3 / B,
+           "inspector_ms_per_image": t_i / B, "auditor_ms_per_image": t_a / B, "postprocess_ms_per_image": host * 1e3 / B,
+           "new_tokens_per_model": new, "verdict": verdict.verdict, "resident_GB": torch.cuda.memory_allocated() / 1e9}
+    if B > 1:
+        # roofline of the step's two halves: the prompt passes against the dense bf16 MFMA peak (executed arithmetic: the
+        # Inspector's text prefix and the Auditor's identical prompt run once per group, not per image - see the notes), the
+        # shared decode loops against HBM (weights streamed once per step for all B sequences)
+        bn = _bench()
+        ti, ta = dict(insp.last_timing), dict(aud.last_timing)
+        n_patches = (th // qc.patch) * (tw // qc.patch)
+        Sq = len(q_ids)
+        P = insp.shared_prefix_len([q_ids] * B)
+        f_i = bn.prefill_flops_executed(qc, n_patches, Sq, P, B)
+        f_a = mllama_prefill_flops(mc, aud.TP if hasattr(aud, "TP") else 6432, 4 * mc.tile_tokens, len(m_ids))
+        wb_i = bn.gemv_bytes_per_step(qc)
+        wb_a = sum(t.numel() * 2 for lw in aud.w.layers for t in (lw.qkv_w, lw.o_w, lw.gateup_w, lw.down_w) if t is not None) \
+            + aud.w.lm_head.numel() * 2
+        steps_i, steps_a = max(1, ti.get("decode_steps", new - 1)), max(1, ta.get("decode_steps", new - 1))
+        out["roofline"] = {
+            "prompt_pass": {"bound": "mfma", "peak": bn.MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                            "inspector": {"ms_per_image": ti["prefill_ms"] / B, "executed_TF_per_image": f_i / 1e12,
+                                          "achieved": f_i * B / (ti["prefill_ms"] * 1e-3) / 1e12,
+                                          "frac": f_i * B / (ti["prefill_ms"] * 1e-3) / 1e12 / bn.MFMA_BF16_PEAK_TF},
+                            "auditor": {"ms_per_image": ta["prefill_ms"] / B, "executed_TF_per_image": f_a / 1e12,
+                                        "achieved": f_a * B / (ta["prefill_ms"] * 1e-3) / 1e12,
+                                        "frac": f_a * B / (ta["prefill_ms"] * 1e-3) / 1e12 / bn.MFMA_BF16_PEAK_TF,
+                                        "note": "per-image arithmetic of the tower + decoder; the text rows of a group's identical "
+                                                "prompts are stacked, not skipped"}},
+            "decode": {"bound": "hbm", "peak": bn.HBM_PEAK_GBS, "unit": "GB/s",
+                       "inspector": {"ms_per_step": ti["decode_ms"] / steps_i, "weight_bytes_per_step": wb_i,
+                                     "achieved": wb_i / (ti["decode_ms"] / steps_i * 1e-3) / 1e9,
+                                     "frac": wb_i / (ti["decode_ms"] / steps_i * 1e-3) / 1e9 / bn.HBM_PEAK_GBS},
+                       "auditor": {"ms_per_step": ta["decode_ms"] / steps_a, "weight_bytes_per_step": wb_a,
+                                   "achieved": wb_a / (ta["decode_ms"] / steps_a * 1e-3) / 1e9,
+                                   "frac": wb_a / (ta["decode_ms"] / steps_a * 1e-3) / 1e9 / bn.HBM_PEAK_GBS},
+                       "note": "whole decode step (projections + attention over the KV caches + finalisations) against the weight "
+                               "bytes alone; kernels per step: profiles/r04_dual_kernel_stats.csv"}}
+    return out
 
 
 def seam_block(engine, n_images=64, size=1024, new=128, model_id="synthetic:bench-seam"):

@@ -888,6 +888,45 @@ extern "C" int vis_argmax_f32(const void* logits, int V, void* ws_val, void* ws_
   return vis_check_launch();
 }
 
+// argmax_stage2_kernel for up to 2048 per-workgroup maxima (vis_gemv_bf16_argmax): 256 threads, every thread's eight
+// entries requested at once (the 64-thread form walks them in 32 dependent round trips: 11.5 us per token in the r04 trace)
+__global__ __launch_bounds__(256) void argmax_merge_kernel(const float* __restrict__ bval, const int* __restrict__ bidx, int nb,
+                                                           int* __restrict__ tokens, int max_tokens,
+                                                           int* __restrict__ cur_token, int* __restrict__ step_ptr) {
+  const int tid = threadIdx.x;
+  float v[8];
+  int ix[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int i = min(tid + 256 * k, nb - 1);        // (clamped duplicates lose every tie against themselves: harmless)
+    v[k] = bval[i];
+    ix[k] = bidx[i];
+  }
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+    if (tid + 256 * k < nb && (v[k] > best || (v[k] == best && ix[k] < bi))) { best = v[k]; bi = ix[k]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  if ((tid & 63) == 0) { sv[tid >> 6] = best; si[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+    const int st = *step_ptr;
+    if (st < max_tokens) tokens[st] = bi;
+    *cur_token = bi;
+    *step_ptr = st + 1;
+  }
+}
+
 // K10 + K12 of the single-sequence step in two launches instead of three: logits = W rmsnorm(x) (f32, all N written, as
 // vis_gemv_bf16 with out_f32) with the pick's first stage in the epilogue, then the merging launch of vis_argmax_f32
 // (tokens[*step] = cur_token = pick, *step += 1).  Same comparison rule and the same Gumbel noise as vis_argmax_f32, so the
@@ -911,7 +950,7 @@ extern "C" int vis_gemv_bf16_argmax(const void* x, const void* W, const void* no
   if (blocks > 2048) blocks = 2048;
   vis_clear_error();
   hipLaunchKernelGGL((gemv_bf16_kernel<1, true>), dim3(blocks), dim3(256), (size_t)K * 2, stream, p);
-  hipLaunchKernelGGL(argmax_stage2_kernel, dim3(1), dim3(64), 0, stream, (const float*)ws_val, (const int*)ws_idx, blocks,
+  hipLaunchKernelGGL(argmax_merge_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws_val, (const int*)ws_idx, blocks,
                      (int*)tokens, max_tokens, (int*)cur_token, (int*)step_ptr);
   return vis_check_launch();
 }

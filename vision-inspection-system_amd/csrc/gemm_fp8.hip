@@ -17,6 +17,17 @@
 #include "common.hip.h"
 
 #define F8_B 256
+// XOR applied to the 16-byte chunk index of tile row r in the LDS image.  A lane of the K = 128 MFMA reads TWO chunks of
+// its row (2h and 2h + 1), and `r & 7` - the swizzle of the bf16 kernels, whose lanes read one chunk - put every
+// ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) on 8 of the 16 slots of the 256-byte bank row twice
+// (profiles/r04_fp8_gemm_pmc.txt: SQ_LDS_BANK_CONFLICT = 4 x SQ_ACTIVE_INST_LDS on the gate/up shape).  With bits 1 and 3 of
+// the row number the two row sets of a group (rows {0-3, 12-15} at chunk c, rows {4-11} at chunk c ^ 2) take disjoint
+// halves of the chunk positions: conflict-free for both reads in all four groups (exhaustive check in the r04 notes).
+#ifdef F8_SWZ_OLD      // A/B build only (tools/ab_bench.sh): the r03 swizzle
+#define F8_SWZ(r) ((r) & 7)
+#else
+#define F8_SWZ(r) ((((r) >> 1) & 1) | ((((r) >> 3) & 1) << 2))
+#endif
 #define F8_BK 128                                  // K elements = bytes per tile row per K-step
 #define F8_STAGE_BYTES (2 * F8_B * F8_BK)          // 65536
 #define F8_LDS_BYTES (2 * F8_STAGE_BYTES)          // 131072
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_128x128_kernel(GemmF8Args p) 
   for (int i = 0; i < 4; ++i) {
     const int c = i * 256 + tid;
     const int row = c >> 3;
-    const int ch = (c & 7) ^ (row & 7);
+    const int ch = (c & 7) ^ F8_SWZ(row);
     a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.lda + ch * 16;
     w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.ldw + ch * 16;
   }
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_128x128_kernel(GemmF8Args p) 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  const int sw = lane & 7;
+  const int sw = F8_SWZ(l15);
   const int rdlo = l15 * 128 + (((2 * h) ^ sw) << 4);
   const int rdhi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
   const int a_rd = wm * 64 * 128;
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
   for (int i = 0; i < 4; ++i) {
     const int c = i * 512 + tid;
     const int row = c >> 3;
-    const int ch = (c & 7) ^ (row & 7);
+    const int ch = (c & 7) ^ F8_SWZ(row);
     a_off[i] = (uint32_t)(min(m0 + row, p.M - 1) - m0) * (uint32_t)p.lda + ch * 16;
     w_off[i] = (uint32_t)(min(n0 + row, p.N - 1) - n0) * (uint32_t)p.ldw + ch * 16;
   }
@@ -235,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int sw = lane & 7;
+  const int sw = F8_SWZ(l15);
   const int rdlo = l15 * 128 + (((2 * h) ^ sw) << 4);
   const int rdhi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
   const int a_rd = wm * 128 * 128;           // + i * 2048
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_pp_kernel(GemmF8Args 
   for (int i = 0; i < 2; ++i) {
     const int c = i * 512 + tid;
     const int hr = c >> 3;
-    const int ch = (c & 7) ^ (hr & 7);
+    const int ch = (c & 7) ^ F8_SWZ(hr);
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int arow = (hr >> 6) * 128 + q * 64 + (hr & 63);
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_pp_kernel(GemmF8Args 
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int sw = l15 & 7;
+  const int sw = F8_SWZ(l15);
   const int rd_lo = l15 * 128 + (((2 * h) ^ sw) << 4);
   const int rd_hi = l15 * 128 + (((2 * h + 1) ^ sw) << 4);
   const int a_rd = wr * (64 * 128);   // + ii * 2048
