@@ -59,6 +59,34 @@ def test_7b_graph_replay_equals_eager(big):
     assert eager == graph
 
 
+def test_7b_chained_decode_equals_four_launches(big, monkeypatch):
+    """The single-sequence decode step with the head of every layer as ONE chained launch (csrc/decode_chain.hip; the first
+    layer reading the token's embedding row itself, the pick's first stage in the lm_head epilogue) against the same step as
+    separate launches (VIS_DECODE_CHAIN=0), full depth, exact 7B shapes: every generated token and the last step's 152 064
+    logits bit for bit, eager and as a replayed hipGraph, greedy and sampled; the chain's status word stays clean."""
+    from vision_inspection_system_amd import hip
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    cfg, eng, (ra, rb) = big
+    assert eng.chain_sync is not None, "the chained layer head must be the default decode path at 7B shapes"
+    monkeypatch.setenv("VIS_DECODE_CHAIN", "0")
+    plain = Qwen2VLEngine(cfg, eng.w, eng.device, max_ctx=4096)
+    monkeypatch.delenv("VIS_DECODE_CHAIN")
+    assert plain.chain_sync is None
+    try:
+        for temperature, use_graph in ((0.0, True), (0.0, False), (0.7, True)):
+            a = eng.generate(rb[0], rb[1], max_new_tokens=24, ignore_eos=True, use_graph=use_graph, temperature=temperature, seed=11)
+            la = eng.logits.clone()
+            b = plain.generate(rb[0], rb[1], max_new_tokens=24, ignore_eos=True, use_graph=use_graph, temperature=temperature,
+                               seed=11)
+            assert a == b, f"tokens differ (temperature {temperature}, graph {use_graph})"
+            assert torch.equal(la, plain.logits), "last-step logits differ"
+            assert int(eng.chain_sync[hip.CHAIN_STATUS_WORD]) == 0
+        assert int(eng.chain_sync[0]) > 0        # launches were counted: the chained path really ran
+    finally:
+        del plain
+        torch.cuda.empty_cache()
+
+
 def test_7b_decode_step_agrees_with_prompt_pass(big):
     """Logits of the token after (prompt + 3 generated tokens): once from three decode steps on the KV cache, once
     from a prompt pass over the extended prompt.  Same function, two kernel families (GEMV / cache attention vs MFMA

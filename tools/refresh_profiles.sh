@@ -11,5 +11,7 @@ rm -rf $O && mkdir -p $O
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 3 --warmup 1 --no-blocks > $O/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o bench -- python3 bench.py --steps 1 --warmup 0 --new-tokens 4 --no-cpu-baseline --no-blocks --no-graph > $O/bench_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o bench -- python3 bench.py --steps 1 --warmup 0 --new-tokens 4 --no-cpu-baseline --no-blocks --no-graph > $O/bench_write.log 2>&1
-python tools/summarize_profile.py --round $R --stats $O/stats --fetch $O/fetch --write $O/write --bench-log $O/bench_stats.log --out $O/profiles
+# the roofline kernel of the chained step is the <1, false> instance (gate/up + down); the lm_head is <1, true>
+python tools/summarize_profile.py --round $R --stats $O/stats --fetch $O/fetch --write $O/write --bench-log $O/bench_stats.log --out $O/profiles \
+    --traffic-kernel "gemv_bf16_kernel<1, false>"
 ls -la $O/profiles

@@ -47,7 +47,7 @@ def main():
                             r["MaxNs"]])
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(one(os.path.join(a.stats, "**", "*_kernel_trace.csv")))):
-            if "gemv_bf16_kernel" in r["Kernel_Name"]:      # gemv_bf16_kernel<1> since the multi-row form
+            if "gemv_bf16_kernel" in r["Kernel_Name"]:      # <1, false>: projections; <1, true>: lm_head with the pick's first stage
                 agg[int(r["Grid_Size_X"]) // 256].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
         with open(os.path.join(a.out, f"{a.round}_gemv_by_shape.csv"), "w", newline="") as f:
             w = csv.writer(f)
