@@ -506,12 +506,12 @@ def run_dry(args, rank: int, world: int) -> None:
     for _ in range(args.warmup):
         one_step()
     if world > 1:
-        dist.barrier()
+        _cpu_barrier(dist)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     if world > 1:
-        dist.barrier()
+        _cpu_barrier(dist)
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -525,8 +525,39 @@ def run_dry(args, rank: int, world: int) -> None:
                           "config": {"workload": "launcher / gather rehearsal on CPU", "backend": args.backend,
                                      "parallelism": f"dp{world}"}}), flush=True)
     if world > 1:
-        dist.barrier()
+        _cpu_barrier(dist)
         dist.destroy_process_group()
+
+
+def _cpu_barrier(dist) -> None:
+    """Barrier of a CPU-only (gloo) rehearsal: an all_reduce of one CPU element.  dist.barrier() asks PyTorch for the current
+    accelerator and thereby opens the GPU in every rank even when it is hidden - a dry run must not touch it."""
+    dist.all_reduce(torch.zeros(1))
+
+
+class HostOnlyEngine:
+    """--dry-ingest: stands where the Inspector's engine stands and consumes its requests WITHOUT a model or a GPU, so that
+    run_batch_inspection does everything the seam does on the HOST - a3 encode (PIL thumbnail / JPEG q85 / base64) and the
+    service-side base64 + Huffman decode on the ingest pool, tokenisation, reply parsing, consensus, gates, aggregation - and
+    nothing else.  What it times is the host ceiling of a rank (the 8-GPU expectation assumes eight ranks'
+    ingest pools and launch threads do not contend).  Test / measurement infrastructure, never selected by the product."""
+    host_only = True
+
+    def __init__(self, cfg, max_batch: int):
+        import threading
+        self.cfg, self.max_batch, self.device = cfg, max_batch, "cpu"
+        self.lock = threading.Lock()
+        self.last_timing: dict = {}
+
+    def generate_batch(self, requests, max_new_tokens: int = 128, **_kw) -> list:
+        out = []
+        for r in requests:
+            try:
+                ids, _frames = r() if callable(r) else r        # waits for the request's encode + Huffman decode
+                out.append([65, 66, 67, 68])
+            except Exception as e:      # noqa: BLE001 - a failed request keeps its exception, as with the real engine
+                out.append(e)
+        return out
 
 
 def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
@@ -565,11 +596,20 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
     os.environ["VIS_SYNTHETIC_REPLY"] = reply           # random weights answer noise: keep the agents on the success path
     CL.set_mock_reply(reply)
     model_id = {"7b": "synthetic:7b", "7b25": "synthetic:qwen2.5-vl-7b", "tiny": "synthetic:tiny"}[args.model]
+    host_only = dry and args.dry_ingest
+    if host_only:      # the Inspector on the local provider with the engine stand-in: the real ingest path, no model
+        from vision_inspection_system_amd.config import Qwen2VLConfig
+        from vision_inspection_system_amd.tokenizer import ByteTokenizer
+        model_id = "synthetic:host-only"
+        hcfg = Qwen2VLConfig.qwen2_vl_7b()
+        tok = ByteTokenizer(hcfg.vocab, hcfg.image_token_id, hcfg.vision_start_id, hcfg.vision_end_id, hcfg.eos_ids)
+        CL.register_model(model_id, "cuda:0", CL.LoadedModel(
+            HostOnlyEngine(hcfg, max(1, min(64, int(os.environ.get("VIS_MAX_BATCH", "64"))))), tok, hcfg, model_id))
     os.environ.setdefault("VIS_TINY_MAX_CTX", "4096")   # the tiny model's byte tokenizer spends one token per prompt character
     new = args.new_tokens if args.model != "tiny" else min(args.new_tokens, 24)
     local_aud = args.auditor == "mllama" and not dry
     C.set_config(C.Config(
-        vlm_inspector_provider="mock" if dry else "mi355x", vlm_inspector_model=model_id, vlm_inspector_max_tokens=new,
+        vlm_inspector_provider="mock" if (dry and not host_only) else "mi355x", vlm_inspector_model=model_id, vlm_inspector_max_tokens=new,
         vlm_inspector_temperature=0.0, vlm_auditor_provider="mi355x" if local_aud else "mock",
         vlm_auditor_model=("synthetic:mllama-11b" if args.model != "tiny" else "synthetic:mllama-tiny") if local_aud else "mock",
         vlm_auditor_max_tokens=new, vlm_auditor_temperature=0.0, max_image_dimension=2048))
@@ -591,7 +631,7 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
         clear_encode_cache()
         CL.TIMING_LOG.clear()
         if world > 1:
-            dist.barrier()
+            (_cpu_barrier(dist) if dry else dist.barrier())
         if not dry:
             torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -600,7 +640,7 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
             torch.cuda.synchronize()
         mine = time.perf_counter() - t0
         if world > 1:
-            dist.barrier()
+            (_cpu_barrier(dist) if dry else dist.barrier())
         elapsed = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([elapsed], dtype=torch.float64,
@@ -623,7 +663,7 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
                 "dtype": "none" if dry else "bf16", "data": "synthetic", "dry": dry,
                 "config": {"workload": f"configs[3]: run_batch_inspection, {args.images} x {size}x{size} PNG files sharded "
                                        f"paths[r::{world}] over {world} rank(s), one gather of the records; Inspector "
-                                       f"{'canned (no model)' if dry else model_id}, Auditor {args.auditor if not dry else 'canned'}",
+                                       f"{('host-only stand-in on the local provider: real a3 encode + base64 / Huffman decode on the ingest pool, no model' if host_only else 'canned (no model)') if dry else model_id}, Auditor {args.auditor if not dry else 'canned'}",
                            "images": args.images, "completed": done, "new_tokens": new,
                            "ingest_threads_per_rank": int(os.environ["VIS_INGEST_THREADS"]), "host_cpus": cores,
                            "parallelism": f"dp{world} (whole images)" if not args.share_gpu else
@@ -634,7 +674,7 @@ def run_batch256(args, rank: int, world: int, local_rank: int) -> None:
                         "and the gather"}), flush=True)
     finally:
         if world > 1:
-            dist.barrier()
+            (_cpu_barrier(dist) if dry else dist.barrier())
         if rank == 0 and tmp:
             import shutil
             shutil.rmtree(tmp, ignore_errors=True)
@@ -682,6 +722,10 @@ def main():
                          "paths[r::W], whole seam per rank - a3 encode, JPEG decode, ingest pool, Inspector engine, parse, "
                          "consensus, gates - and ONE gather of the records), timed across the call")
     ap.add_argument("--images", type=int, default=256, help="--workload batch256: number of PNG files")
+    ap.add_argument("--dry-ingest", action="store_true",
+                    help="--workload batch256 --dry-device cpu: the Inspector on the LOCAL provider with an engine stand-in "
+                         "(HostOnlyEngine): real a3 encode + base64 / Huffman decode on the ingest pool, no model, no GPU - "
+                         "the host ceiling of a rank")
     ap.add_argument("--auditor", default="mock", choices=["mock", "mllama"],
                     help="--workload batch256: Auditor on the canned-response client (Inspector-only timing) or on the "
                          "local Llama-3.2-11B-Vision engine (dual-VLM batch inspection)")
@@ -690,6 +734,11 @@ def main():
                          "batch inspection) - NOT the headline single-image configuration")
     args = ap.parse_args()
 
+    if args.dry_device == "cpu":
+        # a dry run must not open the GPU at all (torch.cuda.is_available() would, in every rank): hide it before any
+        # CUDA / HIP call - the variables are inherited by the ranks the launcher starts
+        os.environ["HIP_VISIBLE_DEVICES"] = ""
+        os.environ["CUDA_VISIBLE_DEVICES"] = ""
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # nobody launched ranks for us: do it here, BEFORE any GPU call (see launch_ranks)
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))

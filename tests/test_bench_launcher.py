@@ -61,3 +61,16 @@ def test_batch256_workload_three_ranks_on_cpu():
     assert out["n_gpus"] == 3 and out["scaling"] == "strong" and out["dry"] is True and out["value"] > 0
     assert out["config"]["images"] == 14 and out["config"]["completed"] == 14
     assert [p["images"] for p in out["per_rank"]] == [5, 5, 4] and [p["rank"] for p in out["per_rank"]] == [0, 1, 2]
+
+
+def test_batch256_host_only_ingest_two_ranks_on_cpu():
+    """`--dry-ingest`: the Inspector on the LOCAL provider with an engine stand-in - the product's ingest path (a3 encode on
+    the pool, base64 + Huffman decode of every data URI, tokenisation, parse, consensus, gates) with no model and no GPU: the
+    host ceiling of a rank.  Two gloo ranks, every image completed, nothing counted as engine time."""
+    r = _run(["--gpus", "2", "--workload", "batch256", "--images", "10", "--dry-ingest", "--model", "7b", "--image-size", "256"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = _json_line(r.stdout)
+    assert out["dry"] is True and out["n_gpus"] == 2 and out["config"]["completed"] == 10
+    assert "host-only stand-in" in out["config"]["workload"]
+    assert [p["images"] for p in out["per_rank"]] == [5, 5]
+    assert all(p["engine_device_s"] == 0.0 for p in out["per_rank"])

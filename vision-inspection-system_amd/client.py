@@ -101,6 +101,10 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
     from .tokenizer import ByteTokenizer, HFTokenizer
     from . import weights as W
     if device is None:
+        with _ENGINES_LOCK:      # a model that is already loaded / registered on exactly one device: no device query needed
+            hits = [k for k in _ENGINES if k[0] == model_id]
+            if len(hits) == 1:
+                return _ENGINES[hits[0]]
         device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
     key = (model_id, str(device))
     with _ENGINES_LOCK:
@@ -329,6 +333,8 @@ class LocalVLMClient:
             def resolve():
                 ids, frames = futs[j].result()
                 n_ids[j] = len(ids)
+                if getattr(eng, "host_only", False):      # bench.py --dry-ingest: an engine stand-in that measures the host side
+                    return ids, frames
                 return ids, [hip.resize_rgb(_frame_to_device(f, eng.device), th, tw) for f, (th, tw) in frames]
             return resolve
 
