@@ -120,6 +120,15 @@ int vis_decode_attn(const void* qkv, const void* cos_t, const void* sin_t, void*
 /* batch > 1: sequence b uses qkv + b*qkv_bs, caches + b*cache_bs, tables + b*tab_bs (element strides),
  * step_ptr[b], part_o/part_ml/out blocks of Hq*nsplit*128 / Hq*nsplit*2 / Hq*128 elements. */
 
+/* vis_decode_attn for a batch whose sequences share their first shared_len cached keys (a multiple of 64: the common text
+ * prefix of a batch inspection - the reference sends the text part first, src/agents/vlm_inspector.py:462-470 - which the
+ * prompt passes copied into every slot): every sequence reads those keys / values from sequence 0's cache (one HBM read +
+ * L2 hits instead of `batch` HBM reads of identical rows).  Bit-identical to vis_decode_attn. */
+int vis_decode_attn_shared(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                           const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
+                           int cache_tokens, int nsplit, float scale, int batch, long long qkv_bs, long long cache_bs,
+                           long long tab_bs, int shared_len, vis_stream_t stream);
+
 /* K10 + K4 + K11 + K10 (single-sequence decode)  the head of a decoder layer as ONE launch:
  *   qkv = W_qkv rmsnorm(x) + b ; attn = attention(rope(q), cache + rope(k), v) ; y = x + W_o attn
  * i.e. vis_gemv_bf16 (norm fused) + vis_decode_attn (split + combine launches) + vis_gemv_bf16 (residual), bit-identical to

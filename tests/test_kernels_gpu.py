@@ -1237,3 +1237,44 @@ def test_gemv_argmax_equals_two_stage(hip, device, N, K, temperature):
             assert out[True][2] == int(out[True][0].argmax())        # torch.argmax: first index on ties
             if trial == 0:
                 assert out[True][2] == N // 3
+
+
+@pytest.mark.parametrize("Hq,Hkv,B,T,P", [(28, 4, 32, 2560, 960), (32, 8, 16, 1024, 704 // 64 * 64), (28, 4, 64, 1536, 64)])
+def test_decode_attn_shared_prefix_is_bit_identical(hip, device, Hq, Hkv, B, T, P):
+    """vis_decode_attn_shared: the first P cached keys of every sequence are copies of one text prefix (what a batch inspection's
+    prompt passes leave in the slots); reading them from sequence 0's cache must change nothing - outputs and appended rows
+    equal to vis_decode_attn bit for bit, ragged contexts, and the result must really come from sequence 0's copy (poisoning
+    the OTHER sequences' prefix rows does not change it)."""
+    HD = 128
+    rng = np.random.default_rng(9)
+    ctx = [int(c) for c in rng.integers(P, T - 1, B)]
+    ctx[0], ctx[1] = P, T - 2
+    kc = _randn((B, Hkv, T, HD), device, 520)
+    vc = _randn((B, Hkv, T, HD), device, 521)
+    kc[:, :, :P] = kc[0:1, :, :P]
+    vc[:, :, :P] = vc[0:1, :, :P]
+    g = torch.Generator().manual_seed(522)
+    ang = torch.rand((T, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos_t = emb.cos().to(device).unsqueeze(0).expand(B, -1, -1)
+    sin_t = emb.sin().to(device).unsqueeze(0).expand(B, -1, -1)
+    qkv = _randn((B, (Hq + 2 * Hkv) * HD), device, 523)
+    step = torch.tensor(ctx, dtype=torch.int32, device=device)
+    ns = -(-T // hip.DECODE_KEYS_PER_SPLIT)
+    po = torch.empty(B * Hq * ns * HD, dtype=torch.float32, device=device)
+    pml = torch.empty(B * Hq * ns * 2, dtype=torch.float32, device=device)
+    assert Hkv * B >= 128                       # the streaming form (the only one that reads the shared copy)
+    res = {}
+    for name, shared, poison in (("own", 0, False), ("shared", P, False), ("poisoned", P, True)):
+        k1, v1 = kc.clone(), vc.clone()
+        if poison:
+            k1[1:, :, :P] = 77.0
+            v1[1:, :, :P] = -55.0
+        out = torch.full((B, Hq * HD), 7.0, dtype=torch.bfloat16, device=device)
+        hip.decode_attn(qkv, cos_t, sin_t, k1, v1, step, po, pml, out, Hq, Hkv, HD, ns, HD ** -0.5, shared_len=shared)
+        res[name] = (out.clone(), k1[:, :, P:].clone(), v1[:, :, P:].clone())
+    for name in ("shared", "poisoned"):
+        assert torch.equal(res[name][0], res["own"][0]), f"{name}: attention output differs"
+        assert torch.equal(res[name][1], res["own"][1]) and torch.equal(res[name][2], res["own"][2]), f"{name}: KV append differs"
+    with pytest.raises(hip.HipLibraryError):
+        hip.decode_attn(qkv, cos_t, sin_t, kc, vc, step, po, pml, out, Hq, Hkv, HD, ns, HD ** -0.5, shared_len=100)   # not x 64

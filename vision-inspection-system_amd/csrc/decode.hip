@@ -486,6 +486,8 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
   const int hkv = blockIdx.x, seq = blockIdx.y;
+  const bf16_t* Kh0 = p.k_cache + (size_t)hkv * p.cache_tokens * 128;     // sequence 0's rows (the batch's shared prefix)
+  const bf16_t* Vh0 = p.v_cache + (size_t)hkv * p.cache_tokens * 128;
   p.qkv += seq * p.qkv_bs;
   p.k_cache += seq * p.cache_bs;
   p.v_cache += seq * p.cache_bs;
@@ -499,13 +501,16 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   struct StepRegs { u32x4 k[4]; uint32_t v[16]; };
   auto load_step = [&](StepRegs& r, int j) {          // keys 16 j .. 16 j + 15 (rows clamped: addresses are always valid)
     const int k0 = j * 16;
+    const bool sh = k0 < p.shared_len;             // (wave-uniform; shared_len is a multiple of 16)
+    const bf16_t* Kb = sh ? Kh0 : Kh;
+    const bf16_t* Vb = sh ? Vh0 : Vh;
     const int krow = min(k0 + l15, p.cache_tokens - 1);
 #pragma unroll
-    for (int ds = 0; ds < 4; ++ds) r.k[ds] = *(const u32x4*)(Kh + (size_t)krow * HD + ds * 32 + 8 * h);
+    for (int ds = 0; ds < 4; ++ds) r.k[ds] = *(const u32x4*)(Kb + (size_t)krow * HD + ds * 32 + 8 * h);
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = min(k0 + i, p.cache_tokens - 1);
-      r.v[i] = *(const uint32_t*)(Vh + (size_t)row * HD + 2 * lane);
+      r.v[i] = *(const uint32_t*)(Vb + (size_t)row * HD + 2 * lane);
     }
   };
   StepRegs r0, r1;
@@ -758,6 +763,40 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
   p.scale_log2 = scale * 1.4426950408889634f;
   p.qkv_bs = qkv_bs; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
   p.q_norm_w = nullptr; p.q_eps = 0.f;
+  p.shared_len = 0;
+  return decode_attn_launch(p, out, batch, stream);
+}
+
+// vis_decode_attn for a batch whose sequences share their first `shared_len` cached keys (a multiple of 64: the common
+// text prefix of a batch inspection, which the prompt passes copied into every slot): those keys / values are read from
+// sequence 0's cache by every sequence - one HBM read and L2 hits instead of `batch` HBM reads of identical rows.  Same
+// values, same arithmetic: results are bit-identical to vis_decode_attn.  The new token's slot must lie beyond the shared
+// range (it always does: the prefix is part of the prompt).  Streaming form only (Hkv * batch >= 128); smaller batches
+// ignore shared_len.
+extern "C" int vis_decode_attn_shared(const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                                      const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
+                                      int cache_tokens, int nsplit, float scale, int batch, long long qkv_bs,
+                                      long long cache_bs, long long tab_bs, int shared_len, hipStream_t stream) {
+  if (shared_len < 0 || shared_len % 64 != 0 || shared_len >= cache_tokens) return VIS_ERR_ARG;
+  if (!qkv || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !part_o || !part_ml || !out)
+    return VIS_ERR_ARG;
+  if (batch <= 0 || batch > 64 || (batch > 1 && (qkv_bs <= 0 || cache_bs <= 0 || tab_bs < 0))) return VIS_ERR_ARG;
+  if ((qkv_bs % 8) || (cache_bs % 8)) return VIS_ERR_ARG;
+  if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  const int G = Hq / Hkv;
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;
+  if (nsplit <= 0 || nsplit > 256 || cache_tokens <= 0) return VIS_ERR_ARG;
+  if ((long long)nsplit * DA_MAXKEYS < cache_tokens) return VIS_ERR_ARG;
+  if (((uintptr_t)k_cache | (uintptr_t)v_cache) & 15) return VIS_ERR_ARG;
+  DecAttnArgs p;
+  p.qkv = (const bf16_t*)qkv; p.cos_t = (const float*)cos_t; p.sin_t = (const float*)sin_t;
+  p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache; p.step_ptr = (const int*)step_ptr;
+  p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
+  p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.nsplit = nsplit;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.qkv_bs = qkv_bs; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
+  p.q_norm_w = nullptr; p.q_eps = 0.f;
+  p.shared_len = shared_len;
   return decode_attn_launch(p, out, batch, stream);
 }
 
@@ -783,6 +822,7 @@ static int decode_cross_attn_impl(const void* q, const void* q_norm_w, const voi
   p.scale_log2 = scale * 1.4426950408889634f;
   p.qkv_bs = q_bs; p.cache_bs = kv_bs; p.tab_bs = 0;
   p.q_norm_w = (const bf16_t*)q_norm_w; p.q_eps = eps;
+  p.shared_len = 0;
   return decode_attn_launch(p, out, batch, stream);
 }
 

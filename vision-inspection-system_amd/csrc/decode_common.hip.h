@@ -276,6 +276,10 @@ struct DecAttnArgs {
   // per-head RMSNorm of q (q_norm) is applied while q is staged.
   const bf16_t* q_norm_w;  // [128] or null (self-attention mode)
   float q_eps;
+  // batched streaming form only: keys [0, shared_len) (a multiple of 16) are the same in every sequence of the batch (the
+  // text prefix a batch inspection shares, copied into every slot by the prompt passes) and are read from sequence 0's
+  // copy - same values, so the same result bit for bit, but one HBM read + L2 hits instead of one HBM read per sequence
+  int shared_len;
 };
 
 // Structure (no cross-lane reductions inside a wave):

@@ -240,6 +240,9 @@ class Qwen2VLEngine:
             for b in weights.vit:
                 self.vq8.append({n: q8pad(getattr(b, n)) for n in ("qkv_w", "proj_w", "fc1_w", "fc2_w")})
         self.slot_prompt_len = [0] * Bm
+        # keys [0, batch_shared_len) of the CURRENT batch's slots are identical copies of one text prefix (prefill_many):
+        # the batched decode attention reads them from slot 0 (VIS_DECODE_SHARED=0: every sequence reads its own copy)
+        self.batch_shared_len = 0
         self._prefill_streams: List[torch.cuda.Stream] = []
         self.last_timing: dict = {}
         self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
@@ -821,11 +824,18 @@ class Qwen2VLEngine:
         P = self.shared_prefix_len([r[0] for r in first]) if (B > 1 and len(first) > 1) else 0
         if P:
             shared = self.cached_prefix(first[0][0], P, temperature, seed)
+        unshared = [False]        # set when some slot of this batch did NOT take the shared prefix
 
         def prefix_for(ids):
             if shared is None or len(ids) <= P:
+                unshared[0] = True
                 return None
-            return shared if np.array_equal(np.asarray(list(ids[:P]), dtype=np.int64), shared["ids"]) else None
+            hit = np.array_equal(np.asarray(list(ids[:P]), dtype=np.int64), shared["ids"])
+            if not hit:
+                unshared[0] = True
+            return shared if hit else None
+
+        self.batch_shared_len = 0
 
         next_slot = 0
         if n_streams == 1:
@@ -837,6 +847,8 @@ class Qwen2VLEngine:
                              max_new_tokens=max_new_tokens, slot=next_slot, prefix=prefix_for(r[0]))
                 slots[b] = next_slot
                 next_slot += 1
+            if shared is not None and not unshared[0] and os.environ.get("VIS_DECODE_SHARED", "1") != "0":
+                self.batch_shared_len = P
             return slots, errors
         cur = torch.cuda.current_stream(self.device)
         if len(self._prefill_streams) < n_streams:
@@ -910,6 +922,8 @@ class Qwen2VLEngine:
             for t in (shared["k"], shared["v"], shared["vt"]):
                 for st in streams:
                     t.record_stream(st)
+        if shared is not None and not unshared[0] and os.environ.get("VIS_DECODE_SHARED", "1") != "0":
+            self.batch_shared_len = P
         return slots, errors
 
     def text_prefix_len(self, ids: Sequence[int]) -> int:
@@ -1037,7 +1051,8 @@ class Qwen2VLEngine:
             ks = hip.decode_gemm(xn, lw.qkv_w, part=part)
             hip.skinny_finalize(part, ks, qkv, nq, bias=lw.qkv_b, eps=eps)
             hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
-                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                            shared_len=self.batch_shared_len)
             ks = hip.decode_gemm(att, lw.o_w, part=part)
             hip.skinny_finalize(part, ks, x2, cfg.hidden, residual=x, norm_w=lw.ln2_w, yn=xn2, eps=eps)
             ks = hip.decode_gemm(xn2, lw.gateup_w, part=part)
@@ -1072,7 +1087,8 @@ class Qwen2VLEngine:
             pick = (lambda n: q8[n]) if fp8 else (lambda n: getattr(lw, n))
             proj(x, pick("qkv_w"), qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=eps)
             hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
-                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                            shared_len=self.batch_shared_len)
             proj(att, pick("o_w"), x2, residual=x)
             proj(x2, pick("gateup_w"), act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=eps)
             proj(act, pick("down_w"), x, residual=x2)
@@ -1101,7 +1117,8 @@ class Qwen2VLEngine:
             ks = hip.decode_gemm_fp8(xq, sxq, *q8["qkv_w"], part=part)
             hip.skinny_finalize_fp8(part, ks, qkv, nq, sx=sxq, sw=q8["qkv_w"][1], bias=lw.qkv_b, eps=eps)
             hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
-                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                            shared_len=self.batch_shared_len)
             ks = hip.decode_gemm(att, lw.o_w, part=part)
             hip.skinny_finalize_fp8(part, ks, x2, cfg.hidden, residual=x, norm_w=lw.ln2_w, yn=xn2, yq=x2q,
                                     yq_scale=sx2q, eps=eps)
@@ -1119,7 +1136,7 @@ class Qwen2VLEngine:
 
     def _ensure_graph(self, batch: int = 0) -> torch.cuda.CUDAGraph:
         # sampling parameters (and the batch size) are kernel arguments baked into the graph
-        key = (self.temperature, self.seed, batch)
+        key = (self.temperature, self.seed, batch, self.batch_shared_len if batch else 0)
         if key in self._graphs:
             return self._graphs[key]
         step_fn = (lambda: self._decode_step_batched(batch)) if batch else self._decode_step

@@ -41,6 +41,7 @@ _SIGS = {
     "vis_gemv_bf16_rows": "pppppp" + "iiiiiiiii" + "f" + "p",
     "vis_gemv_fp8w_rows": "ppppppp" + "iiiiiiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
+    "vis_decode_attn_shared": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "i" + "p",
     "vis_decode_chain_sync_ints": "",
     "vis_decode_chain_ws_bytes": "iii",
     "vis_decode_chain": "ppi" + "p" * 12 + "i" * 8 + "ff" + "p",
@@ -634,11 +635,14 @@ def gemv_fp8_rows(x: torch.Tensor, wq: torch.Tensor, scale: torch.Tensor, out: t
 
 def decode_attn(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
                 v_cache: torch.Tensor, step: torch.Tensor, part_o: torch.Tensor, part_ml: torch.Tensor,
-                out: torch.Tensor, n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float) -> torch.Tensor:
+                out: torch.Tensor, n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float,
+                shared_len: int = 0) -> torch.Tensor:
     """Fused decode step attention: rope(q,k) + KV append at slot step[b] + attention over step[b]+1 keys.
 
     Single sequence: qkv [nq*D], caches [Hkv,T,D], tables [T,D], step [1].
-    Batch of B: qkv [B, nq*D], caches [B,Hkv,T,D], tables [B,T,D], step [B], out [B, Hq*D]."""
+    Batch of B: qkv [B, nq*D], caches [B,Hkv,T,D], tables [B,T,D], step [B], out [B, Hq*D].
+    ``shared_len`` (batch only, a multiple of 64): the first shared_len cached keys are identical in every sequence and are
+    read from sequence 0's copy (vis_decode_attn_shared; same result bit for bit)."""
     _bf16(qkv, "qkv"); _bf16(k_cache, "k_cache")
     if step.dtype != torch.int32 or cos_t.dtype != torch.float32 or sin_t.dtype != torch.float32:
         raise HipLibraryError("decode_attn: step int32 / cos,sin f32 required")
@@ -663,6 +667,12 @@ def decode_attn(qkv: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_c
     if batched and (v_cache.stride(0) != cache_bs or cos_t.stride(0) != sin_t.stride(0)):
         raise HipLibraryError("decode_attn: k/v caches (cos/sin tables) must share their batch stride")
     tab_bs = cos_t.stride(0) if batched else 0
+    if shared_len and batched:
+        rc = load().vis_decode_attn_shared(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(k_cache), _ptr(v_cache), _ptr(step),
+                                           _ptr(part_o), _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, T, nsplit, scale,
+                                           B, qkv_bs, cache_bs, tab_bs, int(shared_len), _stream())
+        _check(rc, "vis_decode_attn_shared")
+        return out
     rc = load().vis_decode_attn(_ptr(qkv), _ptr(cos_t), _ptr(sin_t), _ptr(k_cache), _ptr(v_cache), _ptr(step),
                                 _ptr(part_o), _ptr(part_ml), _ptr(out), n_q, n_kv, head_dim, T, nsplit, scale,
                                 B, qkv_bs, cache_bs, tab_bs, _stream())
