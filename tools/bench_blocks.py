@@ -233,15 +233,28 @@ def seam_block(engine, n_images=64, size=1024, new=128, model_id="synthetic:benc
             ingest.shutdown()
             clear_encode_cache()                                           # the measured run encodes its own images
             torch.cuda.synchronize()
+            ingest.TRACE = []
             t0 = time.perf_counter()
             out = run_batch_inspection(paths, "medium", "general")
             torch.cuda.synchronize()
             t = time.perf_counter() - t0
+            trace, ingest.TRACE = ingest.TRACE, None
         timing = dict(getattr(engine, "last_timing", {}))
+        stages = {}
+        for name, a, b, th in trace:       # per stage: calls, busy seconds (summed over threads), first start / last end
+            st = stages.setdefault(name, {"calls": 0, "busy_s": 0.0, "first_start_s": 1e9, "last_end_s": 0.0, "threads": set()})
+            st["calls"] += 1
+            st["busy_s"] += b - a
+            st["first_start_s"] = min(st["first_start_s"], a - t0)
+            st["last_end_s"] = max(st["last_end_s"], b - t0)
+            st["threads"].add(th)
+        for st in stages.values():
+            st["threads"] = len(st["threads"])
         return {"images_per_s": n_images / t, "seconds": t, "images": n_images, "image_px": size,
                 "completed": out["session_results"]["completed_images"], "new_tokens": new,
                 "ingest_threads": int(os.environ.get("VIS_INGEST_THREADS", "4")), "host_cpus": os.cpu_count(),
                 "engine_device_ms": {"prompt_passes": timing.get("prefill_ms"), "decode_loop": timing.get("decode_ms")},
+                "host_timeline": stages,
                 "write_png_files_s": t_files,
                 "what": "run_batch_inspection on PNG files: a3 encode (PIL thumbnail / JPEG q85 / base64) -> data-URI decode "
                         "(host Huffman + GPU IDCT) -> GPU resize -> tokenise -> per-image prompt pass + shared decode loop -> "

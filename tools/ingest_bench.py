@@ -17,6 +17,8 @@ ap.add_argument("--threads", default="4")
 ap.add_argument("--new-tokens", type=int, default=128)
 ap.add_argument("--direct", action="store_true", help="VIS_DIRECT_FRAMES=1: no JPEG round trip between agent and engine")
 ap.add_argument("--profile", action="store_true", help="cProfile the measured call (main thread) and print the top entries")
+ap.add_argument("--switch-interval", type=float, default=0.0, help="sys.setswitchinterval (s) for the measured runs; 0 = leave")
+ap.add_argument("--repeat", type=int, default=1)
 a = ap.parse_args()
 os.environ["VIS_IGNORE_EOS"] = "1"
 if a.direct:
@@ -45,7 +47,9 @@ with tempfile.TemporaryDirectory() as d:
         Image.fromarray(rng.integers(0, 256, (a.size, a.size, 3), dtype=np.uint8)).save(p)
         paths.append(p)
     run_batch_inspection(paths[:4], "medium", "general")                    # loads the models, warms the graphs
-    for n in [int(x) for x in a.threads.split(",")]:
+    if a.switch_interval > 0:
+        sys.setswitchinterval(a.switch_interval)
+    for n in [int(x) for x in a.threads.split(",")] * a.repeat:
         os.environ["VIS_INGEST_THREADS"] = str(n)
         ingest.shutdown()
         from vision_inspection_system_amd.image_processing import clear_encode_cache
@@ -63,4 +67,4 @@ with tempfile.TemporaryDirectory() as d:
         done = out["session_results"]["completed_images"]
         print(json.dumps({"workload": f"run_batch_inspection, {a.images} PNG files {a.size}x{a.size}, Inspector synthetic:7b"
                                       f" + Auditor {a.auditor}, {a.new_tokens} tokens per model, 1 rank",
-                          "ingest_threads": n, "direct_frames": bool(a.direct), "images_per_s": a.images / t, "seconds": t, "completed": done}), flush=True)
+                          "ingest_threads": n, "switch_interval": sys.getswitchinterval(), "direct_frames": bool(a.direct), "images_per_s": a.images / t, "seconds": t, "completed": done}), flush=True)

@@ -161,7 +161,7 @@ class VLMInspectorAgent(_BaseAgent):
         """Submit the request-side work of every image (open, thumbnail, JPEG q85, base64, prompt) to the ingest pool;
         returns one future per image for ``analyze_many(..., prepared=)``."""
         from . import ingest
-        return [ingest.submit(self._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
+        return [ingest.submit(_traced_messages, self, Path(p), c) for p, c in zip(image_paths, contexts)]
 
 
 class VLMAuditorAgent(_BaseAgent):
@@ -250,7 +250,13 @@ class VLMAuditorAgent(_BaseAgent):
 
     def prepare_many(self, image_paths, contexts) -> list:
         from . import ingest
-        return [ingest.submit(self._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
+        return [ingest.submit(_traced_messages, self, Path(p), c) for p, c in zip(image_paths, contexts)]
+
+
+def _traced_messages(agent, path, context):
+    from . import ingest
+    with ingest.span("request-side a3 encode (PIL thumbnail / JPEG q85 / base64, pool thread)"):
+        return agent._messages(path, context)
 
 
 def _many(agent, image_paths, contexts, prepared=None) -> list:
@@ -262,7 +268,7 @@ def _many(agent, image_paths, contexts, prepared=None) -> list:
     from . import ingest
     results = [None] * len(image_paths)
     futs = prepared if prepared is not None else \
-        [ingest.submit(agent._messages, Path(p), c) for p, c in zip(image_paths, contexts)]
+        [ingest.submit(_traced_messages, agent, Path(p), c) for p, c in zip(image_paths, contexts)]
     streaming = getattr(agent.client, "accepts_futures", False) and hasattr(agent.client, "complete_many")
     todo, msgs = [], []
     for i, (path, fut) in enumerate(zip(image_paths, futs)):
@@ -298,7 +304,8 @@ def _many(agent, image_paths, contexts, prepared=None) -> list:
                 results[i] = agent._failure(text)
                 continue
             try:
-                results[i] = agent._interpret(text, contexts[i])
+                with ingest.span("calling thread: parse + validate a reply"):
+                    results[i] = agent._interpret(text, contexts[i])
             except Exception as e:
                 results[i] = agent._failure(e)
     for fut in futs:        # the batch call is over: VIS_DIRECT_FRAMES handles of its requests are released

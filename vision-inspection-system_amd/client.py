@@ -326,16 +326,22 @@ class LocalVLMClient:
         from . import hip, ingest
         lazy = any(isinstance(m, Future) for m in batch_of_messages)
 
-        futs = [ingest.then(m, lambda msgs: self._prepare(lm, msgs)) for m in batch_of_messages]
+        def prepare(msgs):
+            with ingest.span("service-side decode (base64 + Huffman, pool thread)"):
+                return self._prepare(lm, msgs)
+
+        futs = [ingest.then(m, prepare) for m in batch_of_messages]
         n_ids = {}
 
         def resolver(j):
             def resolve():
-                ids, frames = futs[j].result()
+                with ingest.span("engine thread: waiting for a request's encode + decode"):
+                    ids, frames = futs[j].result()
                 n_ids[j] = len(ids)
                 if getattr(eng, "host_only", False):      # bench.py --dry-ingest: an engine stand-in that measures the host side
                     return ids, frames
-                return ids, [hip.resize_rgb(_frame_to_device(f, eng.device), th, tw) for f, (th, tw) in frames]
+                with ingest.span("engine thread: H2D of coefficients + IDCT / resize launches"):
+                    return ids, [hip.resize_rgb(_frame_to_device(f, eng.device), th, tw) for f, (th, tw) in frames]
             return resolve
 
         with eng.lock:

@@ -15,8 +15,31 @@ import itertools
 import os
 import queue
 import threading
+import time
 from concurrent.futures import Future
 from typing import Any, Callable, Iterable, List, Optional, Tuple
+
+# Host timeline of the seam (bench.py's seam64 block): when TRACE is a list, every `span` appends
+# (stage, start, end, thread name) - perf_counter seconds.  None (the default) costs one attribute test per stage.
+TRACE: Optional[list] = None
+
+
+class span:
+    __slots__ = ("name", "t0")
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        self.t0 = time.perf_counter() if TRACE is not None else 0.0
+        return self
+
+    def __exit__(self, *exc):
+        tr = TRACE
+        if tr is not None:
+            tr.append((self.name, self.t0, time.perf_counter(), threading.current_thread().name))
+        return False
+
 
 # Priorities (smaller runs first).  The request-side encodes of a whole batch are queued up front; the service-side decode
 # of image i must not wait behind the encodes of images i+1.. (the GPU is waiting for it), so it is queued - by `then`,
