@@ -166,3 +166,22 @@ def test_attention_key_split_entry_refuses_bad_arguments_without_gpu(lib_path):
     assert lib.vis_attn_prefill_split(*args(ws=None)) == 1
     assert lib.vis_attn_prefill_split(*args(ws=P + 16)) == 1        # 256-byte alignment
     assert lib.vis_attn_prefill_split(*args(ws_bytes=need - 1)) == 1
+
+
+def test_attn_plan_key_ranges_and_whole_rounds():
+    """plan_attn_items_split (host), r04 generalisation: a segment may carry its own key range (mllama tower: present rows
+    over every canvas row, pad rows over the present ones) and a segment longer than one round of slots is topped up to the
+    next whole round; the rule looks at one segment only (same items alone and stacked, shifted by the canvas offset)."""
+    from vision_inspection_system_amd import hip
+    one, n1 = hip.plan_attn_items_split([(0, 6404, 0, 6432), (6404, 6432, 0, 6404)], 16)
+    assert n1 == 45 and len(one) == 6 + 90 + 1              # 51 blocks on 48 slots per head -> two rounds of 48 (+ the pad item)
+    halves = [it for it in one if it[1] >> 8]
+    assert {(it[2], it[3]) for it in halves} == {(0, 3200), (3200, 6432)}          # key halves cut on a 64-key boundary
+    whole = [it for it in one if not it[1] >> 8]
+    assert (6404, 28, 0, 6404) in whole and all(it[2:] == (0, 6432) for it in whole if it[0] < 6404)
+    two, n2 = hip.plan_attn_items_split([(0, 6404, 0, 6432), (6404, 6432, 0, 6404),
+                                         (6464, 6464 + 6404, 6464, 6464 + 6432), (6464 + 6404, 6464 + 6432, 6464, 6464 + 6404)], 16)
+    assert n2 == 2 * n1
+    first = [it for it in two if it[0] < 6464]
+    assert sorted((it[0], it[1] & 0xFF, it[1] >> 8 & 3, it[2], it[3]) for it in first) == \
+        sorted((it[0], it[1] & 0xFF, it[1] >> 8 & 3, it[2], it[3]) for it in one)

@@ -390,22 +390,30 @@ def plan_attn_items_split(segments, heads: int, block_q: int = 128, slots: int =
     features stay bit-identical whether it runs alone or stacked with others.  Whole items first, split ones last."""
     whole, split, n_pairs = [], [], 0
     budget = slots // max(heads, 1)
-    for (s, e) in segments:
+    for seg in segments:
+        # (start, end): queries and keys are the same range; (start, end, k0, k1): queries [start, end) over keys [k0, k1)
+        # (the mllama tower: a present tile's rows see every canvas row, the pad rows only the present ones)
+        s, e = seg[0], seg[1]
+        ks, ke = (seg[2], seg[3]) if len(seg) == 4 else (s, e)
         blocks = [(q0, min(block_q, e - q0)) for q0 in range(s, e, block_q)]
         nb = len(blocks)
         n_whole = sum(1 for b in blocks if b[1] == block_q)
-        ns = min(n_whole, max(0, budget - nb)) if (heads > 0 and nb >= ATTN_SPLIT_MIN_BLOCKS) else 0
-        mid = ((s + e) // 2 + 32) // 64 * 64
-        if not (s < mid < e):
+        # fill whole rounds: a segment of nb <= budget blocks is topped up to one round (budget - nb splits), a longer one -
+        # 51 blocks per head on 48 slots for a 2 x 2-tile mllama canvas: two rounds with the second 6 % full - to the next
+        # whole number of rounds
+        rounds = -(-nb // budget) if budget > 0 else 1
+        ns = min(n_whole, max(0, rounds * budget - nb)) if (heads > 0 and nb >= ATTN_SPLIT_MIN_BLOCKS) else 0
+        mid = ((ks + ke) // 2 + 32) // 64 * 64
+        if not (ks < mid < ke):
             ns = 0
         first_split = n_whole - ns
         for i, (q0, qn) in enumerate(blocks):
             if qn == block_q and i >= first_split and ns > 0:
-                for part, (k0, k1) in enumerate(((s, mid), (mid, e))):
+                for part, (k0, k1) in enumerate(((ks, mid), (mid, ke))):
                     split.append((q0, qn | ((1 | part << 1 | n_pairs << 2) << 8), k0, k1))
                 n_pairs += 1
             else:
-                whole.append((q0, qn, s, e))
+                whole.append((q0, qn, ks, ke))
     return whole + split, n_pairs
 
 
@@ -429,11 +437,17 @@ class AttnPlan:
 
 
 def make_vit_attn_plan(segments, device, heads: int, split: bool = True) -> AttnPlan:
-    """Plan for attn_prefill_plan over independent token ranges [(start, end)] (non-causal, head_dim 80)."""
+    """Plan for attn_prefill_plan over independent token ranges [(start, end)] - or [(start, end, k0, k1)]: queries over a
+    key range of their own - (non-causal, head_dim 80)."""
     n_pairs = 0
     if split:
         items, n_pairs = plan_attn_items_split(segments, heads)
     if n_pairs == 0:
+        if any(len(sg) == 4 for sg in segments):
+            items = [(q0, min(128, sg[1] - q0), sg[2] if len(sg) == 4 else sg[0], sg[3] if len(sg) == 4 else sg[1])
+                     for sg in segments for q0 in range(sg[0], sg[1], 128)]
+            work = torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
+            return AttnPlan(work, 0, 0, heads)
         return AttnPlan(make_attn_work(segments, False, device, heads=heads), 0, 0, heads)
     work = torch.tensor(items, dtype=torch.int32, device=device).reshape(-1, 4).contiguous()
     nbytes = int(load().vis_attn_split_ws_bytes(n_pairs, heads))

@@ -154,6 +154,7 @@ class MllamaEngine:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
         self._graphs_b: Dict[tuple, torch.cuda.CUDAGraph] = {}
+        self._vis_plans: Dict[tuple, "hip.AttnPlan"] = {}
         self.temperature, self.seed = 0.0, 0
         self.prompt_len = 0
         self._decoded = 0
@@ -175,10 +176,30 @@ class MllamaEngine:
         return frame.contiguous(), th, tw, ar_id
 
     # ------------------------------------------------------------------ vision tower
-    def _vision_work(self, n_real: int, n_all: int, block: int = 128) -> torch.Tensor:
-        items = [(q0, min(block, n_real - q0), 0, n_all) for q0 in range(0, n_real, block)]
-        items += [(q0, min(block, n_all - q0), 0, n_real) for q0 in range(n_real, n_all, block)]
-        return torch.tensor(items, dtype=torch.int32, device=self.device).reshape(-1, 4).contiguous()
+    def _vision_plan(self, layout: Sequence[Tuple[int, int, int]]) -> "hip.AttnPlan":
+        """Attention plan of the tower over a stack of canvases [(first row, present rows, canvas rows)]: a present tile's
+        rows attend every canvas row, the pad rows only the present ones (HF's mask as two key ranges).  The long segment
+        of a canvas (51 row blocks per head for 2 x 2 tiles, on 48 resident slots per head) is key-split up to whole rounds
+        of the chip (hip.plan_attn_items_split; r04 - DESIGN section 4 had it as "does not yet"); the rule looks at one
+        canvas only, so an image's features do not depend on what it is stacked with.  Measured (r04, exact 11B shapes, same
+        box, alternating): ONE canvas 44.2 -> 43.1 ms per prompt pass (two rounds with the second 6 % full become 2.02 rounds of
+        mostly half items), FOUR stacked canvases (the batch path) 33.75 -> 34.0 ms per image (4.3 rounds of whole items already
+        fill the chip; the halves add merge work) - and one rule has to serve both, or an image's features would differ between
+        the single and the batched path.  Hence OFF by default (VIS_MLLAMA_ATTN_SPLIT=1 turns it on)."""
+        key = tuple(layout)
+        plan = self._vis_plans.get(key)
+        if plan is None:
+            segs = []
+            for r0, n_real, n_all in layout:
+                segs.append((r0, r0 + n_real, r0, r0 + n_all))
+                if n_all > n_real:
+                    segs.append((r0 + n_real, r0 + n_all, r0, r0 + n_real))
+            if len(self._vis_plans) >= 16:
+                self._vis_plans.clear()
+            plan = self._vis_plans[key] = hip.make_vit_attn_plan(
+                segs, self.device, self.cfg.v_heads,
+                split=(self.cfg.v_head_dim == 80 and os.environ.get("VIS_MLLAMA_ATTN_SPLIT", "0") == "1"))
+        return plan
 
     def vision_forward(self, frame: torch.Tensor, taps: Optional[dict] = None) -> Tuple[torch.Tensor, int]:
         """uint8 device frame [H, W, 3] -> (cross-attention states [max_tiles*tile_tokens, hidden] bf16, n_tiles)."""
@@ -193,7 +214,7 @@ class MllamaEngine:
         x = torch.zeros((N, E), dtype=bf, device=dev)                      # pad rows start as exact zeros
         hip.gemm(patches, w.patch_w, residual=w.cls_pos[ar_id].view(TP, E), out=x[:TP])
         hip.layernorm(x[:TP], w.ln_pre_w, w.ln_pre_b, 1e-5, out=x[:TP])
-        work = self._vision_work(nR, N)
+        plan = self._vision_plan([(0, nR, N)])
         ld = _round_up(N, 64)
         y = torch.empty((N, E), dtype=bf, device=dev)
         qkv = torch.empty((N, 3 * E), dtype=bf, device=dev)
@@ -209,7 +230,7 @@ class MllamaEngine:
             hip.layernorm(x, b.ln1_w, b.ln1_b, cfg.v_eps, out=y)
             hip.gemm(y, b.qkv_w, out=qkv)
             hip.qkv_rope_split(qkv, None, None, q, k, None, vt, Hh, Hh, D)
-            hip.attn_prefill(q, k, vt, att, work, False, scale)
+            hip.attn_prefill_plan(q, k, vt, att, plan, scale)
             hip.gemm(att, b.o_w, residual=x, out=x)
             hip.layernorm(x, b.ln2_w, b.ln2_b, cfg.v_eps, out=y)
             hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_GELU_ERF, out=hmid)
@@ -248,7 +269,7 @@ class MllamaEngine:
         TP, N = T * P, T * (P + npad)
         NS = _round_up(N, 64)                         # rows per image in the stack
         x = torch.zeros((k * NS, E), dtype=bf, device=dev)
-        items, n_tiles_of = [], []
+        layout, n_tiles_of = [], []
         tile_of = np.concatenate([np.repeat(np.arange(T), P), np.repeat(np.arange(T), npad),
                                   np.zeros(NS - N, dtype=np.int64)]).astype(np.int32)
         idx_all = np.empty(k * NS, dtype=np.int32)
@@ -261,10 +282,9 @@ class MllamaEngine:
             hip.patchify_tiles(fr, patches, th, tw, cfg.image_size, cfg.image_mean, cfg.image_std)
             hip.gemm(patches, w.patch_w, residual=w.cls_pos[ar_id].view(TP, E), out=x[r0:r0 + TP])
             hip.layernorm(x[r0:r0 + TP], w.ln_pre_w, w.ln_pre_b, 1e-5, out=x[r0:r0 + TP])
-            items += [(r0 + q0, min(128, nR - q0), r0, r0 + N) for q0 in range(0, nR, 128)]
-            items += [(r0 + q0, min(128, N - q0), r0, r0 + nR) for q0 in range(nR, N, 128)]
+            layout.append((r0, nR, N))
             idx_all[r0:r0 + NS] = ar_id * T + tile_of
-        work = torch.tensor(items, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous()
+        plan = self._vision_plan(layout)
         M = k * NS
         y = torch.empty((M, E), dtype=bf, device=dev)
         qkv = torch.empty((M, 3 * E), dtype=bf, device=dev)
@@ -280,7 +300,7 @@ class MllamaEngine:
             hip.layernorm(x, b.ln1_w, b.ln1_b, cfg.v_eps, out=y)
             hip.gemm(y, b.qkv_w, out=qkv)
             hip.qkv_rope_split(qkv, None, None, q, kk, None, vt, Hh, Hh, D)
-            hip.attn_prefill(q, kk, vt, att, work, False, scale)
+            hip.attn_prefill_plan(q, kk, vt, att, plan, scale)
             hip.gemm(att, b.o_w, residual=x, out=x)
             hip.layernorm(x, b.ln2_w, b.ln2_b, cfg.v_eps, out=y)
             hip.gemm(y, b.fc1_w, bias=b.fc1_b, act=hip.ACT_GELU_ERF, out=hmid)
