@@ -142,7 +142,8 @@ int vis_decode_attn_shared(const void* qkv, const void* cos_t, const void* sin_t
  * bounded wait gave up (results invalid; zero ws and sync before the next launch).  The packed projection row and the merged
  * attention row live in ws as granules (low 32 bits = two bf16): ws[0 .. (Hq + 2 Hkv) * 64) and the next Hq * 64 words.
  * VIS_ERR_ARG for shapes outside the chained form (HD != 128, K or Hq * 128 > 4096, Hq > 64, a grid above what the device
- * holds resident): the caller then issues the four launches. */
+ * holds resident): the caller then issues the four launches.  ONE chained launch at a time per device: its workgroups wait
+ * for each other inside the grid, so launches from two streams at once must be ordered by the caller (an event). */
 int vis_decode_chain_sync_ints(void);
 long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit);
 int vis_decode_chain(const void* x, const void* x_idx, int x_rows, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,

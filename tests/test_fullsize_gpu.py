@@ -87,6 +87,45 @@ def test_7b_chained_decode_equals_four_launches(big, monkeypatch):
         torch.cuda.empty_cache()
 
 
+def test_7b_two_engines_decoding_on_two_streams(big):
+    """Two engines on one GPU, driven by two host threads on two HIP streams at the same time (a host app with two different
+    Qwen models, or two agents on their own streams).  A chained launch needs its whole grid resident, so two of them must not
+    run side by side: Qwen2VLEngine.decode orders the chained decode calls of a device on the GPU with an event.  Both engines
+    must produce exactly their solo tokens, every round, with clean status words."""
+    import threading
+    from vision_inspection_system_amd import hip
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    cfg, eng, (ra, rb) = big
+    other = Qwen2VLEngine(cfg, eng.w, eng.device, max_ctx=4096)
+    try:
+        assert eng.chain_sync is not None and other.chain_sync is not None
+        solo = (eng.generate(ra[0], ra[1], max_new_tokens=40, ignore_eos=True),
+                other.generate(rb[0], rb[1], max_new_tokens=40, ignore_eos=True))
+        for rnd in range(3):
+            out, errs = [None, None], []
+
+            def run(i, e, r):
+                try:
+                    st = torch.cuda.Stream(device=e.device)
+                    with torch.cuda.stream(st):
+                        out[i] = e.generate(r[0], r[1], max_new_tokens=40, ignore_eos=True, check_every=4)
+                    st.synchronize()
+                except Exception as ex:      # noqa: BLE001
+                    errs.append(ex)
+            ts = [threading.Thread(target=run, args=(0, eng, ra)), threading.Thread(target=run, args=(1, other, rb))]
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            assert not errs, errs
+            assert out[0] == solo[0] and out[1] == solo[1], f"round {rnd}: tokens differ from the solo runs"
+            torch.cuda.synchronize()
+            assert int(eng.chain_sync[hip.CHAIN_STATUS_WORD]) == 0 and int(other.chain_sync[hip.CHAIN_STATUS_WORD]) == 0
+    finally:
+        del other
+        torch.cuda.empty_cache()
+
+
 def test_7b_decode_step_agrees_with_prompt_pass(big):
     """Logits of the token after (prompt + 3 generated tokens): once from three decode steps on the KV cache, once
     from a prompt pass over the extended prompt.  Same function, two kernel families (GEMV / cache attention vs MFMA

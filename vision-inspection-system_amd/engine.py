@@ -129,6 +129,11 @@ def mrope_cos_sin(cfg: Qwen2VLConfig, pos3: np.ndarray) -> Tuple[np.ndarray, np.
     return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
 
 
+# the last chained decode call enqueued per device (Qwen2VLEngine.decode orders such calls on the GPU)
+_CHAIN_ORDER_LOCK = threading.Lock()
+_CHAIN_LAST: Dict[Optional[int], "torch.cuda.Event"] = {}
+
+
 # ----------------------------------------------------------------------------- engine
 class Qwen2VLEngine:
     """One model replica on one GPU.  Not re-entrant: callers serialise through ``self.lock``."""
@@ -1165,6 +1170,24 @@ class Qwen2VLEngine:
         if self.prompt_len + self._decoded + n_steps > self.decode_limit:
             raise ValueError("decode beyond the rope rows prepared by prefill (pass max_new_tokens)")
         self._decoded += n_steps
+        if self.chain_sync is None:
+            return self._decode_steps(n_steps, use_graph)
+        # Chained launches wait inside the grid for workgroups of the SAME launch, which only works while that launch can
+        # have its whole grid resident (860 of the device's 1024 slots at 7B shapes).  Two engines decoding on two streams at
+        # once could strand each other (each holding slots the other's producers need; the bounded waits would then raise).
+        # So the chained decode calls of a device are ordered on the GPU: a call waits for the previous call's last launch
+        # (an event, no host blocking), whatever streams or threads they come from.  Decode is HBM-bound: nothing is lost.
+        with _CHAIN_ORDER_LOCK:
+            cur = torch.cuda.current_stream(self.device)
+            prev = _CHAIN_LAST.get(self.device.index)
+            if prev is not None:
+                cur.wait_event(prev)
+            self._decode_steps(n_steps, use_graph)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            _CHAIN_LAST[self.device.index] = ev
+
+    def _decode_steps(self, n_steps: int, use_graph: bool) -> None:
         if use_graph:
             g = self._ensure_graph()
             for _ in range(n_steps):
