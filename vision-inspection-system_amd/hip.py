@@ -83,7 +83,10 @@ def upload(arr, device) -> "torch.Tensor":
     st = _UPLOAD_STREAMS.get(dev)
     if st is None:
         st = _UPLOAD_STREAMS[dev] = torch.cuda.Stream(device=dev)
-    src = torch.from_numpy(_np.ascontiguousarray(arr)).pin_memory()
+    if isinstance(arr, torch.Tensor) and arr.device.type == "cpu" and arr.is_pinned():
+        src = arr                                        # already page-locked (jpeg.parse on a pool thread): no staging copy
+    else:
+        src = torch.from_numpy(_np.ascontiguousarray(arr)).pin_memory()
     with torch.cuda.stream(st):
         out = src.to(dev, non_blocking=True)
     cur = torch.cuda.current_stream(dev)

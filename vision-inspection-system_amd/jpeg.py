@@ -69,6 +69,7 @@ class JpegCoeffs:
     dh: tuple
     qt: np.ndarray          # [3, 64] uint16, natural order
     coeffs: np.ndarray      # [total_blocks, 64] int16, natural order, quantised
+    pinned: object = None   # the page-locked torch tensor `coeffs` is a view of (when the Huffman decode wrote straight into one)
 
     @property
     def size(self):         # PIL convention: (width, height)
@@ -85,14 +86,35 @@ def parse(data: bytes) -> Optional[JpegCoeffs]:
     info = _Info()
     if lib.vis_jpeg_probe(data, len(data), ctypes.byref(info)) != 0:
         return None
-    coeffs = np.empty((info.total_blocks, 64), dtype=np.int16)
+    # On a GPU process the Huffman decoder writes straight into page-locked memory (this pool thread allocates it; PyTorch's
+    # caching host allocator recycles the blocks): the engine thread then only queues an async copy instead of first copying
+    # 3 MB into a staging buffer - 64-image seam: 6.9 ms of launch-thread time per image for upload + IDCT / resize launches
+    # (profiles/r04_seam64_host_timeline.json).  CPU-only processes (tests, dry runs) never initialise CUDA: plain numpy.
+    pinned = None
+    if _pin_coeffs():
+        import torch
+        try:
+            pinned = torch.empty((info.total_blocks, 64), dtype=torch.int16, pin_memory=True)
+        except RuntimeError:
+            pinned = None
+    coeffs = pinned.numpy() if pinned is not None else np.empty((info.total_blocks, 64), dtype=np.int16)
     if lib.vis_jpeg_decode_coeffs(data, len(data), ctypes.byref(info), coeffs.ctypes.data) != 0:   # releases the GIL
         return None
     n = info.ncomp
     t = lambda a: tuple(int(a[i]) for i in range(n))
     qt = np.array([[info.qt[c][k] for k in range(64)] for c in range(3)], dtype=np.uint16)
     return JpegCoeffs(info.width, info.height, n, t(info.hs), t(info.vs), t(info.bw), t(info.bh), t(info.dw), t(info.dh),
-                      qt, coeffs)
+                      qt, coeffs, pinned)
+
+
+def _pin_coeffs() -> bool:
+    if os.environ.get("VIS_PIN_COEFFS", "1") == "0":
+        return False
+    import torch
+    return torch.cuda.is_initialized()
+
+
+_QT_DEVICE: dict = {}       # quantisation tables already on the device (the agents' q85 tables never change)
 
 
 def parse_data_uri(url: str) -> Optional[JpegCoeffs]:
@@ -112,6 +134,11 @@ def to_rgb_device(jc: JpegCoeffs, device):
     """H2D of the coefficients + the two HIP kernels -> uint8 [H, W, 3] on ``device`` (current stream)."""
     import torch
     from . import hip
-    coeffs = hip.upload(jc.coeffs, device)                 # pinned staging on the upload stream: the host does not wait
-    qt = hip.upload(jc.qt.astype(np.int32), device)
+    coeffs = hip.upload(jc.pinned if jc.pinned is not None else jc.coeffs, device)   # upload stream: the host does not wait
+    key = (str(device), jc.qt.tobytes())
+    qt = _QT_DEVICE.get(key)
+    if qt is None:
+        if len(_QT_DEVICE) > 64:
+            _QT_DEVICE.clear()
+        qt = _QT_DEVICE[key] = torch.from_numpy(jc.qt.astype(np.int32)).to(device)
     return hip.jpeg_to_rgb(coeffs, qt, jc)
