@@ -14,4 +14,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o ben
 # the roofline kernel of the chained step is the <1, false> instance (gate/up + down); the lm_head is <1, true>
 python tools/summarize_profile.py --round $R --stats $O/stats --fetch $O/fetch --write $O/write --bench-log $O/bench_stats.log --out $O/profiles \
     --traffic-kernel "gemv_bf16_kernel<1, false>"
+# HBM traffic of the chained layer-head launch (algorithmic: 58.7 MB of weights + the KV rows of the context): what its polling costs
+python tools/summarize_profile.py --round $R --fetch $O/fetch --write $O/write --out $O/profiles \
+    --traffic-kernel "decode_chain_kernel" --traffic-name chain
 ls -la $O/profiles
