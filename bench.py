@@ -756,6 +756,7 @@ def main():
         raise SystemExit("bench.py needs a ROCm GPU: the hot path has no CPU fallback")
     if args.share_gpu:
         local_rank = 0                       # rehearsal: every rank on the one GPU of the box
+        os.environ["VIS_DECODE_CHAIN"] = "0"  # two PROCESSES' chained launches cannot both be resident on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist

@@ -510,3 +510,31 @@ def test_prefix_cache_across_requests_is_bit_identical(device, monkeypatch):
     monkeypatch.setenv("VIS_PREFIX_CACHE", "0")
     eng._prefix_cache.clear()
     assert eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True) == full_a and len(eng._prefix_cache) == 0
+
+
+def test_stalled_chained_launch_is_re_served_on_the_unchained_step(device):
+    """A chained layer-head launch whose in-grid wait gave up (another process running chained launches on the same GPU) raises
+    the status word; the engine must notice it at the end of the request, serve the request again on the four-launch step -
+    identical tokens - and stay there.  Simulated by raising the status word by hand."""
+    from vision_inspection_system_amd import hip
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    w = pack_device_weights(cfg, synth_state_dict(cfg, seed=0), device)
+    g = load_golden()
+    ids, frames = g["ids_a"].tolist(), [torch.from_numpy(g["frame_a"]).to(device)]
+    ref = Qwen2VLEngine(cfg, w, device, max_ctx=256).generate(ids, frames, max_new_tokens=12, ignore_eos=True)
+    eng = Qwen2VLEngine(cfg, w, device, max_ctx=256)
+    assert eng.chain_sync is not None
+    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # chained, graph captured
+    eng.chain_sync[hip.CHAIN_STATUS_WORD] = 1                                            # "a wait timed out"
+    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # noticed, re-served unchained
+    assert eng.chain_sync is None
+    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # and stays on the four launches
+    with pytest.raises(hip.ChainStalled):                                                # the low-level path reports it
+        e2 = Qwen2VLEngine(cfg, w, device, max_ctx=256)
+        e2.prefill(ids, frames, max_new_tokens=4)
+        e2.decode(2)
+        e2.chain_sync[hip.CHAIN_STATUS_WORD] = 1
+        e2.generated(3)

@@ -1208,7 +1208,13 @@ class Qwen2VLEngine:
         if self.chain_sync is not None and int(self.chain_sync[hip.CHAIN_STATUS_WORD].item()) != 0:
             self.chain_sync.zero_()
             self.chain_ws.zero_()
-            raise hip.HipLibraryError("vis_decode_chain: a hand-off wait inside the launch timed out (decode results invalid)")
+            raise hip.ChainStalled("vis_decode_chain: a hand-off wait inside the launch timed out (decode results invalid)")
+
+    def disable_chain(self) -> None:
+        """Back to the four launches per layer head (same results bit for bit); the captured decode graphs hold chained launches
+        and are dropped."""
+        self.chain_sync = None
+        self._graphs.clear()
 
     def generate(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (), max_new_tokens: int = 128,
                  ignore_eos: bool = False, use_graph: bool = True, check_every: int = 16,
@@ -1217,6 +1223,18 @@ class Qwen2VLEngine:
         ``check_every`` tokens so the decode loop itself never synchronises; output is truncated at the
         first EOS (exclusive)."""
         max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
+        try:
+            return self._generate(input_ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)
+        except hip.ChainStalled as e:
+            # Something else ran chained launches on this device at the same time (another PROCESS sharing the GPU: launches of
+            # this process are ordered, Qwen2VLEngine.decode).  The request is served again on the unchained launches - the same
+            # HIP kernels' arithmetic, identical tokens - and the engine stays on them.
+            import logging
+            logging.getLogger("vision_inspection_system_amd.engine").warning("%s - continuing on the unchained decode step", e)
+            self.disable_chain()
+            return self._generate(input_ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)
+
+    def _generate(self, input_ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed) -> List[int]:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # per-stage device time (SURVEY section 5: tracing)
         ev[0].record()
         # the text in front of the image (the agents' fixed inspection prompt): its K / V come from the prefix cache

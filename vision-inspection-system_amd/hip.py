@@ -99,6 +99,11 @@ class HipLibraryError(RuntimeError):
     """The gfx950 extension is missing or an entry point rejected its arguments."""
 
 
+class ChainStalled(HipLibraryError):
+    """A bounded wait inside a chained layer-head launch (vis_decode_chain) gave up: its workgroups could not all be resident
+    - another process or stream was running a chained launch on the same device at the same time."""
+
+
 _lib: Optional[ctypes.CDLL] = None
 
 
