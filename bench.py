@@ -494,6 +494,7 @@ def run_dry(args, rank: int, world: int) -> None:
     JSON line - with synthetic token records instead of a model.  The figure it prints measures nothing."""
     import torch.distributed as dist
     from vision_inspection_system_amd.batch import gather_records
+    from vision_inspection_system_amd import hip as hip_mod
     if world > 1:
         dist.init_process_group(args.backend)
     rng = np.random.default_rng(rank)
@@ -820,7 +821,12 @@ def main():
         m.record()
         engine.decode(new - 1, use_graph=not args.no_graph)
         e.record()
-        toks = engine.generated(new)  # D2H of the 128 token ids (synchronises)
+        try:
+            toks = engine.generated(new)  # D2H of the 128 token ids (synchronises)
+        except hip_mod.ChainStalled as ex:   # something else used this GPU's chained launches: same step on the four launches
+            print(f"[bench] {ex}: decode chain switched off, step repeated", file=sys.stderr, flush=True)
+            engine.disable_chain()
+            return one_step(timed)
         rec = gather_records([{"image": f"synthetic_{rank}", "tokens": toks}], world)
         if timed:
             pre_ev.append((s, m, e))
@@ -905,6 +911,7 @@ def main():
                                       "shared text prefix less arithmetic is actually executed, so this is an "
                                       "effective rate") if B > 1 else "one prompt pass"},
             "decode": {"ms": t_dec * 1e3, "ms_per_token": t_dec / (new - 1) * 1e3,
+                       "chained_layer_head": bool(B == 1 and engine.chain_sync is not None),
                        "weight_GBps": step_bytes * (new - 1) / t_dec / 1e9,
                        "sequences_per_step": B},
         }
