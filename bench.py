@@ -494,7 +494,6 @@ def run_dry(args, rank: int, world: int) -> None:
     JSON line - with synthetic token records instead of a model.  The figure it prints measures nothing."""
     import torch.distributed as dist
     from vision_inspection_system_amd.batch import gather_records
-    from vision_inspection_system_amd import hip as hip_mod
     if world > 1:
         dist.init_process_group(args.backend)
     rng = np.random.default_rng(rank)
@@ -772,6 +771,7 @@ def main():
     from vision_inspection_system_amd.engine import Qwen2VLEngine
     from vision_inspection_system_amd.weights import random_device_weights
     from vision_inspection_system_amd.batch import gather_records
+    from vision_inspection_system_amd import hip as hip_mod
 
     cfg = {"7b": Qwen2VLConfig.qwen2_vl_7b, "7b25": Qwen2VLConfig.qwen2_5_vl_7b, "tiny": Qwen2VLConfig.tiny}[args.model]()
     weights = random_device_weights(cfg, dev, seed=0)
