@@ -16,7 +16,9 @@
  *  - no allocation, no global state, no synchronisation: kernels are enqueued
  *    on `stream` (a hipStream_t passed as void*) and may be captured in a hipGraph;
  *  - return value: 0 = enqueued, 1 = argument/shape/alignment precondition
- *    violated (nothing launched), 2 = HIP launch error.
+ *    violated (nothing launched), 2 = HIP launch error, 3 = valid arguments but
+ *    this kernel form does not cover the shape on this device (nothing launched;
+ *    the caller issues the equivalent separate launches - vis_decode_chain only).
  */
 #ifndef VIS_HIP_H
 #define VIS_HIP_H
@@ -30,6 +32,7 @@ typedef void* vis_stream_t; /* hipStream_t */
 #define VIS_OK 0
 #define VIS_ERR_ARG 1
 #define VIS_ERR_LAUNCH 2
+#define VIS_ERR_UNSUPPORTED 3
 
 /* activation selectors for vis_gemm_bf16 / vis_gemv_bf16 */
 #define VIS_ACT_NONE 0
@@ -139,10 +142,14 @@ int vis_decode_attn_shared(const void* qkv, const void* cos_t, const void* sin_t
  * tables, caches, step_ptr as vis_decode_attn.
  * ws: vis_decode_chain_ws_bytes(Hq, Hkv, nsplit) bytes and sync: vis_decode_chain_sync_ints() ints, both zeroed once by the
  * caller and owned by one stream; sync[0] counts completed launches, sync[32] is a status word: non-zero after a launch = a
- * bounded wait gave up (results invalid; zero ws and sync before the next launch).  The packed projection row and the merged
+ * bounded wait gave up (results invalid; zero ws and sync before the next launch - until then every further launch on this
+ * sync block returns at once without computing: a stranded request costs one wait bound, not one per launch).  The tag of a
+ * launch is sync[0] + 1, and 1 after 2^32 - 1 (tag 0 marks a never-written granule): zero ws and sync between requests
+ * before sync[0] gets near 2^32.  The packed projection row and the merged
  * attention row live in ws as granules (low 32 bits = two bf16): ws[0 .. (Hq + 2 Hkv) * 64) and the next Hq * 64 words.
- * VIS_ERR_ARG for shapes outside the chained form (HD != 128, K or Hq * 128 > 4096, Hq > 64, a grid above what the device
- * holds resident): the caller then issues the four launches.  ONE chained launch at a time per device: its workgroups wait
+ * VIS_ERR_UNSUPPORTED for shapes outside the chained form (HD != 128, Hq / Hkv not in {1, 2, 4, 7, 8}, K or Hq * 128 > 4096,
+ * Hq > 64, a grid above what the device holds resident minus a margin of 32 workgroups): the caller then issues the four
+ * launches.  VIS_ERR_ARG is a caller bug.  ONE chained launch at a time per device: its workgroups wait
  * for each other inside the grid, so launches from two streams at once must be ordered by the caller (an event). */
 int vis_decode_chain_sync_ints(void);
 long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit);

@@ -26,7 +26,7 @@ def test_header_symbols_exported(lib_path):
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in vis_hip.h but not exported"
     lib.vis_abi_version.restype = ctypes.c_int
-    assert lib.vis_abi_version() == 2
+    assert lib.vis_abi_version() == 3
 
 
 def test_binding_covers_header(lib_path):

@@ -512,10 +512,12 @@ def test_prefix_cache_across_requests_is_bit_identical(device, monkeypatch):
     assert eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True) == full_a and len(eng._prefix_cache) == 0
 
 
-def test_stalled_chained_launch_is_re_served_on_the_unchained_step(device):
+def test_stalled_chained_launch_is_re_served_on_the_unchained_step(device, monkeypatch):
     """A chained layer-head launch whose in-grid wait gave up (another process running chained launches on the same GPU) raises
     the status word; the engine must notice it at the end of the request, serve the request again on the four-launch step -
-    identical tokens - and stay there.  Simulated by raising the status word by hand."""
+    identical tokens - stay there for VIS_CHAIN_RETRY_AFTER clean requests and then go back to the chained launch (one
+    transient stall must not cost the engine its faster step for good).  Simulated by raising the status word by hand."""
+    monkeypatch.setenv("VIS_CHAIN_RETRY_AFTER", "2")
     from vision_inspection_system_amd import hip
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
@@ -531,7 +533,12 @@ def test_stalled_chained_launch_is_re_served_on_the_unchained_step(device):
     eng.chain_sync[hip.CHAIN_STATUS_WORD] = 1                                            # "a wait timed out"
     assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # noticed, re-served unchained
     assert eng.chain_sync is None
-    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # and stays on the four launches
+    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # stays on the four launches ...
+    assert eng.chain_sync is None
+    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref          # ... for two clean requests,
+    assert eng.chain_sync is not None                                                    # then the chained launch is back
+    assert eng.generate(ids, frames, max_new_tokens=12, ignore_eos=True) == ref
+    assert eng.chain_sync is not None and int(eng.chain_sync[hip.CHAIN_STATUS_WORD]) == 0
     with pytest.raises(hip.ChainStalled):                                                # the low-level path reports it
         e2 = Qwen2VLEngine(cfg, w, device, max_ctx=256)
         e2.prefill(ids, frames, max_new_tokens=4)

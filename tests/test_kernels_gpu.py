@@ -1119,14 +1119,17 @@ def test_gemv_rows_bit_identical_to_single_row(hip, device, B, N, K, act, fused)
             assert torch.equal(many[b], one), f"row {b} of {B} differs from the single-row kernel (fp8={fp8})"
 
 
-@pytest.mark.parametrize("Hq,Hkv,K,T", [(28, 4, 3584, 4096), (28, 4, 3584, 2560), (2, 1, 256, 1024), (32, 8, 4096, 1024),
-                                        (16, 16, 2048, 512)])
+@pytest.mark.parametrize("Hq,Hkv,K,T", [(28, 4, 3584, 4608), (28, 4, 3584, 2560), (2, 1, 256, 1024), (32, 8, 4096, 1024),
+                                        (16, 16, 2048, 512), (28, 4, 3584, 6144)])
 def test_decode_chain_equals_unchained(hip, device, Hq, Hkv, K, T):
     """vis_decode_chain (qkv projection + RMSNorm + bias -> rope / KV append / split attention + merge -> o projection +
     residual as ONE launch with in-grid hand-offs) against the four launches it replaces (vis_gemv_bf16, vis_decode_attn =
     split + combine, vis_gemv_bf16): y, the merged attention row, the packed projection row and both caches bit for bit,
     at the 7B / 11B / tiny head shapes, at context lengths on and off the 64-key split boundaries up to the last cache row;
-    launches repeated back to back on one workspace (granule tags are launch numbers: no reset between launches), status clean."""
+    launches repeated back to back on one workspace (granule tags are launch numbers: no reset between launches), status clean.
+    T = 4608 is the client's default context (VIS_MAX_CTX: the reference's prompt + its default max_tokens) - a launcher that
+    refused that grid (e.g. a register footprint that grew past four waves per SIMD) fails here, not silently in the bench;
+    T = 6144 = 96 splits exercises the merge role's path for more than 64 splits and the largest grid the device holds."""
     HD = 128
     nq = (Hq + 2 * Hkv) * HD
     g = torch.Generator(device="cpu").manual_seed(Hq * 1000 + K + T)
@@ -1144,7 +1147,8 @@ def test_decode_chain_equals_unchained(hip, device, Hq, Hkv, K, T):
     ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
     assert hip.decode_chain_supported(Hq, Hkv, HD, K)
     launches = 0
-    for ctx in sorted({c for c in (0, 1, 62, 63, 64, 65, 127, 128, 700, T // 2 + 3, T - 2, T - 1) if c < T}):
+    ctxs = (0, 1, 62, 63, 64, 65, 127, 128, 700, T // 2 + 3, T - 2, T - 1) if T != 6144 else (63, 4095, 4097, 5000, T - 1)
+    for ctx in sorted({c for c in ctxs if c < T}):
         x = _randn((K,), device, 400 + ctx)
         step = torch.tensor([ctx], dtype=torch.int32, device=device)
         # ---- the four launches
@@ -1195,11 +1199,103 @@ def test_decode_chain_refuses_unsupported_shapes(hip, device):
     z = lambda *s: torch.zeros(s, dtype=torch.bfloat16, device=device)
     ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
     tab = torch.zeros((T, HD), dtype=torch.float32, device=device)
-    with pytest.raises(hip.HipLibraryError):
+    with pytest.raises(hip.ChainRefused):      # VIS_ERR_UNSUPPORTED, the one status the engine answers with the four launches
         hip.decode_chain(z(K), z(nq, K), None, z(K), z(K, Hq * HD), z(K), tab, tab, z(Hkv, T, HD), z(Hkv, T, HD),
                          torch.zeros(1, dtype=torch.int32, device=device), ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
     torch.cuda.synchronize()
     assert int(sync[0]) == 0 and int(sync[hip.CHAIN_STATUS_WORD]) == 0        # nothing was launched
+    # a caller bug is NOT a refusal: a misaligned pointer must surface as an error, never as a silent fall-back
+    Hq, Hkv, K, T = 28, 4, 3584, 256
+    ns, nq = T // hip.DECODE_KEYS_PER_SPLIT, (Hq + 2 * Hkv) * HD
+    ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
+    tab = torch.zeros((T, HD), dtype=torch.float32, device=device)
+    xbad = torch.zeros(K + 1, dtype=torch.bfloat16, device=device)[1:]     # 2-byte aligned
+    with pytest.raises(hip.HipLibraryError) as ei:
+        hip.decode_chain(xbad, z(nq, K), None, z(K), z(K, Hq * HD), z(K), tab, tab, z(Hkv, T, HD), z(Hkv, T, HD),
+                         torch.zeros(1, dtype=torch.int32, device=device), ws, sync, Hq, Hkv, HD, ns, HD ** -0.5, 1e-6)
+    assert not isinstance(ei.value, hip.ChainRefused)
+
+
+def _chain_case(device, Hq, Hkv, K, T, seed):
+    HD = 128
+    nq = (Hq + 2 * Hkv) * HD
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    c = {"wqkv": (torch.randn((nq, K), generator=g) / K ** 0.5).to(torch.bfloat16).to(device),
+         "bq": torch.randn((nq,), generator=g).mul(0.1).to(torch.bfloat16).to(device),
+         "nw": (1 + 0.1 * torch.randn((K,), generator=g)).to(torch.bfloat16).to(device),
+         "wo": (torch.randn((K, Hq * HD), generator=g) / (Hq * HD) ** 0.5).to(torch.bfloat16).to(device),
+         "kc": _randn((Hkv, T, HD), device, seed + 1), "vc": _randn((Hkv, T, HD), device, seed + 2)}
+    ang = torch.rand((T, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    c["cos"], c["sin"] = emb.cos().to(device).contiguous(), emb.sin().to(device).contiguous()
+    return c
+
+
+def test_decode_chain_epoch_wrap(hip, device):
+    """The granule tag of a chained launch is the sync block's 32-bit launch counter + 1; tag 0 is what a never-written
+    (zero-initialised) granule carries.  Six launches across the wrap (counter seeded at 0xFFFFFFFD: tags ...FE, ...FF, then 1
+    instead of 0, 2, 3, 4) on a FRESH workspace - a launch that ran with tag 0 would accept unwritten granules at once - each
+    bit-identical to the four launches."""
+    Hq, Hkv, K, T, HD = 28, 4, 3584, 1024, 128
+    nq = (Hq + 2 * Hkv) * HD
+    c = _chain_case(device, Hq, Hkv, K, T, 900)
+    ns = -(-T // hip.DECODE_KEYS_PER_SPLIT)
+    po = torch.empty(Hq * ns * HD, dtype=torch.float32, device=device)
+    pml = torch.empty(Hq * ns * 2, dtype=torch.float32, device=device)
+    ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
+    sync[0] = -3                                                           # 0xFFFFFFFD
+    expect = [-2, -1, 1, 2, 3, 4]                                          # the counter after each launch (int32 view)
+    for i, ctx in enumerate((5, 130, 700, 64, 1000, 333)):
+        x = _randn((K,), device, 950 + i)
+        step = torch.tensor([ctx], dtype=torch.int32, device=device)
+        k1, v1, k2, v2 = c["kc"].clone(), c["vc"].clone(), c["kc"].clone(), c["vc"].clone()
+        qkv1 = torch.empty(nq, dtype=torch.bfloat16, device=device)
+        att1 = torch.empty(Hq * HD, dtype=torch.bfloat16, device=device)
+        y1 = torch.empty(K, dtype=torch.bfloat16, device=device)
+        y2 = torch.full((K,), 3.0, dtype=torch.bfloat16, device=device)
+        hip.gemv(x, c["wqkv"], qkv1, bias=c["bq"], norm_w=c["nw"], eps=1e-6)
+        hip.decode_attn(qkv1, c["cos"], c["sin"], k1, v1, step, po, pml, att1, Hq, Hkv, HD, ns, HD ** -0.5)
+        hip.gemv(att1, c["wo"], y1, residual=x)
+        hip.decode_chain(x, c["wqkv"], c["bq"], c["nw"], c["wo"], y2, c["cos"], c["sin"], k2, v2, step, ws, sync, Hq, Hkv, HD, ns,
+                         HD ** -0.5, 1e-6)
+        torch.cuda.synchronize()
+        assert int(sync[hip.CHAIN_STATUS_WORD]) == 0, f"launch {i}: a wait timed out"
+        assert int(sync[0]) == expect[i], f"launch {i}: counter {int(sync[0])}, expected {expect[i]}"
+        assert torch.equal(y2, y1) and torch.equal(k2, k1) and torch.equal(v2, v1), f"launch {i} (tag across the wrap) differs"
+
+
+def test_decode_chain_fails_fast_after_a_stall(hip, device):
+    """Once the status word of a sync block is raised (a bounded wait of an earlier launch gave up), every further chained launch
+    on that block returns at once: no waits, nothing computed, the launch counter still advances (a
+    stranded request used to spin through every remaining launch's bounds - minutes - before the host looked at the word)."""
+    import time
+    Hq, Hkv, K, T, HD = 28, 4, 3584, 4608, 128
+    c = _chain_case(device, Hq, Hkv, K, T, 990)
+    ns = -(-T // hip.DECODE_KEYS_PER_SPLIT)
+    ws, sync = hip.decode_chain_state(device, Hq, Hkv, ns)
+    x = _randn((K,), device, 991)
+    step = torch.tensor([2300], dtype=torch.int32, device=device)
+    y = torch.full((K,), 3.0, dtype=torch.bfloat16, device=device)
+    args = (x, c["wqkv"], c["bq"], c["nw"], c["wo"], y, c["cos"], c["sin"], c["kc"], c["vc"], step, ws, sync, Hq, Hkv, HD, ns,
+            HD ** -0.5, 1e-6)
+    hip.decode_chain(*args)                                               # a healthy launch first
+    torch.cuda.synchronize()
+    assert int(sync[hip.CHAIN_STATUS_WORD]) == 0 and int(sync[0]) == 1 and not torch.equal(y, torch.full_like(y, 3.0))
+    sync[hip.CHAIN_STATUS_WORD] = 1                                       # "a wait gave up"
+    y.fill_(3.0)
+    kc0 = c["kc"].clone()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 28 * 128                                                          # the launches of 128 further tokens
+    for _ in range(n):
+        hip.decode_chain(*args)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert int(sync[0]) == 1 + n and int(sync[hip.CHAIN_STATUS_WORD]) == 1
+    assert torch.equal(y, torch.full_like(y, 3.0)) and torch.equal(c["kc"], kc0), "a launch behind a raised status word computed"
+    # 3584 launches of ~860 workgroups that only read one word: host-launch bound (~5-10 us each); the r04 kernel spun
+    # up to three bounds of 65 536 polls in every one of them
+    assert dt < 0.5, f"{n} launches behind a raised status word took {dt:.3f} s"
 
 
 @pytest.mark.parametrize("N,K,temperature", [(152064, 3584, 0.0), (152064, 3584, 0.7), (512, 256, 0.0), (1001, 704, 0.3)])

@@ -110,7 +110,10 @@ def get_model(model_id: str, device: Optional[str] = None) -> LoadedModel:
     with _ENGINES_LOCK:
         if key in _ENGINES:
             return _ENGINES[key]
-        max_ctx = int(os.environ.get("VIS_MAX_CTX", "4096"))
+        # KV-cache rows per sequence.  Default: the reference's request fits as the reference sends it - ~2300 prompt tokens
+        # (inspection prompt + one 1024 x 1024 image) + its own default max_tokens = 2048 (/root/reference utils/config.py:50-53)
+        # = 4348 -> 4608 (72 context splits: the chained decode launch stays resident up to ~6700)
+        max_ctx = int(os.environ.get("VIS_MAX_CTX", "4608"))
         max_batch = max(1, min(64, int(os.environ.get("VIS_MAX_BATCH", "64"))))
         mllama = _load_mllama(model_id, device, max_ctx, max_batch)
         if mllama is not None:

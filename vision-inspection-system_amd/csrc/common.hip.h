@@ -17,6 +17,9 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 #define VIS_OK 0
 #define VIS_ERR_ARG 1     // shape / alignment precondition violated
 #define VIS_ERR_LAUNCH 2  // hipGetLastError() after the launch was not hipSuccess
+#define VIS_ERR_UNSUPPORTED 3  // valid arguments, but this kernel form does not cover the shape on this device (vis_decode_chain:
+                               // head shape outside the chained form, or a grid larger than the device holds resident); nothing
+                               // was launched and the caller uses the equivalent separate launches
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float((uint32_t)v << 16); }
 

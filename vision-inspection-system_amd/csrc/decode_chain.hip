@@ -91,6 +91,7 @@ __device__ __forceinline__ void chain_merge_head(const gran_t* part_g, gran_t* a
   float m = -1.0e30f, l = 0.f;
   if (tid < 64) {                       // first sign of life (split 0's statistics): until then one granule per poll
     for (int it = 0; it < GV_CHAIN_SPIN_MAX; ++it) {
+      if (gr_poll_abort(status, it)) break;
       if (__all(gr_ok(gr_ld(pg + 128), tag))) break;
       __builtin_amdgcn_s_sleep(4);
     }
@@ -100,6 +101,7 @@ __device__ __forceinline__ void chain_merge_head(const gran_t* part_g, gran_t* a
     bool ok = false;
     const int st = min(tid, max(active - 1, 0));
     for (int it = 0; it < GV_CHAIN_SPIN_MAX && !ok; ++it) {
+      if (gr_poll_abort(status, it)) break;
 #pragma unroll
       for (int j = 0; j < PRE; ++j) {     // wave-uniform row (scalar offset) + the lane's dim: no per-load address registers
         const int sj = __builtin_amdgcn_readfirstlane(min(half + 2 * j, max(active - 1, 0)));
@@ -140,6 +142,7 @@ __device__ __forceinline__ void chain_merge_head(const gran_t* part_g, gran_t* a
     gran_t g = 0;
     bool ok = false;
     for (int it = 0; it < GV_CHAIN_SPIN_MAX; ++it) {
+      if (gr_poll_abort(status, it)) break;
       g = gr_ld(pg + (size_t)s * 130 + d);
       if (gr_ok(g, tag)) { ok = true; break; }
       __builtin_amdgcn_s_sleep(2);
@@ -167,10 +170,19 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const unsigned e = (unsigned)__hip_atomic_load(p.sync + CH_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const unsigned tag = e + 1u;
+  // tag 0 is what a zero-initialised (never written) granule carries: the launch after epoch 2^32 - 1 takes tag 1 (the
+  // engine zeroes workspace and sync block long before a counter gets there: Qwen2VLEngine._chain_epoch_guard)
+  const unsigned tag = (e + 1u != 0u) ? e + 1u : 1u;
   int* status = p.sync + CH_STATUS;
   const int Hkv = p.att.Hkv, Hq = p.att.Hq;
   CH_STAMP(0);
+  // Fail fast: a wait of an EARLIER launch on this sync block gave up - this request's results are
+  // already invalid and the host will serve it again (hip.ChainStalled).  Nobody waits for anybody: the launch is over in
+  // one dispatch; workgroup 0 still publishes the launch number so that the block stays consistent until the host zeroes it.
+  if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+    if (b == 0 && tid == 0) __hip_atomic_store(p.sync + CH_EPOCH, (int)tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
 
   if (b < p.n_gv) {
     // ------------------------------------------------------------------ projection role
@@ -201,6 +213,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs p) {
     if (wave == 0) {                                   // hold the W_o requests back until every kv group's rows are out
       const gran_t* cue = p.cue_g + min(lane, Hkv - 1);
       for (int it = 0; it < GV_CHAIN_SPIN_MAX; ++it) {
+        if (gr_poll_abort(status, it)) break;
         if (__all(gr_ok(gr_ld(cue), tag))) break;
         __builtin_amdgcn_s_sleep(4);
       }
@@ -216,6 +229,7 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs p) {
     if (wave == 0) {
       const gran_t* cue = p.attn_g + min(lane, Hq - 1) * 64 + 63;
       for (int it = 0; it < GV_CHAIN_SPIN_MAX; ++it) {
+        if (gr_poll_abort(status, it)) break;
         const bool ok = gr_ok(gr_ld(cue), tag);
         if (CH_CUE_ALL ? __all(ok) : __any(ok)) break;
         __builtin_amdgcn_s_sleep(8);
@@ -235,7 +249,12 @@ __global__ __launch_bounds__(256) void decode_chain_kernel(ChainArgs p) {
 #pragma unroll
         for (int k = 0; k < NST; ++k)
           if (tid + 256 * k < ng && !gr_ok(g[k], tag)) ok = false;
-        if (!ok) __builtin_amdgcn_s_sleep(2);
+        if (!ok) {
+          // (the "somebody gave up" check sits HERE, where the granule registers are dead: at the top of the loop it cost
+          // 18 VGPRs - 141 instead of 123, i.e. three waves per SIMD instead of four and a grid that no longer fits)
+          if (gr_poll_abort(status, it)) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
       }
 #pragma unroll
       for (int k = 0; k < NST; ++k)
@@ -290,20 +309,40 @@ static size_t chain_lds_bytes(int K) {
 }
 
 // workgroups of this kernel the device holds at once, from the kernel's own footprint (the occupancy API reads one block per
-// CU high for some SGPR counts - MI355X_MICROARCH.md; here a short count would make a workgroup wait for one never placed)
+// CU high for some SGPR counts - MI355X_MICROARCH.md; here a short count would make a workgroup wait for one never placed).
+// The model is an otherwise EMPTY device: whatever else runs there at the same time (another stream's prompt pass, another
+// process) is covered by the bounded waits and the status word only - CH_RESIDENT_MARGIN workgroup slots are left unclaimed
+// so that a neighbour's small kernels do not turn straight into timeouts.  Cached per (device, dynamic LDS bytes): the
+// first call on a device also raises the kernel's dynamic-LDS limit THERE (a process-wide static kept the
+// first device's / first K's answer).
+#define CH_RESIDENT_MARGIN 32
+#define CH_MAX_DEVICES 16
 template <int G>
 static int chain_resident_blocks(size_t lds) {
+  struct Entry { size_t lds; int blocks; bool attr_set; };
+  static Entry cache[CH_MAX_DEVICES] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= CH_MAX_DEVICES) return 0;
+  Entry& en = cache[dev];
+  if (!en.attr_set) {
+    if (hipFuncSetAttribute((const void*)decode_chain_kernel<G>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(64 * 1024)) !=
+        hipSuccess)
+      return 0;
+    en.attr_set = true;
+  }
+  if (en.lds == lds && en.blocks > 0) return en.blocks;
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, (const void*)decode_chain_kernel<G>) != hipSuccess) return 0;
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-    return 0;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   const int vg = ((fa.numRegs > 0 ? fa.numRegs : 512) + 7) / 8 * 8;
   int per_simd = 512 / vg;                         // a 256-thread workgroup puts one wave on each of the CU's four SIMDs
   if (per_simd > 8) per_simd = 8;
   const int by_lds = (int)((160 * 1024) / (lds + fa.sharedSizeBytes + 256));
   const int per_cu = per_simd < by_lds ? per_simd : by_lds;
-  return per_cu * cus;
+  en.lds = lds;
+  en.blocks = per_cu * cus - CH_RESIDENT_MARGIN;
+  return en.blocks;
 }
 
 static unsigned long long* g_chain_probe = nullptr;
@@ -322,19 +361,21 @@ extern "C" long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit) {
 // One launch for qkv projection (+ RMSNorm, bias) -> rope / KV append / attention -> o projection (+ residual); see the top
 // of this file.  `sync`: vis_decode_chain_sync_ints() zero-initialised ints, `ws`: vis_decode_chain_ws_bytes() zero-initialised
 // bytes; both owned by the caller's stream (one pair per engine; zero both again after a non-zero status word).
-// Returns VIS_ERR_ARG for shapes the chained form does not cover (the caller then uses the four launches): head_dim != 128,
-// K or Hq * 128 above 4096, more than 64 query heads, a grid larger than the device holds resident.
+// Returns VIS_ERR_UNSUPPORTED (nothing launched; the caller then uses the four launches) for shapes the chained form does not
+// cover: head_dim != 128, a group size other than 1 / 2 / 4 / 7 / 8, K or Hq * 128 above 4096, more than 64 query heads, a grid
+// larger than the device holds resident.  VIS_ERR_ARG is a caller bug (null / misaligned pointers, inconsistent sizes).
 extern "C" int vis_decode_chain(const void* x, const void* x_idx, int x_rows, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
                                 const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr,
                                 void* ws, void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o,
                                 int cache_tokens, int nsplit, float scale, float eps, hipStream_t stream) {
   if (!x || !Wqkv || !norm_w || !Wo || !y || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !ws || !sync)
     return VIS_ERR_ARG;
-  if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq > 64 || Hkv > 16 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  if (Hq <= 0 || Hkv <= 0 || HD <= 0 || K <= 0) return VIS_ERR_ARG;
+  if (HD != 128 || Hq > 64 || Hkv > 16 || Hq % Hkv != 0) return VIS_ERR_UNSUPPORTED;
   const int G = Hq / Hkv;
-  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_UNSUPPORTED;
   const int Nqkv = (Hq + 2 * Hkv) * 128, Ko = Hq * 128, No = K;
-  if (K <= 0 || K % 8 != 0 || K > 4096 || Ko > 4096 || (No & 1)) return VIS_ERR_ARG;   // one K-segment per weight row
+  if (K % 8 != 0 || K > 4096 || Ko > 4096 || (No & 1)) return VIS_ERR_UNSUPPORTED;   // one K-segment per weight row
   if (ldw_qkv % 8 != 0 || ldw_qkv < K || ldw_o % 8 != 0 || ldw_o < Ko) return VIS_ERR_ARG;
   if (nsplit <= 0 || nsplit > 256 || cache_tokens <= 0 || (long long)nsplit * DA_MAXKEYS < cache_tokens) return VIS_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)Wqkv | (uintptr_t)norm_w | (uintptr_t)Wo | (uintptr_t)k_cache | (uintptr_t)v_cache) & 15)
@@ -362,26 +403,20 @@ extern "C" int vis_decode_chain(const void* x, const void* x_idx, int x_rows, co
   p.probe = g_chain_probe;
   p.n_gv = Nqkv / 8;                                   // four waves x one row pair
   p.n_att = Hkv * nsplit;
-  if (No / 2 > p.n_gv * 4) return VIS_ERR_ARG;         // every o row pair needs a wave
+  if (No / 2 > p.n_gv * 4) return VIS_ERR_UNSUPPORTED; // every o row pair needs a wave
   const int grid = p.n_gv + p.n_att + Hq;
   size_t lds = 0;
   int resident = 0;
-#define CHAIN_CASE(GG)                                                                                         \
-  case GG: {                                                                                                   \
-    lds = chain_lds_bytes<GG>(K > Ko ? K : Ko);                                                               \
-    static const int res = [](size_t l) {                                                                      \
-      if (hipFuncSetAttribute((const void*)decode_chain_kernel<GG>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)(64 * 1024)) != hipSuccess)                                                 \
-        return 0;                                                                                              \
-      return chain_resident_blocks<GG>(l);                                                                     \
-    }(lds);                                                                                                    \
-    resident = res;                                                                                            \
+#define CHAIN_CASE(GG)                                        \
+  case GG: {                                                  \
+    lds = chain_lds_bytes<GG>(K > Ko ? K : Ko);              \
+    if (lds <= 64 * 1024) resident = chain_resident_blocks<GG>(lds); \
   } break;
   switch (G) {
     CHAIN_CASE(1) CHAIN_CASE(2) CHAIN_CASE(4) CHAIN_CASE(7) CHAIN_CASE(8)
   }
 #undef CHAIN_CASE
-  if (lds > 64 * 1024 || grid > resident) return VIS_ERR_ARG;
+  if (lds > 64 * 1024 || grid > resident) return VIS_ERR_UNSUPPORTED;
   vis_clear_error();
   switch (G) {
     case 1: hipLaunchKernelGGL(decode_chain_kernel<1>, dim3(grid), dim3(256), lds, stream, p); break;

@@ -234,8 +234,13 @@ __device__ __forceinline__ void gv_stage_row(const bf16_t* __restrict__ x, const
 // round trip, with no store drain, no counter and no second load after a flag (MI355X_MICROARCH.md, persistent-kernel
 // price list: "handoff" rows / granules).  A first version of the chain used counters (sc1 payload -> s_waitcnt vmcnt(0)
 // -> barrier -> agent-scope atomic add; consumer: poll -> barrier -> sc1 loads): ~6 us per hop, 30.5 us for the whole
-// head against 27.5 us for the four launches it replaced.  Every poll loop is bounded.
-#define GV_CHAIN_SPIN_MAX (1 << 16)
+// head against 27.5 us for the four launches it replaced.  Every poll loop is bounded: GV_CHAIN_SPIN_MAX polls of one
+// `sc1` load round trip + s_sleep each (measured period with the whole grid polling: tools/probes/poll_period.py, DESIGN
+// section 4 - a bound of the order of 10 ms, three orders of magnitude above the ~10 us a hand-off takes when the grid is
+// resident), and every 32nd poll also looks at the sync block's status word: once ANY wait of the launch has given up, every
+// other wait of that launch - and, through the entry check of decode_chain_kernel, every later launch of the request - ends
+// at once instead of spinning through its own bound (a stranded request cost minutes, now one bound).
+#define GV_CHAIN_SPIN_MAX (1 << 13)
 typedef unsigned long long gran_t;
 
 __device__ __forceinline__ gran_t gr_ld(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -243,6 +248,13 @@ __device__ __forceinline__ void gr_st(gran_t* p, uint32_t payload, unsigned tag)
   __hip_atomic_store(p, (gran_t)payload | ((gran_t)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ bool gr_ok(gran_t v, unsigned tag) { return (unsigned)(v >> 32) == tag; }
+// top of every poll iteration: a compiler barrier (the granule reads of a poll loop must be re-issued every time round -
+// relaxed atomics and buffer loads alone do not forbid hoisting them) and, every 32nd poll, the "somebody gave
+// up" check; true = stop waiting (workgroup-uniform only where the caller makes it so: callers treat it like a timeout)
+__device__ __forceinline__ bool gr_poll_abort(const int* status, int it) {
+  asm volatile("" ::: "memory");
+  return (it & 31) == 31 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
 
 
 // ---------------------------------------------------------------------------
@@ -338,6 +350,7 @@ __device__ __forceinline__ void chain_stage_qkv(const ChainCtx& cc, DecAttnLds<G
   }
   bool left = true;
   for (int it = 0; it < GV_CHAIN_SPIN_MAX && left; ++it) {
+    if (gr_poll_abort(cc.status, it)) break;
     gran_t v[NIT];
 #pragma unroll
     for (int k = 0; k < NIT; ++k) v[k] = gr_ld(src[k]);

@@ -116,7 +116,7 @@ extern "C" int vis_scatter_rows(const void* src, const void* idx, void* dst, int
   return vis_check_launch();
 }
 
-extern "C" int vis_abi_version(void) { return 2; }   // 2: V^T columns in k-slot order
+extern "C" int vis_abi_version(void) { return 3; }   // 2: V^T columns in k-slot order; 3: VIS_ERR_UNSUPPORTED, r04/r05 entry points
 
 // ---------------------------------------------------------------------------
 // Row f2 (mllama): vis_patchify_tiles_u8 - the resized RGB frame [H][W][3] u8, zero-padded on the right/bottom to

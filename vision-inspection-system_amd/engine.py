@@ -17,6 +17,7 @@ Stages (kernel ids as in SURVEY.md section 8a):
 from __future__ import annotations
 
 import collections
+import logging
 import os
 import threading
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -129,9 +130,17 @@ def mrope_cos_sin(cfg: Qwen2VLConfig, pos3: np.ndarray) -> Tuple[np.ndarray, np.
     return np.cos(emb).astype(np.float32), np.sin(emb).astype(np.float32)
 
 
-# the last chained decode call enqueued per device (Qwen2VLEngine.decode orders such calls on the GPU)
-_CHAIN_ORDER_LOCK = threading.Lock()
+# the last chained decode call enqueued per device (Qwen2VLEngine.decode orders such calls on the GPU); one lock per device:
+# engines on different GPUs driven from different threads do not serialise their host launch loops
+_CHAIN_LOCKS_GUARD = threading.Lock()
+_CHAIN_ORDER_LOCKS: Dict[Optional[int], threading.Lock] = {}
 _CHAIN_LAST: Dict[Optional[int], "torch.cuda.Event"] = {}
+_LOG = logging.getLogger("vision_inspection_system_amd.engine")
+
+
+def _chain_order_lock(index: Optional[int]) -> threading.Lock:
+    with _CHAIN_LOCKS_GUARD:
+        return _CHAIN_ORDER_LOCKS.setdefault(index, threading.Lock())
 
 
 # ----------------------------------------------------------------------------- engine
@@ -198,6 +207,9 @@ class Qwen2VLEngine:
         # launch whose stages hand over inside the grid (csrc/decode_chain.hip; bit-identical to the four launches it
         # replaces).  VIS_DECODE_CHAIN=0 keeps the four launches (A/B).
         self.chain_sync: Optional[torch.Tensor] = None
+        self._chain_state: Optional[tuple] = None      # (ws, sync) kept while the chain is switched off after a stall
+        self._chain_launches = 0                       # host-side count of chained launches on the sync block (epoch guard)
+        self._chain_clean_requests = 0                 # requests served on the four launches since a stall
         if decode_weights == "bf16" and os.environ.get("VIS_DECODE_CHAIN", "1") != "0" \
                 and hip.decode_chain_supported(Hq, Hkv, D, H):
             self.chain_ws, self.chain_sync = hip.decode_chain_state(dev, Hq, Hkv, self.nsplit)
@@ -1007,10 +1019,13 @@ class Qwen2VLEngine:
                     hip.decode_chain(w.embed if li == 0 else x[0], lw.qkv_w, lw.qkv_b, lw.ln1_w, lw.o_w, x2[0], self.cos_t,
                                      self.sin_t, self.kcache[li], self.vcache[li], self.step, self.chain_ws, self.chain_sync,
                                      Hq, Hkv, D, self.nsplit, scale, cfg.rms_eps, x_index=self.cur_token if li == 0 else None)
-                except hip.HipLibraryError:
+                except hip.ChainRefused as e:
+                    # VIS_ERR_UNSUPPORTED and nothing else (a bad argument or a launch error propagates): the grid for this
+                    # context length is larger than the device holds resident -> the four launches, same results; said once
                     if li:
                         raise
-                    self.chain_sync, chained = None, False     # the launcher refused the grid (not resident here): four launches
+                    _LOG.warning("%s - decoding on the four launches per layer head (VIS_MAX_CTX=%d)", e, self.max_ctx)
+                    self.chain_sync, self._chain_state, chained = None, None, False
                     hip.gather_rows(w.embed, self.cur_token, self.d_x)
             if self.chain_sync is None:
                 hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
@@ -1177,7 +1192,8 @@ class Qwen2VLEngine:
         # once could strand each other (each holding slots the other's producers need; the bounded waits would then raise).
         # So the chained decode calls of a device are ordered on the GPU: a call waits for the previous call's last launch
         # (an event, no host blocking), whatever streams or threads they come from.  Decode is HBM-bound: nothing is lost.
-        with _CHAIN_ORDER_LOCK:
+        self._chain_epoch_guard(n_steps)
+        with _chain_order_lock(self.device.index):
             cur = torch.cuda.current_stream(self.device)
             prev = _CHAIN_LAST.get(self.device.index)
             if prev is not None:
@@ -1186,6 +1202,17 @@ class Qwen2VLEngine:
             ev = torch.cuda.Event()
             ev.record(cur)
             _CHAIN_LAST[self.device.index] = ev
+
+    def _chain_epoch_guard(self, n_steps: int) -> None:
+        """The granule tag of a chained launch is the sync block's 32-bit launch counter + 1.  Long before it can wrap
+        (2^31 launches = ~2.6 days of continuous single-sequence decode) workspace and sync block are zeroed on the stream,
+        between two decode calls - no launch of this engine is in flight then (same stream), and the kernel itself skips
+        tag 0, the mark of a never-written granule (tests/test_kernels_gpu.py::test_decode_chain_epoch_wrap)."""
+        self._chain_launches += n_steps * len(self.w.llm)
+        if self._chain_launches >= (1 << 31):
+            self.chain_sync.zero_()
+            self.chain_ws.zero_()
+            self._chain_launches = n_steps * len(self.w.llm)
 
     def _decode_steps(self, n_steps: int, use_graph: bool) -> None:
         if use_graph:
@@ -1208,13 +1235,34 @@ class Qwen2VLEngine:
         if self.chain_sync is not None and int(self.chain_sync[hip.CHAIN_STATUS_WORD].item()) != 0:
             self.chain_sync.zero_()
             self.chain_ws.zero_()
+            self._chain_launches = 0
             raise hip.ChainStalled("vis_decode_chain: a hand-off wait inside the launch timed out (decode results invalid)")
 
     def disable_chain(self) -> None:
         """Back to the four launches per layer head (same results bit for bit); the captured decode graphs hold chained launches
-        and are dropped."""
+        and are dropped.  The (zeroed) workspace is kept: `_maybe_reenable_chain` switches back after VIS_CHAIN_RETRY_AFTER
+        requests served cleanly on the four launches - one transient stall (a co-tenant's burst) does not cost the engine
+        its faster step for good."""
+        if self.chain_sync is not None:
+            self._chain_state = (self.chain_ws, self.chain_sync)
         self.chain_sync = None
+        self._chain_clean_requests = 0
         self._graphs.clear()
+
+    def _maybe_reenable_chain(self) -> None:
+        if self.chain_sync is not None or self._chain_state is None:
+            return
+        self._chain_clean_requests += 1
+        retry_after = int(os.environ.get("VIS_CHAIN_RETRY_AFTER", "64"))
+        if retry_after > 0 and self._chain_clean_requests >= retry_after:
+            self.chain_ws, self.chain_sync = self._chain_state
+            self._chain_state = None
+            self.chain_sync.zero_()
+            self.chain_ws.zero_()
+            self._chain_launches = 0
+            self._graphs.clear()
+            _LOG.warning("vis_decode_chain: %d requests served on the four launches since the stall - chained layer head back on",
+                         self._chain_clean_requests)
 
     def generate(self, input_ids: Sequence[int], frames: Sequence[torch.Tensor] = (), max_new_tokens: int = 128,
                  ignore_eos: bool = False, use_graph: bool = True, check_every: int = 16,
@@ -1222,15 +1270,24 @@ class Qwen2VLEngine:
         """Generate up to max_new_tokens (greedy at temperature 0).  EOS is checked on the host every
         ``check_every`` tokens so the decode loop itself never synchronises; output is truncated at the
         first EOS (exclusive)."""
-        max_new_tokens = max(1, min(max_new_tokens, self.max_ctx - len(input_ids) - 1))
+        room = self.max_ctx - len(input_ids) - 1
+        if max_new_tokens > room and not getattr(self, "_warned_clamp", False):
+            self._warned_clamp = True          # said once per engine: the reply may end before the model is done
+            _LOG.warning("max_tokens=%d does not fit the context (prompt %d + reply <= VIS_MAX_CTX=%d): generating at most %d",
+                         max_new_tokens, len(input_ids), self.max_ctx, max(1, room))
+        max_new_tokens = max(1, min(max_new_tokens, room))
         try:
-            return self._generate(input_ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)
+            out = self._generate(input_ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)
+            self._maybe_reenable_chain()
+            return out
         except hip.ChainStalled as e:
-            # Something else ran chained launches on this device at the same time (another PROCESS sharing the GPU: launches of
-            # this process are ordered, Qwen2VLEngine.decode).  The request is served again on the unchained launches - the same
-            # HIP kernels' arithmetic, identical tokens - and the engine stays on them.
-            import logging
-            logging.getLogger("vision_inspection_system_amd.engine").warning("%s - continuing on the unchained decode step", e)
+            # Something else held CU slots this launch's producers needed (another PROCESS sharing the GPU, or other work of
+            # this process on another stream: chained launches of this process are ordered, Qwen2VLEngine.decode, everything
+            # else is covered by the bounded wait only).  From the launch after the stall on every chained launch of the
+            # request returned at once (status word read at kernel entry), so what was lost is one wait bound.  The request is
+            # served again on the unchained launches - the same HIP kernels' arithmetic, identical tokens - and the engine
+            # stays on them for the next VIS_CHAIN_RETRY_AFTER requests.
+            _LOG.warning("%s - continuing on the unchained decode step", e)
             self.disable_chain()
             return self._generate(input_ids, frames, max_new_tokens, ignore_eos, use_graph, check_every, temperature, seed)
 

@@ -99,6 +99,11 @@ class HipLibraryError(RuntimeError):
     """The gfx950 extension is missing or an entry point rejected its arguments."""
 
 
+class ChainRefused(HipLibraryError):
+    """vis_decode_chain returned VIS_ERR_UNSUPPORTED: the head shape is outside the chained form or its grid is larger than the
+    device holds resident.  Nothing was launched; the caller issues the four launches (same results bit for bit)."""
+
+
 class ChainStalled(HipLibraryError):
     """A bounded wait inside a chained layer-head launch (vis_decode_chain) gave up: its workgroups could not all be resident
     - another process or stream was running a chained launch on the same device at the same time."""
@@ -132,7 +137,8 @@ def load() -> ctypes.CDLL:
 
 def _check(rc: int, name: str) -> None:
     if rc != 0:
-        why = {1: "argument/shape/alignment precondition violated", 2: "HIP launch error"}.get(rc, "unknown")
+        why = {1: "argument/shape/alignment precondition violated", 2: "HIP launch error",
+               3: "shape not covered by this kernel form on this device"}.get(rc, "unknown")
         raise HipLibraryError(f"{name} failed with status {rc} ({why})")
 
 
@@ -754,6 +760,9 @@ def decode_chain(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: Optional[torch.Ten
     rc = lib.vis_decode_chain(_ptr(x), _ptr(x_index), x_rows, _ptr(qkv_w), _ptr(qkv_b), _ptr(norm_w), _ptr(o_w), _ptr(y), _ptr(cos_t), _ptr(sin_t),
                               _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(ws), _ptr(sync), n_q, n_kv, head_dim, K,
                               qkv_w.stride(0), o_w.stride(0), T, nsplit, scale, eps, _stream())
+    if rc == 3:
+        raise ChainRefused(f"vis_decode_chain: {n_q}/{n_kv} heads, hidden {K}, {nsplit} context splits are outside the chained "
+                           "form on this device (shape, or grid larger than the device holds resident); nothing was launched")
     _check(rc, "vis_decode_chain")
 
 
