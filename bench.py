@@ -175,18 +175,21 @@ def measure_gemv(engine, reps: int = 5):
     return s.elapsed_time(e) * 1e-3 / reps / launches, launches
 
 
-def measured_traffic(kind: str = "gemv"):
+def measured_traffic(kind: str = "gemv", with_source: bool = False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_<kind>_traffic.json: "gemv" = gemv_bf16_kernel, "decode_stream" = gemm_decode_stream_kernel), or None."""
+    (profiles/*_<kind>_traffic.json: "gemv" = gemv_bf16_kernel, "decode_stream" = the batched decode projection kernel), or
+    None.  The figure is NOT measured in this run (PMC passes need their own rocprofv3 invocations): ``with_source`` also
+    returns the tracked file it was read from, which the JSON line names next to it ("traffic_source")."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{kind}_traffic.json")))
-    if not files:
-        return None
-    try:
-        with open(files[-1]) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
-    except Exception:
-        return None
+    val, src = None, None
+    if files:
+        try:
+            with open(files[-1]) as f:
+                val, src = float(json.load(f)["hbm_bytes_per_launch"]), "profiles/" + os.path.basename(files[-1])
+        except Exception:
+            val, src = None, None
+    return (val, src) if with_source else val
 
 
 def cpu_baseline(cfg, n_patches: int, S: int, new_tokens: int):
@@ -253,7 +256,14 @@ def cpu_baseline(cfg, n_patches: int, S: int, new_tokens: int):
             _ = h[-1] @ lm_head.t()
         t_lm = (time.perf_counter() - t0) / 2
     t_img = cfg.v_depth * t_vit + cfg.layers * t_llm + new_tokens * (cfg.layers * t_dec + t_lm)
+    host = "unknown"
+    try:   # quote the baseline with the box it ran on (the lease lands on different hosts: never a ratio across runs)
+        with open("/proc/cpuinfo") as f:
+            host = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {"value": 1.0 / t_img, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpu": f"{host} ({os.cpu_count()} logical CPUs)",
             "sample": (f"oracle fp32 at 7B shapes: 1 ViT block N={n_patches} ({t_vit:.2f}s), 1 LLM prefill layer "
                        f"S={S} ({t_llm:.2f}s), {n_dec} decode-layer steps ({t_dec * 1e3:.0f}ms each), lm_head "
                        f"({t_lm * 1e3:.0f}ms); extrapolated x{cfg.v_depth}/x{cfg.layers}/x{new_tokens} to one image "
@@ -270,6 +280,9 @@ def measure_decode_gemm(engine, B: int, reps: int = 5):
     n = [0]
 
     def projections():
+        if engine.fused_proj:        # r05: decode_proj_kernel (projection + reduction + epilogue in one launch)
+            n[0] += engine._decode_step_fused(B, projections_only=True)
+            return
         xn, xn2, att, act, part = engine.b_xn[:B], engine.b_xn2[:B], engine.b_attn[:B], engine.b_act[:B], engine.b_part
         if fp8:
             xq, x2q, aq = engine.b_xq[:B], engine.b_x2q[:B], engine.b_actq[:B]
@@ -858,8 +871,10 @@ def main():
         p8 = args.prefill_dtype == "fp8"
         if B > 1:
             k_avg, k_launches = measure_decode_gemm(engine, B)
-            kernel = "gemm_decode_stream_kernel" + ("<fp8>" if fp8 and engine.fp8_batched else "") + \
-                f" (batched decode projection, weights streamed once for {B} sequences)"
+            kernel = ("decode_proj_kernel" if engine.fused_proj else "gemm_decode_stream_kernel") + \
+                ("<fp8>" if fp8 and engine.fp8_batched else "") + \
+                f" (batched decode projection, weights streamed once for {B} sequences" + \
+                (", split-K reduction and epilogue in the same launch)" if engine.fused_proj else ")")
         else:
             k_avg, k_launches = measure_gemv(engine)
             kernel = ("gemv_fp8w_kernel" if fp8 else "gemv_bf16_kernel") + " (decode weight streaming)"
@@ -903,8 +918,14 @@ def main():
                        f"REHEARSAL: {world} ranks sharing ONE GPU, records over gloo - not a scaling measurement"},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (fp8 or B > 1) else measured_traffic(), "bytes_per_launch": bytes_per_launch,
-                         "avg_launch_us": k_avg * 1e6, "launches_per_token": k_launches},
+                         "traffic": None if (fp8 or B > 1) else measured_traffic("gemv", True)[0],
+                         # not measured in this run: read from the tracked rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+                         "traffic_source": None if (fp8 or B > 1) else measured_traffic("gemv", True)[1],
+                         "bytes_per_launch": bytes_per_launch,
+                         "avg_launch_us": k_avg * 1e6, "launches_per_token": k_launches,
+                         # the same bound over the WHOLE decode token (every weight byte of a step / the step's time): the
+                         # figure that stays comparable when the set of kernels behind `kernel` changes between rounds
+                         "whole_token_frac": step_bytes * (new - 1) / t_dec / 1e9 / HBM_PEAK_GBS},
             "prefill_mfma": {"flops": flops, "ms": t_pre * 1e3, "images": B, "achieved": flops / t_pre / 1e12,
                              "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": flops / t_pre / 1e12 / MFMA_BF16_PEAK_TF,
                              "note": ("FLOPs of B full prompt passes / time of the B prompt passes of a step; with a "

@@ -212,7 +212,7 @@ int vis_resize_rgb_u8(const void* src, void* tmp, void* dst, int in_h, int in_w,
  * chroma planes; dw_c / dh_c: real chroma size in samples.  Integer arithmetic throughout: the result equals
  * libjpeg-turbo's default decoder (islow IDCT, fancy upsampling) bit for bit. */
 int vis_jpeg_to_rgb(const void* coeffs, const void* qt, void* planes, void* rgb, int width, int height, int ncomp,
-                    int hs, int vs, int bw_y, int bh_y, int bw_c, int bh_c, int dw_c, int dh_c, hipStream_t stream);
+                    int hs, int vs, int bw_y, int bh_y, int bw_c, int bh_c, int dw_c, int dh_c, vis_stream_t stream);
 
 /* K1 (front)  resized RGB u8 frame [H][W][3] -> normalised bf16 patch rows
  * out[row0 + p][ld_out] in the merge-group order of
@@ -251,6 +251,41 @@ int vis_splitk_finalize_norm(const void* part, int ksplit, const void* bias, con
 int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* bias, const void* R,
                   const void* norm_w, void* y, int N, int K, int ldw, int act, int out_f32, float eps,
                   vis_stream_t stream);
+
+/* K10 (batched decode), round 5: projection + split-K reduction + row-wise epilogue in ONE launch (csrc/decode_stream.hip);
+ * replaces vis_gemm_decode_* + vis_skinny_finalize* in the engines (those stay exported).  Same persistent stream-K ring;
+ * a tile cut between workgroups is summed, in fixed segment order, by whichever of them takes the tile's last ticket
+ * (nobody waits), then finished there:
+ *   VIS_DP_PLAIN       C[b][n] = (x W^T)[b][n] * rs[b] + bias[n]         bf16, or f32 when out_f32 (q/k/v, lm_head)
+ *   VIS_DP_SWIGLU      C[b][o] = silu(g * rs[b]) * (u * rs[b])           16-row interleaved gate/up weight, N / 2 outputs
+ *   VIS_DP_RESID_NORMW C = y = bf16(x W^T + R), Cw = bf16(y * nw[n]), ssq_out[n / 128][b] = sum over the tile of y^2
+ * The RMSNorm in front of a projection (TF modeling_qwen2_vl.py:96-110) is applied in two exact halves: the PRODUCER of the
+ * row multiplies by the norm weight (Cw, a per-column factor), the CONSUMER by rs[b] = rsqrt(sum_t ssq_in[t][b] / norm_dim +
+ * eps) (a per-row factor that commutes with the projection); ssq_in == NULL means rs = 1.  ssq buffers: [tiles][64] f32.
+ * ws: vis_decode_proj_ws_bytes(B, N, K, fp8) bytes, 256-byte aligned, zeroed once (the kernel leaves it reusable), one
+ * launch at a time per workspace.  A row's result depends on that row alone (bitwise slot / batch-size invariance).
+ * Cq / Cqs (SWIGLU, RESID_NORMW; may be NULL): the row the next projection consumes (act, or y * nw) as MX blocks: OCP
+ * e4m3 bytes [B][ldcq] + one E8M0 scale byte per 32 columns [B][ldcqs] (the smallest power of two with block maximum /
+ * scale <= 448).  vis_decode_proj_fp8 (BASELINE configs[4]): A given as such blocks (Aq, As), Wq e4m3 [N][ldw] with
+ * per-output-row f32 scales sw[N], on v_mfma_scale_f32_16x16x128_f8f6f4 with the block scale in the instruction's scale
+ * operand; K % 128 == 0.  vis_decode_prep_rows: head of a step - x[b] = table[ids[b]] (clamped), xw = bf16(x * nw), the
+ * MX copy of xw (xq / xqs, may be NULL) and ssq[n / 128][b]; H % 128 == 0. */
+#define VIS_DP_PLAIN 0
+#define VIS_DP_SWIGLU 1
+#define VIS_DP_RESID_NORMW 2
+long long vis_decode_proj_ws_bytes(int B, int N, int K, int fp8);
+int vis_decode_proj_bf16(const void* A, const void* W, void* ws, void* C, void* Cw, void* Cq, void* Cqs,
+                         const void* bias, const void* R, const void* nw, const void* ssq_in, void* ssq_out,
+                         int B, int N, int K, int lda, int ldw, int ldc, int ldr, int ldcq, int ldcqs, int mode,
+                         int out_f32, int tiles_in, int norm_dim, float eps, vis_stream_t stream);
+int vis_decode_proj_fp8(const void* Aq, const void* As, const void* Wq, const void* sw, void* ws, void* C,
+                        void* Cw, void* Cq, void* Cqs, const void* bias, const void* R, const void* nw,
+                        const void* ssq_in, void* ssq_out, int B, int N, int K, int ldaq, int ldas, int ldw,
+                        int ldc, int ldr, int ldcq, int ldcqs, int mode, int out_f32, int tiles_in,
+                        int norm_dim, float eps, vis_stream_t stream);
+int vis_decode_prep_rows(const void* table, const void* ids, const void* nw, void* x, void* xw, void* xq,
+                         void* xqs, void* ssq, int B, int table_rows, int H, int ldx, int ldq, int ldqs,
+                         vis_stream_t stream);
 
 /* K10 for a handful of in-flight sequences (1 <= B <= 4): vis_gemv_bf16 / vis_gemv_fp8w over B input rows
  * (x [B][ldx], y [B][ldy], R [B][ldr]; bias and norm_w shared).  The weights are streamed ONCE for all rows, each row's

@@ -37,6 +37,31 @@ def test_binding_covers_header(lib_path):
     hip.load()
 
 
+def test_binding_signatures_match_header(lib_path):
+    """Every ctypes signature of hip.py against the prototype in include/vis_hip.h, argument by argument (pointer / int /
+    float / unsigned / long long).  A binding one int short is a ctypes.ArgumentError at the first call - on the GPU box, after
+    minutes of queueing (r05) - or, worse, shifted arguments; this is the CPU-side check."""
+    from vision_inspection_system_amd import hip
+    header = open(os.path.join(ROOT, "include", "vis_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", " ", header, flags=re.S)
+    protos = dict((m.group(1), m.group(2)) for m in re.finditer(r"\b(vis_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", header))
+
+    def code(param: str) -> str:
+        param = " ".join(param.split())
+        if "*" in param or param.startswith("vis_stream_t") or param.startswith("hipStream_t"):
+            return "p"
+        for prefix, c in (("long long", "l"), ("unsigned", "u"), ("float", "f"), ("int", "i")):
+            if param.startswith(prefix + " ") or param == prefix:
+                return c
+        raise AssertionError(f"unparsed parameter {param!r}")
+
+    for name, sig in hip._SIGS.items():
+        assert name in protos, name
+        params = [p for p in protos[name].split(",") if p.strip() and p.strip() != "void"]
+        want = "".join(code(p) for p in params)
+        assert sig == want, f"{name}: hip.py binds {sig!r} ({len(sig)} arguments), vis_hip.h declares {want!r} ({len(want)})"
+
+
 def test_launchers_reject_bad_arguments_without_gpu(lib_path):
     """Argument validation happens before any HIP call, so it is testable without a device."""
     from vision_inspection_system_amd import hip

@@ -70,6 +70,8 @@ def batch_block(engine, frame, n_patches, n_img_tok, B, new, prompt_tokens, step
     P = engine.shared_prefix_len([ids] * B) if (B > 1 and os.environ.get("VIS_SHARE_PREFIX", "1") != "0") else 0
     flops_ex = bn.prefill_flops_executed(cfg, n_patches, S, P, B) * B
     peak_tf = bn.MFMA_BF16_PEAK_TF * (2 if engine.prefill_dtype == "fp8" else 1)
+    traffic, traffic_src = (bn.measured_traffic("decode_stream", True) if (B == 64 and not fp8) else
+                            bn.measured_traffic("decode_stream_fp8", True) if (B == 4 and fp8) else (None, None))
     return {
         "images_per_s": B / wall, "ms_per_step": wall * 1e3, "batch": B, "steps": steps, "prompt_tokens": S,
         "new_tokens": new, "prompt_pass_ms_per_image": t_pre * 1e3 / B, "decode_ms_per_step": t_dec * 1e3 / (new - 1),
@@ -82,12 +84,12 @@ def batch_block(engine, frame, n_patches, n_img_tok, B, new, prompt_tokens, step
                                  "(vision tower + suffix rows + the prefix once per batch)"
                                  + ("; LLM + ViT projections on the fp8 MFMA, attention bf16: priced against the fp8 dense peak"
                                     if engine.prefill_dtype == "fp8" else "")},
-        "roofline": {"bound": "hbm", "kernel": "gemm_decode_stream_kernel" + ("<fp8>" if fp8 else ""),
+        "roofline": {"bound": "hbm", "kernel": ("decode_proj_kernel" if engine.fused_proj else "gemm_decode_stream_kernel")
+                     + ("<fp8>" if fp8 else ""),
                      "achieved": bpl / k_avg / 1e9, "peak": bn.HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": bpl / k_avg / 1e9 / bn.HBM_PEAK_GBS,
                      # PMC passes exist for the bf16 kernel at 64 rows and for the fp8 kernel at 4 rows (profiles/*_traffic.json)
-                     "traffic": bn.measured_traffic("decode_stream") if (B == 64 and not fp8) else
-                     (bn.measured_traffic("decode_stream_fp8") if (B == 4 and fp8) else None),
+                     "traffic": traffic, "traffic_source": traffic_src,
                      "bytes_per_launch": bpl, "avg_launch_us": k_avg * 1e6, "launches_per_step": k_launches},
         "dtype": ("fp8-e4m3 prompt-pass projections / " if engine.prefill_dtype == "fp8" else "bf16 prompt pass / ")
         + ("fp8-e4m3 decode weights" if engine.decode_weights == "fp8" else "bf16 decode weights"),

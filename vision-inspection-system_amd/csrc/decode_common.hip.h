@@ -235,12 +235,13 @@ __device__ __forceinline__ void gv_stage_row(const bf16_t* __restrict__ x, const
 // price list: "handoff" rows / granules).  A first version of the chain used counters (sc1 payload -> s_waitcnt vmcnt(0)
 // -> barrier -> agent-scope atomic add; consumer: poll -> barrier -> sc1 loads): ~6 us per hop, 30.5 us for the whole
 // head against 27.5 us for the four launches it replaced.  Every poll loop is bounded: GV_CHAIN_SPIN_MAX polls of one
-// `sc1` load round trip + s_sleep each (measured period with the whole grid polling: tools/probes/poll_period.py, DESIGN
-// section 4 - a bound of the order of 10 ms, three orders of magnitude above the ~10 us a hand-off takes when the grid is
-// resident), and every 32nd poll also looks at the sync block's status word: once ANY wait of the launch has given up, every
-// other wait of that launch - and, through the entry check of decode_chain_kernel, every later launch of the request - ends
-// at once instead of spinning through its own bound (a stranded request cost minutes, now one bound).
-#define GV_CHAIN_SPIN_MAX (1 << 13)
+// `sc1` load round trip + s_sleep each.  Measured with the whole 860-workgroup grid polling granules that never arrive
+// (tools/probes/poll_period.hip, profiles/r05_chain_poll_period.txt): 0.27 us per poll, i.e. 32 768 polls = ~9 ms - three
+// orders of magnitude above the ~10 us a hand-off takes when the grid is resident.  Every 32nd poll also looks at the sync
+// block's status word: once ANY wait of the launch has given up, every other wait of that launch - and, through the entry
+// check of decode_chain_kernel, every later launch of the request - ends at once instead of spinning through its own bound
+// (a stranded request cost minutes; now one bound, ~9 ms, then ~22 us per remaining launch).
+#define GV_CHAIN_SPIN_MAX (1 << 15)
 typedef unsigned long long gran_t;
 
 __device__ __forceinline__ gran_t gr_ld(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -198,6 +198,16 @@ class Qwen2VLEngine:
             self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
             self.b_xn = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
+        # Batched decode, r05: every projection is ONE launch (vis_decode_proj_*: stream + split-K reduction + epilogue, the
+        # RMSNorm split into the producer's per-column and the consumer's per-row factor; csrc/decode_stream.hip).
+        # VIS_DECODE_FUSED=0 keeps the r02-r04 pair of launches per projection (stream kernel + finalisation) for A/B.
+        self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "1") != "0"
+        if self.fused_proj:
+            self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)        # x * ln1_w of the next layer (A operand of qkv / lm_head)
+            self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)       # x2 * ln2_w (A operand of gate/up)
+            self.b_ssq1 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
+            self.b_ssq2 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
+        elif Bm > 1:
             self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
                                       device=dev)   # 16 stream-K slots x (16 or 32) rows
         self.decode_weights = decode_weights
@@ -229,6 +239,10 @@ class Qwen2VLEngine:
             self.b_x2q = torch.zeros((Bm, cfg.hidden), dtype=torch.uint8, device=dev)
             self.b_actq = torch.zeros((Bm, kp), dtype=torch.uint8, device=dev)       # pad columns stay 0
             self.b_sx = torch.zeros((3, Bm), dtype=torch.float32, device=dev)
+            if self.fused_proj:   # MX blocks: one E8M0 scale byte per row and 32 columns (pad blocks stay 0 = 2^-127 x code 0)
+                self.b_xqs = torch.zeros((Bm, cfg.hidden // 32), dtype=torch.uint8, device=dev)
+                self.b_x2qs = torch.zeros((Bm, cfg.hidden // 32), dtype=torch.uint8, device=dev)
+                self.b_actqs = torch.zeros((Bm, kp // 32), dtype=torch.uint8, device=dev)
         if prefill_dtype == "fp8" or self.fp8_batched:   # fp8 MFMA needs K % 128 == 0: zero-pad down's K if necessary
             self.kpad = _round_up(cfg.intermediate, 128)
             if self.kpad != cfg.intermediate:
@@ -239,6 +253,15 @@ class Qwen2VLEngine:
                     q["down_w_pad"] = (pad, sc)
             if prefill_dtype == "fp8" and (cfg.hidden % 128 or (cfg.heads * cfg.head_dim) % 128):
                 raise ValueError("fp8 prefill needs hidden and heads*head_dim to be multiples of 128")
+        if self.fused_proj:
+            fp8b = self.fp8_batched
+            kd = self.kpad if fp8b else cfg.intermediate
+            shapes = [(nq, H, fp8b), (H, Hq * D, False), (2 * cfg.intermediate, H, fp8b), (H, kd, fp8b), (cfg.vocab, H, fp8b)]
+            lib = hip.load()
+            need = max(int(lib.vis_decode_proj_ws_bytes(Bm, n, k, 1 if f8 else 0)) for n, k, f8 in shapes)
+            if need <= 0:
+                raise ValueError("vis_decode_proj_ws_bytes refused a projection shape of this model")
+            self.b_proj_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
         self.vq8: List[dict] = []
         if prefill_dtype == "fp8" and cfg.v_mlp % 128 == 0 and os.environ.get("VIS_VIT_FP8", "1") == "1":
             # ViT block projections in e4m3 too (VIS_VIT_FP8=0 keeps the tower in bf16).  With only the 256x256 fp8 tile
@@ -1056,6 +1079,8 @@ class Qwen2VLEngine:
         rows_max = int(os.environ.get("VIS_ROWS_GEMV", "0"))
         if 2 <= B <= min(rows_max, 4) and max(self.cfg.intermediate, self.cfg.hidden) * 2 * (2 if B <= 2 else 4) <= 152 * 1024:
             return self._decode_step_rows(B)
+        if self.fused_proj:
+            return self._decode_step_fused(B)
         if self.decode_weights == "fp8" and self.fp8_batched:
             return self._decode_step_batched_fp8(B)
         cfg, w = self.cfg, self.w
@@ -1083,6 +1108,59 @@ class Qwen2VLEngine:
         hip.decode_gemm(xn, w.lm_head, out=self.logits_b[:B])
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
+
+    def _decode_step_fused(self, B: int, projections_only: bool = False) -> int:
+        """One decode step for B in-flight sequences, every projection ONE launch (r05, csrc/decode_stream.hip): the stream-K
+        weight pass, the fixed-order sum of a cut tile's segments by the last workgroup to arrive, and the epilogue - bias (qkv),
+        SwiGLU (gate/up), residual + the NEXT norm's weight + the tile's sum of squares (o, down); the consumer of a normed row
+        applies rs[b] = rsqrt(mean(x^2) + eps) to its finished sums (the RMSNorm, TF modeling_qwen2_vl.py:96-110, split into a
+        per-column and a per-row factor).  5 launches per layer (r04: 9).  fp8 (configs[4]): activations travel as MX blocks
+        written by the producing epilogue.  ``projections_only``: bench.py's replay of the weight-streaming launches alone.
+        Returns the number of projection launches."""
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
+        scale, eps = D ** -0.5, cfg.rms_eps
+        x, x2, qkv, att, act = self.b_x[:B], self.b_x2[:B], self.b_qkv[:B], self.b_attn[:B], self.b_act[:B]
+        xw, x2w, s1, s2, ws = self.b_xw[:B], self.b_x2w[:B], self.b_ssq1, self.b_ssq2, self.b_proj_ws
+        fp8 = self.decode_weights == "fp8" and self.fp8_batched
+        if fp8:
+            xq, xqs, x2q, x2qs = self.b_xq[:B], self.b_xqs[:B], self.b_x2q[:B], self.b_x2qs[:B]
+            aq, aqs = self.b_actq[:B], self.b_actqs[:B]
+        if not projections_only:
+            hip.decode_prep_rows(w.embed, self.cur_b[:B], w.llm[0].ln1_w, x, None if fp8 else xw, s1,
+                                 xq if fp8 else None, xqs if fp8 else None)
+        n_layers = len(w.llm)
+        for li, lw in enumerate(w.llm):
+            next_norm = w.llm[li + 1].ln1_w if li + 1 < n_layers else w.final_norm_w
+            if fp8:
+                q8 = self.q8[li]
+                hip.decode_proj_fp8(xq, xqs, *q8["qkv_w"], ws, hip.DP_PLAIN, out=qkv, bias=lw.qkv_b, ssq_in=s1, norm_dim=H, eps=eps)
+            else:
+                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=qkv, bias=lw.qkv_b, ssq_in=s1, norm_dim=H, eps=eps)
+            if not projections_only:
+                hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                                self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                                shared_len=self.batch_shared_len)
+            if fp8:     # the o projection keeps bf16 weights (its input comes from the attention kernel); its epilogue writes MX
+                hip.decode_proj(att, lw.o_w, ws, hip.DP_RESID_NORMW, out=x2, out_q=x2q, out_qs=x2qs, residual=x,
+                                norm_w=lw.ln2_w, ssq_out=s2)
+                hip.decode_proj_fp8(x2q, x2qs, *q8["gateup_w"], ws, hip.DP_SWIGLU, out_q=aq, out_qs=aqs, ssq_in=s2,
+                                    norm_dim=H, eps=eps)
+                hip.decode_proj_fp8(aq, aqs, *q8.get("down_w_pad", q8["down_w"]), ws, hip.DP_RESID_NORMW, out=x, out_q=xq,
+                                    out_qs=xqs, residual=x2, norm_w=next_norm, ssq_out=s1)
+            else:
+                hip.decode_proj(att, lw.o_w, ws, hip.DP_RESID_NORMW, out=x2, out_w=x2w, residual=x, norm_w=lw.ln2_w, ssq_out=s2)
+                hip.decode_proj(x2w, lw.gateup_w, ws, hip.DP_SWIGLU, out=act, ssq_in=s2, norm_dim=H, eps=eps)
+                hip.decode_proj(act, lw.down_w, ws, hip.DP_RESID_NORMW, out=x, out_w=xw, residual=x2, norm_w=next_norm,
+                                ssq_out=s1)
+        if fp8:
+            hip.decode_proj_fp8(xq, xqs, *self.q8_lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1, norm_dim=H, eps=eps)
+        else:
+            hip.decode_proj(xw, w.lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1, norm_dim=H, eps=eps)
+        if not projections_only:
+            hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
+                       self.temperature, self.seed)
+        return 4 * n_layers + 1
 
     def _decode_step_rows(self, B: int) -> None:
         """A couple of in-flight sequences: the single-sequence step with the multi-row GEMV (vis_gemv_*_rows) - one pass

@@ -53,6 +53,10 @@ _SIGS = {
     "vis_gemm_decode_fp8": "pppppp" + "iiiiiiii" + "p",
     "vis_skinny_finalize_fp8": "p" + "i" + "ppppp" + "pppp" + "iiiiiii" + "f" + "p",
     "vis_skinny_finalize": "p" + "i" + "ppppp" + "iiiiii" + "f" + "p",
+    "vis_decode_proj_ws_bytes": "iiii",
+    "vis_decode_proj_bf16": "p" * 12 + "i" * 13 + "f" + "p",
+    "vis_decode_proj_fp8": "p" * 14 + "i" * 14 + "f" + "p",
+    "vis_decode_prep_rows": "p" * 8 + "i" * 6 + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_resize_rgb_u8": "ppp" + "iiii" + "ppi" + "ppi" + "p",
     "vis_jpeg_to_rgb": "pppp" + "i" * 11 + "p",
@@ -131,6 +135,7 @@ def load() -> ctypes.CDLL:
         fn.restype = ctypes.c_int
         fn.argtypes = [_CT[c] for c in sig]
     lib.vis_decode_chain_ws_bytes.restype = ctypes.c_longlong
+    lib.vis_decode_proj_ws_bytes.restype = ctypes.c_longlong
     _lib = lib
     return lib
 
@@ -809,6 +814,123 @@ def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tok
                                _ptr(cur_token), _ptr(step), (1.0 / temperature) if temperature > 0 else 0.0,
                                seed & 0xFFFFFFFF, B, logits.stride(0) if logits.dim() == 2 else V, _stream())
     _check(rc, "vis_argmax_f32")
+
+
+DP_PLAIN, DP_SWIGLU, DP_RESID_NORMW = 0, 1, 2
+SSQ_LD = 64      # row stride of the [tiles][64] f32 sum-of-squares partials (csrc/decode_stream.hip: DS_SSQ_LD)
+
+
+def decode_proj_ws(device, B: int, N: int, K: int, fp8: bool = False) -> torch.Tensor:
+    """Zeroed workspace of decode_proj / decode_proj_fp8 for (B, N, K): arrival counters + the segment blocks of split tiles.
+    Allocate for the largest (B, N, K) it will serve; one launch at a time per workspace."""
+    n = int(load().vis_decode_proj_ws_bytes(B, N, K, 1 if fp8 else 0))
+    if n <= 0:
+        raise HipLibraryError(f"decode_proj_ws: unsupported shape B={B} N={N} K={K} fp8={fp8}")
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def _dp_common(name, B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm_w, ssq_in, ssq_out, ws, need):
+    n_out = N // 2 if mode == DP_SWIGLU else N
+    for t, what in ((out, "out"), (out_w, "out_w")):
+        if t is not None and (t.dim() != 2 or t.shape[0] != B or t.shape[1] != n_out or t.stride(1) != 1):
+            raise HipLibraryError(f"{name}: bad {what} shape")
+    if out is not None and out.dtype not in (torch.bfloat16, torch.float32):
+        raise HipLibraryError(f"{name}: out must be bf16 or f32")
+    if out_w is not None and (out is None or out_w.dtype != torch.bfloat16 or out_w.stride(0) != out.stride(0)):
+        raise HipLibraryError(f"{name}: out_w needs out and its row stride")
+    if (out_q is None) != (out_qs is None) or (out_q is not None and (
+            out_q.dtype != torch.uint8 or out_qs.dtype != torch.uint8 or out_q.shape[0] != B or out_q.shape[1] < n_out
+            or out_qs.shape[0] != B or out_qs.shape[1] * 32 < n_out or out_q.stride(1) != 1 or out_qs.stride(1) != 1)):
+        raise HipLibraryError(f"{name}: bad MX outputs")
+    if residual is not None and (residual.dtype != torch.bfloat16 or residual.shape != (B, N) or residual.stride(1) != 1):
+        raise HipLibraryError(f"{name}: bad residual")
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.numel() != N):
+        raise HipLibraryError(f"{name}: bad bias")
+    if norm_w is not None and (norm_w.dtype != torch.bfloat16 or norm_w.numel() != N):
+        raise HipLibraryError(f"{name}: bad norm_w")
+    for t, tiles in ((ssq_in, None), (ssq_out, (N + 127) // 128)):
+        if t is not None and (t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != SSQ_LD or not t.is_contiguous()
+                              or (tiles is not None and t.shape[0] < tiles)):
+            raise HipLibraryError(f"{name}: ssq buffers are f32 [tiles, {SSQ_LD}]")
+    if ws.dtype != torch.uint8 or ws.numel() < need:
+        raise HipLibraryError(f"{name}: workspace too small ({ws.numel()} < {need})")
+
+
+def decode_proj(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, mode: int = DP_PLAIN,
+                out: Optional[torch.Tensor] = None, out_w: Optional[torch.Tensor] = None,
+                out_q: Optional[torch.Tensor] = None, out_qs: Optional[torch.Tensor] = None,
+                bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                norm_w: Optional[torch.Tensor] = None, ssq_in: Optional[torch.Tensor] = None,
+                ssq_out: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6) -> None:
+    """Batched-decode projection with its epilogue in the same launch (vis_decode_proj_bf16; include/vis_hip.h): x [B, K] bf16,
+    w [N, K] bf16.  DP_PLAIN: out = x w^T * rs + bias (bf16 / f32).  DP_SWIGLU: out [B, N/2].  DP_RESID_NORMW: out = y =
+    x w^T + residual, out_w = y * norm_w, ssq_out = per-tile sums of y^2.  rs from ssq_in (norm_dim columns) or 1."""
+    _bf16(x, "decode_proj x"); _bf16(w, "decode_proj w")
+    B, K = x.shape
+    N = w.shape[0]
+    if w.shape[1] != K or x.stride(1) != 1 or w.stride(1) != 1:
+        raise HipLibraryError("decode_proj: bad operand shapes")
+    lib = load()
+    _dp_common("decode_proj", B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm_w, ssq_in, ssq_out, ws,
+               int(lib.vis_decode_proj_ws_bytes(B, N, K, 0)))
+    ldc = out.stride(0) if out is not None else 0
+    rc = lib.vis_decode_proj_bf16(_ptr(x), _ptr(w), _ptr(ws), _ptr(out), _ptr(out_w), _ptr(out_q), _ptr(out_qs), _ptr(bias),
+                                  _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), B, N, K, x.stride(0), w.stride(0),
+                                  ldc, residual.stride(0) if residual is not None else 0,
+                                  out_q.stride(0) if out_q is not None else 0, out_qs.stride(0) if out_qs is not None else 0,
+                                  mode, 1 if (out is not None and out.dtype == torch.float32) else 0,
+                                  ssq_in.shape[0] if ssq_in is not None else 0, norm_dim, eps, _stream())
+    _check(rc, "vis_decode_proj_bf16")
+
+
+def decode_proj_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, sw: torch.Tensor, ws: torch.Tensor,
+                    mode: int = DP_PLAIN, out: Optional[torch.Tensor] = None, out_w: Optional[torch.Tensor] = None,
+                    out_q: Optional[torch.Tensor] = None, out_qs: Optional[torch.Tensor] = None,
+                    bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                    norm_w: Optional[torch.Tensor] = None, ssq_in: Optional[torch.Tensor] = None,
+                    ssq_out: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6) -> None:
+    """fp8 form: xq [B, K] e4m3 bytes + xs [B, >= K/32] E8M0 block scales (MX blocks of 32 columns), wq [N, K] e4m3 + sw [N] f32."""
+    B, K = xq.shape
+    N = wq.shape[0]
+    if xq.dtype != torch.uint8 or wq.dtype != torch.uint8 or xs.dtype != torch.uint8 or wq.shape[1] != K \
+            or xq.stride(1) != 1 or wq.stride(1) != 1 or xs.stride(1) != 1 or xs.shape[0] != B or xs.shape[1] * 32 < K \
+            or sw.dtype != torch.float32 or sw.numel() != N:
+        raise HipLibraryError("decode_proj_fp8: bad operands")
+    lib = load()
+    _dp_common("decode_proj_fp8", B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm_w, ssq_in, ssq_out, ws,
+               int(lib.vis_decode_proj_ws_bytes(B, N, K, 1)))
+    ldc = out.stride(0) if out is not None else 0
+    rc = lib.vis_decode_proj_fp8(_ptr(xq), _ptr(xs), _ptr(wq), _ptr(sw), _ptr(ws), _ptr(out), _ptr(out_w), _ptr(out_q),
+                                 _ptr(out_qs), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), B, N, K,
+                                 xq.stride(0), xs.stride(0), wq.stride(0), ldc,
+                                 residual.stride(0) if residual is not None else 0,
+                                 out_q.stride(0) if out_q is not None else 0, out_qs.stride(0) if out_qs is not None else 0,
+                                 mode, 1 if (out is not None and out.dtype == torch.float32) else 0,
+                                 ssq_in.shape[0] if ssq_in is not None else 0, norm_dim, eps, _stream())
+    _check(rc, "vis_decode_proj_fp8")
+
+
+def decode_prep_rows(table: torch.Tensor, ids: torch.Tensor, norm_w: torch.Tensor, x: torch.Tensor,
+                     xw: Optional[torch.Tensor], ssq: torch.Tensor, xq: Optional[torch.Tensor] = None,
+                     xqs: Optional[torch.Tensor] = None) -> None:
+    """Head of a batched decode step: x[b] = table[ids[b]], xw = x * norm_w (bf16), ssq = per-tile sums of x^2, optionally
+    the MX copy of xw - what the first decode_proj of the step consumes."""
+    _bf16(table, "decode_prep_rows table"); _bf16(x, "decode_prep_rows x"); _bf16(norm_w, "decode_prep_rows norm_w")
+    B, H = x.shape
+    if table.dim() != 2 or table.shape[1] != H or not table.is_contiguous() or ids.dtype != torch.int32 or ids.numel() != B \
+            or x.stride(1) != 1 or norm_w.numel() != H or (xw is not None and (xw.shape != x.shape or xw.stride() != x.stride()
+                                                                                 or xw.dtype != torch.bfloat16)) \
+            or ssq.dtype != torch.float32 or ssq.dim() != 2 or ssq.shape[1] != SSQ_LD or ssq.shape[0] * 128 < H \
+            or not ssq.is_contiguous():
+        raise HipLibraryError("decode_prep_rows: bad shapes")
+    if (xq is None) != (xqs is None) or (xq is not None and (xq.dtype != torch.uint8 or xqs.dtype != torch.uint8
+                                                             or xq.shape[0] != B or xq.shape[1] < H or xqs.shape[0] != B
+                                                             or xqs.shape[1] * 32 < H)):
+        raise HipLibraryError("decode_prep_rows: bad MX outputs")
+    rc = load().vis_decode_prep_rows(_ptr(table), _ptr(ids), _ptr(norm_w), _ptr(x), _ptr(xw), _ptr(xq), _ptr(xqs), _ptr(ssq),
+                                     B, table.shape[0], H, x.stride(0), xq.stride(0) if xq is not None else 0,
+                                     xqs.stride(0) if xqs is not None else 0, _stream())
+    _check(rc, "vis_decode_prep_rows")
 
 
 def part_rows(B: int) -> int:

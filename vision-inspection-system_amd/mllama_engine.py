@@ -148,6 +148,21 @@ class MllamaEngine:
             self.b_qkv = torch.empty((Bm, nq), dtype=bf, device=dev)
             self.b_attn = torch.empty((Bm, Hq * D), dtype=bf, device=dev)
             self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
+        # r05: every batched-decode projection is ONE launch (vis_decode_proj_bf16: stream + split-K reduction + epilogue;
+        # Qwen2VLEngine._decode_step_fused).  VIS_DECODE_FUSED=0 keeps the r02-r04 pair of launches per projection (A/B).
+        self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "1") != "0"
+        if self.fused_proj:
+            self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)
+            self.b_ssq1 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
+            self.b_ssq2 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
+            lib = hip.load()
+            need = max(int(lib.vis_decode_proj_ws_bytes(Bm, n, k, 0)) for n, k in
+                       ((nq, H), (H, Hq * D), (2 * cfg.intermediate, H), (H, cfg.intermediate), (cfg.vocab, H)))
+            if need <= 0:
+                raise ValueError("vis_decode_proj_ws_bytes refused a projection shape of this model")
+            self.b_proj_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
+        elif Bm > 1:
             self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
                                       device=dev)
         self.slot_prompt_len = [0] * Bm
@@ -620,6 +635,8 @@ class MllamaEngine:
         """Every projection = gemm_decode (weights streamed once for all B sequences, stream-K f32 partials) +
         skinny_finalize (row-wise: sum, residual / SwiGLU, and the RMSNorm of the NEXT projection); self-attention and
         cross-attention take the sequence index on the grid."""
+        if self.fused_proj:
+            return self._decode_step_fused(B)
         cfg, w = self.cfg, self.w
         Hq, Hkv, D, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
         scale, eps = D ** -0.5, cfg.rms_eps
@@ -654,6 +671,42 @@ class MllamaEngine:
             next_norm = w.layers[li + 1].ln1_w if li + 1 < n_layers else w.norm_w
             hip.skinny_finalize(part, ks, x, H, residual=x2, norm_w=next_norm, yn=xn, eps=eps)
         hip.decode_gemm(xn, w.lm_head, out=self.logits_b[:B])
+        hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
+                   self.temperature, self.seed)
+
+    def _decode_step_fused(self, B: int) -> None:
+        """The batched step with every projection as ONE launch (r05, csrc/decode_stream.hip; see Qwen2VLEngine._decode_step_fused):
+        q / qkv (plain, rs of the input norm), o (+ residual, x ln2_w, sums of squares), gate/up (SwiGLU, rs), down (+ residual,
+        x the next ln1_w, sums of squares); 5 launches per layer instead of 9.  The tanh gates of the cross-attention layers are
+        folded into o_w / down_w at load time, so both layer kinds share the sequence."""
+        cfg, w = self.cfg, self.w
+        Hq, Hkv, D, H = cfg.heads, cfg.kv_heads, cfg.head_dim, cfg.hidden
+        scale, eps = D ** -0.5, cfg.rms_eps
+        x, x2, xw, x2w = self.b_x[:B], self.b_x2[:B], self.b_xw[:B], self.b_x2w[:B]
+        qkv, att, act = self.b_qkv[:B], self.b_attn[:B], self.b_act[:B]
+        s1, s2, ws = self.b_ssq1, self.b_ssq2, self.b_proj_ws
+        cosb = self.cos_t.unsqueeze(0).expand(B, -1, -1)          # batch stride 0: the rope table is shared
+        sinb = self.sin_t.unsqueeze(0).expand(B, -1, -1)
+        hip.decode_prep_rows(w.embed, self.cur_b[:B], w.layers[0].ln1_w, x, xw, s1)
+        n_layers = len(w.layers)
+        si = ci = 0
+        for li, lw in enumerate(w.layers):
+            if lw.cross:
+                q = qkv[:, :Hq * D]
+                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=q, ssq_in=s1, norm_dim=H, eps=eps)
+                hip.decode_cross_attn_batch(q, lw.q_norm, self.xk_b[:B, ci], self.xv_b[:B, ci], self.nkeys_b[:B],
+                                            self.part_o, self.part_ml, att, Hq, Hkv, D, self.xsplit, scale, eps)
+                ci += 1
+            else:
+                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=qkv, ssq_in=s1, norm_dim=H, eps=eps)
+                hip.decode_attn(qkv, cosb, sinb, self.kcache_b[:B, si], self.vcache_b[:B, si], self.step_b[:B],
+                                self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                si += 1
+            hip.decode_proj(att, lw.o_w, ws, hip.DP_RESID_NORMW, out=x2, out_w=x2w, residual=x, norm_w=lw.ln2_w, ssq_out=s2)
+            hip.decode_proj(x2w, lw.gateup_w, ws, hip.DP_SWIGLU, out=act, ssq_in=s2, norm_dim=H, eps=eps)
+            next_norm = w.layers[li + 1].ln1_w if li + 1 < n_layers else w.norm_w
+            hip.decode_proj(act, lw.down_w, ws, hip.DP_RESID_NORMW, out=x, out_w=xw, residual=x2, norm_w=next_norm, ssq_out=s1)
+        hip.decode_proj(xw, w.lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1, norm_dim=H, eps=eps)
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
 
