@@ -148,15 +148,20 @@ int vis_decode_attn_shared(const void* qkv, const void* cos_t, const void* sin_t
  * before sync[0] gets near 2^32.  The packed projection row and the merged
  * attention row live in ws as granules (low 32 bits = two bf16): ws[0 .. (Hq + 2 Hkv) * 64) and the next Hq * 64 words.
  * VIS_ERR_UNSUPPORTED for shapes outside the chained form (HD != 128, Hq / Hkv not in {1, 2, 4, 7, 8}, K or Hq * 128 > 4096,
- * Hq > 64, a grid above what the device holds resident minus a margin of 32 workgroups): the caller then issues the four
- * launches.  VIS_ERR_ARG is a caller bug.  ONE chained launch at a time per device: its workgroups wait
+ * Hq > 64, or more WAITING workgroups - the projection and merge roles plus Hkv attention items per 64 keys of ctx_bound -
+ * than the device holds resident minus a margin of 32): the caller then issues the four launches.  ctx_bound: the largest
+ * context (cached keys incl. the new one) any launch with these arguments will see (a captured launch is replayed at growing
+ * positions), <= 0 = cache_tokens; attention items of splits past the context return at once and need no residency.
+ * VIS_ERR_ARG is a caller bug.  ONE chained launch at a time per device: its workgroups wait
  * for each other inside the grid, so launches from two streams at once must be ordered by the caller (an event). */
 int vis_decode_chain_sync_ints(void);
 long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit);
+/* largest ctx_bound vis_decode_chain accepts for (Hq, Hkv, head_dim 128, hidden K) on the current device; 0 = shape not covered */
+int vis_decode_chain_ctx_limit(int Hq, int Hkv, int K);
 int vis_decode_chain(const void* x, const void* x_idx, int x_rows, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
-                     const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr, void* ws,
-                     void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o, int cache_tokens, int nsplit,
-                     float scale, float eps, vis_stream_t stream);
+                     const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr,
+                     void* ws, void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o,
+                     int cache_tokens, int nsplit, int ctx_bound, float scale, float eps, vis_stream_t stream);
 
 /* K10 + K12  lm_head of the single-sequence step with the pick's first stage in its epilogue, then the merging launch:
  * logits[N] f32 = W rmsnorm(x); tokens[*step] = cur_token = pick; *step += 1 - the pick vis_gemv_bf16 + vis_argmax_f32 make

@@ -168,3 +168,47 @@ def test_7b_full_depth_fp8_vs_bf16(device, family):
             assert int(a.argmax()) == int(b.argmax()), f"{name}: greedy pick differs off a near-tie"
     del e16, e8
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("depth", [4, 8])
+def test_mllama_11b_shapes_depth_vs_oracle(device, depth):
+    """The Auditor's logit tolerance at depth (the call /root/reference/src/agents/vlm_auditor.py:152-158
+    becomes): Llama-3.2-11B-Vision shapes, `depth` vision layers (the last quarter global / gated, intermediate features
+    concatenated as in the released model) over the 2 x 2-tile canvas of a 1024^2 image, projector, `depth` decoder layers of
+    which index 3 is a cross-attention layer (the released model's first: cross_attention_layers = [3, 8, ...]), the 128 256-row
+    lm_head; bf16 engine against the fp32 oracle (oracle/mllama_ref.py, pinned to transformers by tests/test_oracle_mllama.py):
+    cross states, the last layer's hidden state, first-step logits and three teacher-forced decode steps on the KV cache and the
+    cached cross keys.  Same stated bounds as the Inspector's rows of the table in DESIGN section 2."""
+    from oracle import mllama_ref as R
+    from test_oracle_mllama import ref_cfg
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    from vision_inspection_system_amd.mllama_weights import MllamaConfig, pack_device_weights, synth_state_dict
+    n_glob = depth // 4
+    n_loc = depth - n_glob
+    cfg = dataclasses.replace(MllamaConfig.mllama_11b(), layers=depth, cross_layers=(3,), v_layers=n_loc,
+                              v_global_layers=n_glob, v_inter=tuple(range(1, n_loc, 2)))
+    sd = synth_state_dict(cfg, seed=6, rng="torch", device=device)
+    eng = MllamaEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=1024)
+    rng = np.random.default_rng(3)
+    image = rng.integers(0, 256, (1024, 1024, 3), dtype=np.uint8)
+    ids = [1] + rng.integers(1000, cfg.vocab - 8, 600).tolist() + [cfg.image_token_id] + \
+        rng.integers(1000, cfg.vocab - 8, 102).tolist()                      # 704 tokens, image token after the text
+    taps, rtaps = {}, {}
+    eng.prefill(ids, torch.from_numpy(image).to(device), taps=taps)
+    with torch.no_grad():
+        ref_toks, ref_logits = R.generate(ref_cfg(cfg), sd, ids, image, 4, taps=rtaps)
+    mx, mean = BF16_TOL[depth]
+    tag = f"mllama depth {depth} bf16"
+    _stat(tag, f"vision tower ({n_loc} local + {n_glob} global layers) + projector -> cross states", taps["cross_states"],
+          rtaps["cross_states"], mx, mean)
+    _stat(tag, f"hidden state after decoder layer {depth - 1} (layer 3 = cross-attention), S = 704", taps[f"layer{depth - 1}"],
+          rtaps[f"layer{depth - 1}"], mx, mean)
+    err = _stat(tag, "first-step logits [128256]", taps["first_logits"], ref_logits[0], mx, mean)
+    _pick_ok("first token", taps["first_logits"], ref_logits[0], err)
+    for t in range(3):
+        eng.cur_token.fill_(ref_toks[t])
+        eng.decode(1, use_graph=False)
+        err = _stat(tag, f"decode step {t + 1} logits", eng.logits, ref_logits[t + 1], mx, mean)
+        _pick_ok(f"decode step {t + 1}", eng.logits, ref_logits[t + 1], err)
+    del eng
+    torch.cuda.empty_cache()

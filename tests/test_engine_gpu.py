@@ -512,6 +512,29 @@ def test_prefix_cache_across_requests_is_bit_identical(device, monkeypatch):
     assert eng.generate(pa, fa, max_new_tokens=8, ignore_eos=True) == full_a and len(eng._prefix_cache) == 0
 
 
+def test_chain_context_limit_is_crossed_mid_request(device):
+    """The chained layer head runs while the context fits what the device holds resident for the head shape
+    (hip.decode_chain_ctx_limit - waiting workgroups only, independent of VIS_MAX_CTX) and the four launches take over beyond:
+    a request that crosses the limit in the middle of its decode loop gives the same tokens and logits as one that never
+    chains and one that always does."""
+    from vision_inspection_system_amd.config import Qwen2VLConfig
+    from vision_inspection_system_amd.engine import Qwen2VLEngine
+    from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    cfg = Qwen2VLConfig.tiny()
+    w = pack_device_weights(cfg, synth_state_dict(cfg, seed=0), device)
+    g = load_golden()
+    ids, frames = g["ids_a"].tolist(), [torch.from_numpy(g["frame_a"]).to(device)]
+    eng = Qwen2VLEngine(cfg, w, device, max_ctx=256)
+    assert eng.chain_sync is not None and eng.chain_ctx_limit >= 256
+    ref = eng.generate(ids, frames, max_new_tokens=14, ignore_eos=True)
+    ref_logits = eng.logits.clone()
+    for limit in (0, len(ids) + 1, len(ids) + 5):
+        eng.chain_ctx_limit = limit
+        for use_graph in (False, True):
+            assert eng.generate(ids, frames, max_new_tokens=14, ignore_eos=True, use_graph=use_graph) == ref, (limit, use_graph)
+            assert torch.equal(eng.logits, ref_logits)
+
+
 def test_stalled_chained_launch_is_re_served_on_the_unchained_step(device, monkeypatch):
     """A chained layer-head launch whose in-grid wait gave up (another process running chained launches on the same GPU) raises
     the status word; the engine must notice it at the end of the request, serve the request again on the four-launch step -

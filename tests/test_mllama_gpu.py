@@ -108,6 +108,41 @@ def test_graph_replay_equals_eager_and_text_only(setup, device):
         eng.prefill(ids, None)                        # image token without a frame
 
 
+def test_chained_self_layers_equal_separate_launches(setup, device, monkeypatch):
+    """The Auditor's single-sequence decode with the head of every SELF-attention layer as one chained launch + the lm_head with
+    the pick in its epilogue (vis_decode_chain, vis_gemv_bf16_argmax) against the separate launches
+    (VIS_DECODE_CHAIN=0): tokens and last-step logits bit for bit, eager and from the graph; and a context limit that is crossed
+    in the middle of a request - the engine switches to the separate launches there - changes nothing."""
+    from vision_inspection_system_amd import hip
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    cfg, rc, sd, eng, g = setup
+    assert eng.chain_sync is not None and eng.chain_ctx_limit > 0, "the chained layer head must be the default for the Auditor"
+    monkeypatch.setenv("VIS_DECODE_CHAIN", "0")
+    plain = MllamaEngine(cfg, eng.w, device, max_ctx=256)
+    assert plain.chain_sync is None
+    for case in "ab":
+        ids = g[f"{case}_ids"].tolist()
+        frame = torch.from_numpy(g[f"{case}_image"]).to(device)
+        ref = plain.generate(ids, frame, max_new_tokens=14, stop_on_eos=False, use_graph=False)
+        ref_logits = plain.logits.clone()
+        before = int(eng.chain_sync[0])
+        for use_graph in (False, True):
+            assert eng.generate(ids, frame, max_new_tokens=14, stop_on_eos=False, use_graph=use_graph) == ref
+            assert torch.equal(eng.logits, ref_logits)
+            assert int(eng.chain_sync[hip.CHAIN_STATUS_WORD]) == 0
+        assert int(eng.chain_sync[0]) > before, "no chained launch ran"
+        saved = eng.chain_ctx_limit
+        eng.chain_ctx_limit = len(ids) + 6            # steps 1..6 chained, 7..13 on the separate launches
+        try:
+            assert eng.generate(ids, frame, max_new_tokens=14, stop_on_eos=False, use_graph=True) == ref
+            assert torch.equal(eng.logits, ref_logits)
+        finally:
+            eng.chain_ctx_limit = saved
+    # text-only prompts skip the cross layers; the chained self layers serve them as well
+    tids = [1, 5, 6, 40, 41, 42, 7, 8]
+    assert eng.generate(tids, None, max_new_tokens=8, stop_on_eos=False) == plain.generate(tids, None, max_new_tokens=8, stop_on_eos=False)
+
+
 def test_batched_decode_matches_single_and_is_batch_invariant(device):
     """verify_many path: several images share ONE decode loop (stream-K batched projections, batched
     self- and cross-attention).  A request's tokens do not depend on its slot, on the batch size or on what shares the

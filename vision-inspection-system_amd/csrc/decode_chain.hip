@@ -364,10 +364,47 @@ extern "C" long long vis_decode_chain_ws_bytes(int Hq, int Hkv, int nsplit) {
 // Returns VIS_ERR_UNSUPPORTED (nothing launched; the caller then uses the four launches) for shapes the chained form does not
 // cover: head_dim != 128, a group size other than 1 / 2 / 4 / 7 / 8, K or Hq * 128 above 4096, more than 64 query heads, a grid
 // larger than the device holds resident.  VIS_ERR_ARG is a caller bug (null / misaligned pointers, inconsistent sizes).
+// ctx_bound: the caller's promise about the largest context (cached keys incl. the new one) any launch with these arguments
+// will see - a captured launch is replayed at growing positions - or <= 0 for cache_tokens.  Only the workgroups that WAIT
+// need to be resident together: the projection and merge roles and the attention items of splits the context reaches; an
+// item past the context returns at once, whenever it is placed, so the bound counts ceil(ctx_bound / 64) splits, not
+// nsplit.  (Llama-3.2-11B: 768 + 32 + 8 splits-per-64-keys leaves room for 1536 keys; with nsplit counted a 2048-row cache
+// was refused outright.)  vis_decode_chain_ctx_limit gives the largest bound the device holds.
+template <int G>
+static int chain_waiting_limit(int Hq, int Hkv, int K) {
+  const int Nqkv = (Hq + 2 * Hkv) * 128, Ko = Hq * 128;
+  const size_t lds = chain_lds_bytes<G>(K > Ko ? K : Ko);
+  if (lds > 64 * 1024) return 0;
+  const int resident = chain_resident_blocks<G>(lds);
+  const int fixed = Nqkv / 8 + Hq;
+  return resident > fixed ? (resident - fixed) / Hkv : 0;       // attention splits that may be active
+}
+
+static int chain_split_limit(int Hq, int Hkv, int K) {
+  if (Hq <= 0 || Hkv <= 0 || Hq > 64 || Hkv > 16 || Hq % Hkv != 0 || K <= 0 || K % 8 != 0 || K > 4096 || Hq * 128 > 4096) return 0;
+  if (K / 2 > (Hq + 2 * Hkv) * 128 / 8 * 4) return 0;
+  switch (Hq / Hkv) {
+    case 1: return chain_waiting_limit<1>(Hq, Hkv, K);
+    case 2: return chain_waiting_limit<2>(Hq, Hkv, K);
+    case 4: return chain_waiting_limit<4>(Hq, Hkv, K);
+    case 7: return chain_waiting_limit<7>(Hq, Hkv, K);
+    case 8: return chain_waiting_limit<8>(Hq, Hkv, K);
+    default: return 0;
+  }
+}
+
+// largest context (cached keys) for which vis_decode_chain accepts (Hq, Hkv, head_dim 128, hidden K) on the current device;
+// 0: the chained form does not cover the shape.  The engines run the chained launch while prompt + generated tokens stay
+// within it and the four launches beyond (same results bit for bit).
+extern "C" int vis_decode_chain_ctx_limit(int Hq, int Hkv, int K) {
+  const int splits = chain_split_limit(Hq, Hkv, K);
+  return splits > 0 ? splits * DA_MAXKEYS : 0;
+}
+
 extern "C" int vis_decode_chain(const void* x, const void* x_idx, int x_rows, const void* Wqkv, const void* bqkv, const void* norm_w, const void* Wo, void* y,
                                 const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr,
                                 void* ws, void* sync, int Hq, int Hkv, int HD, int K, int ldw_qkv, int ldw_o,
-                                int cache_tokens, int nsplit, float scale, float eps, hipStream_t stream) {
+                                int cache_tokens, int nsplit, int ctx_bound, float scale, float eps, hipStream_t stream) {
   if (!x || !Wqkv || !norm_w || !Wo || !y || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !ws || !sync)
     return VIS_ERR_ARG;
   if (Hq <= 0 || Hkv <= 0 || HD <= 0 || K <= 0) return VIS_ERR_ARG;
@@ -406,17 +443,17 @@ extern "C" int vis_decode_chain(const void* x, const void* x_idx, int x_rows, co
   if (No / 2 > p.n_gv * 4) return VIS_ERR_UNSUPPORTED; // every o row pair needs a wave
   const int grid = p.n_gv + p.n_att + Hq;
   size_t lds = 0;
-  int resident = 0;
-#define CHAIN_CASE(GG)                                        \
-  case GG: {                                                  \
-    lds = chain_lds_bytes<GG>(K > Ko ? K : Ko);              \
-    if (lds <= 64 * 1024) resident = chain_resident_blocks<GG>(lds); \
-  } break;
   switch (G) {
-    CHAIN_CASE(1) CHAIN_CASE(2) CHAIN_CASE(4) CHAIN_CASE(7) CHAIN_CASE(8)
+    case 1: lds = chain_lds_bytes<1>(K > Ko ? K : Ko); break;
+    case 2: lds = chain_lds_bytes<2>(K > Ko ? K : Ko); break;
+    case 4: lds = chain_lds_bytes<4>(K > Ko ? K : Ko); break;
+    case 7: lds = chain_lds_bytes<7>(K > Ko ? K : Ko); break;
+    default: lds = chain_lds_bytes<8>(K > Ko ? K : Ko); break;
   }
-#undef CHAIN_CASE
-  if (lds > 64 * 1024 || grid > resident) return VIS_ERR_UNSUPPORTED;
+  const int bound = (ctx_bound > 0 && ctx_bound < cache_tokens) ? ctx_bound : cache_tokens;
+  int active = (bound + DA_MAXKEYS - 1) / DA_MAXKEYS;
+  if (active > nsplit) active = nsplit;
+  if (lds > 64 * 1024 || active > chain_split_limit(Hq, Hkv, K)) return VIS_ERR_UNSUPPORTED;
   vis_clear_error();
   switch (G) {
     case 1: hipLaunchKernelGGL(decode_chain_kernel<1>, dim3(grid), dim3(256), lds, stream, p); break;

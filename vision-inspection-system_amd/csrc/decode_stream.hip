@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
   static_assert(5 * G::PER < 64, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char ring[];
   __shared__ int tick_s[NSEG];
+  __shared__ int segt_s[NSEG];
+  __shared__ float rs_s[64];
   __shared__ float red_s[4][MB * 16];
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
@@ -124,30 +126,10 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
   const int nsteps = min(s0 + p.spb, p.total) - s0;
   if (nsteps <= 0) return;  // whole workgroup
 
-  // ---- rs[row] of the deferred RMSNorm: requested before the ring so that only these loads are waited for
+  // rs[row] of the deferred RMSNorm: computed at the end of the range (finish_sets), behind the partial stores' drain
   float rs[MB];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) rs[mb] = 1.0f;
-  if (p.ssq_in) {
-    float acc_s[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) acc_s[mb] = 0.f;
-    for (int t0 = 0; t0 < p.tiles_in; t0 += 8) {
-      float v[8][MB];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) v[u][mb] = p.ssq_in[(size_t)min(t0 + u, p.tiles_in - 1) * DS_SSQ_LD + mb * 16 + l15];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (t0 + u < p.tiles_in) {
-#pragma unroll
-          for (int mb = 0; mb < MB; ++mb) acc_s[mb] += v[u][mb];
-        }
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) rs[mb] = rsqrtf(acc_s[mb] * p.inv_norm_dim + p.eps);
-  }
 
   // ---- staging: x tile 32 (MB = 4: 64) rows x 8 chunks (rows >= M repeat row M - 1), W tile 128 x 8 (4 per thread)
   uint32_t a_off[XI], w_off[4], s_off = 0;
@@ -208,7 +190,6 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
 
   int c_tile = s0 / p.nk_all, c_kt = s0 - c_tile * p.nk_all;  // consumer cursor
   const int pre = min(DEPTH - 1, nsteps);
-  if (p.ssq_in) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rs operands are in (nothing else is in flight yet)
   for (int s = 0; s < pre; ++s) stage(s);
   int slot = 0, fill = pre % DEPTH;  // slot consumed this step / slot refilled this step
   int st = 0;
@@ -223,9 +204,14 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
     }
     const char* base = ring + slot * STAGE_BYTES;
     if constexpr (FP8) {
-      // lane holds row l15, k = 32 h .. 32 h + 31: 16-byte chunks 2h and 2h+1 at their swizzled positions
+      // The instruction's K order (tools/probes/mfma_scale_probe.hip, profiles/r05_mfma_scale_map.txt): a lane's first four
+      // VGPRs are K elements 16 h .. 16 h + 15, its last four 64 + 16 h .. + 15, and the scale lane (l15, s) supplies governs
+      // K elements 32 s .. 32 s + 31.  With 16-byte chunks h and 4 + h of the row (as in the bf16 form) the instruction's K
+      // index IS the memory column, so MX block s of the K-step (columns 32 s ..) takes its scale from lane (l15, s).
+      // (Chunks 2h, 2h + 1 - the r02 kernels' choice, equally good with unit scales - put half of every memory block under
+      // another block's scale: first version of this kernel, caught by test_decode_proj_fp8_mx.)
       typedef int i32x8 __attribute__((ext_vector_type(8)));
-      const int qlo = l15 * 128 + (((2 * h) ^ sw7) << 4), qhi = l15 * 128 + (((2 * h + 1) ^ sw7) << 4);
+      const int qlo = rd0, qhi = rd1;
       auto frag8 = [&](const char* p0) -> i32x8 {
         const u32x4 lo = *(const u32x4*)(p0 + qlo), hi = *(const u32x4*)(p0 + qhi);
         return (i32x8){(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
@@ -501,20 +487,40 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
   // owns the tile or holds its last ticket.  The per-set part is ONE copy of the code working on a copy of the set (a
   // register array cannot be indexed by a run-time set number; 32 moves per set are nothing next to NSEG inlined epilogues)
   auto finish_sets = [&](int lo, int hi) __attribute__((always_inline)) {
+    // the deferred RMSNorm's row factors: wave 0, lane = row, every tile's partial requested at once (coalesced 256-byte
+    // rows); the round trip hides under the partial stores' drain below.  (A first version computed rs in the kernel's
+    // prologue, 8 tiles per round trip: 4 dependent round trips = ~8 us in front of the weight stream.)
+    float sq[32];
+    if (p.ssq_in && wn == 0) {
+#pragma unroll
+      for (int t = 0; t < 32; ++t) sq[t] = p.ssq_in[(size_t)min(t, p.tiles_in - 1) * DS_SSQ_LD + lane];
+    }
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg)
-      if (sg >= lo && sg < hi) store_partial(accs[sg], seg_tile[sg]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave's stores are out (write-through) ...
-    __syncthreads();                                    // ... before the one lane that signals for all of them
-    if (tid == 0) {
-#pragma unroll
-      for (int sg = 0; sg < NSEG; ++sg) {
-        if (sg < lo || sg >= hi) continue;
-        int first, ns;
-        seg_geom(seg_tile[sg], first, ns);
-        tick_s[sg] = (ns == 1) ? 0 : __hip_atomic_fetch_add(p.cnt + seg_tile[sg], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sg >= lo && sg < hi) {
+        store_partial(accs[sg], seg_tile[sg]);
+        if (tid == 0) segt_s[sg] = seg_tile[sg];
       }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave's stores are out (write-through) ...
+    if (wn == 0) {
+      float tot = 0.f;
+      if (p.ssq_in) {
+#pragma unroll
+        for (int t = 0; t < 32; ++t)
+          if (t < p.tiles_in) tot += sq[t];
+        for (int t = 32; t < p.tiles_in; ++t) tot += p.ssq_in[(size_t)t * DS_SSQ_LD + lane];   // (norm dims > 4096: none today)
+      }
+      rs_s[lane] = p.ssq_in ? rsqrtf(tot * p.inv_norm_dim + p.eps) : 1.0f;
     }
+    __syncthreads();                                    // ... before the lanes that signal for all of them
+    if (tid >= lo && tid < hi) {                        // one lane per set: the tickets travel together (one round trip)
+      const int tile = segt_s[tid];
+      int first, ns;
+      seg_geom(tile, first, ns);
+      tick_s[tid] = (ns == 1) ? 0 : __hip_atomic_fetch_add(p.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) rs[mb] = rs_s[mb * 16 + l15];
     __syncthreads();                                    // the other waves load only behind this barrier
     // The per-set part exists once and always works on set 0; after every pass the sets move down by one.  (Selecting set
     // `sg` at run time - by index or by a chain of guarded copies, which hipcc folds back into an index - moves EVERY

@@ -223,6 +223,12 @@ class Qwen2VLEngine:
         if decode_weights == "bf16" and os.environ.get("VIS_DECODE_CHAIN", "1") != "0" \
                 and hip.decode_chain_supported(Hq, Hkv, D, H):
             self.chain_ws, self.chain_sync = hip.decode_chain_state(dev, Hq, Hkv, self.nsplit)
+        # contexts up to this many cached keys decode on the chained launch, longer ones on the four launches (same bits):
+        # what must be resident together are the workgroups that wait - projection and merge roles + Hkv attention items per
+        # 64 keys of context (7B shapes: 6208 keys, whatever VIS_MAX_CTX is)
+        self.chain_ctx_limit = hip.decode_chain_ctx_limit(Hq, Hkv, H) if self.chain_sync is not None else 0
+        if self.chain_sync is not None and self.chain_ctx_limit <= 0:
+            self.chain_sync = None
         self.q8: List[dict] = []
         self.prefill_dtype = prefill_dtype
         if prefill_dtype not in ("bf16", "fp8"):
@@ -1015,11 +1021,13 @@ class Qwen2VLEngine:
         return P if P >= self.min_shared_prefix else 0
 
     # ------------------------------------------------------------------ decode
-    def _decode_step(self) -> None:
+    def _decode_step(self, chained: Optional[bool] = None) -> None:
         cfg, w = self.cfg, self.w
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         scale = D ** -0.5
-        chained = self.chain_sync is not None
+        if chained is None:
+            chained = self.chain_sync is not None
+        chained = chained and self.chain_sync is not None
         if not chained:
             hip.gather_rows(w.embed, self.cur_token, self.d_x)
         x, x2 = self.d_x, self.d_x2
@@ -1037,11 +1045,12 @@ class Qwen2VLEngine:
                        self.temperature, self.seed)
             return
         for li, lw in enumerate(w.llm):
-            if self.chain_sync is not None:
+            if chained:
                 try:   # layer 0 reads the new token's embedding row itself (x_index): no gather launch
                     hip.decode_chain(w.embed if li == 0 else x[0], lw.qkv_w, lw.qkv_b, lw.ln1_w, lw.o_w, x2[0], self.cos_t,
                                      self.sin_t, self.kcache[li], self.vcache[li], self.step, self.chain_ws, self.chain_sync,
-                                     Hq, Hkv, D, self.nsplit, scale, cfg.rms_eps, x_index=self.cur_token if li == 0 else None)
+                                     Hq, Hkv, D, self.nsplit, scale, cfg.rms_eps, x_index=self.cur_token if li == 0 else None,
+                                     ctx_bound=self.chain_ctx_limit)
                 except hip.ChainRefused as e:
                     # VIS_ERR_UNSUPPORTED and nothing else (a bad argument or a launch error propagates): the grid for this
                     # context length is larger than the device holds resident -> the four launches, same results; said once
@@ -1050,7 +1059,7 @@ class Qwen2VLEngine:
                     _LOG.warning("%s - decoding on the four launches per layer head (VIS_MAX_CTX=%d)", e, self.max_ctx)
                     self.chain_sync, self._chain_state, chained = None, None, False
                     hip.gather_rows(w.embed, self.cur_token, self.d_x)
-            if self.chain_sync is None:
+            if not chained:
                 hip.gemv(x[0], lw.qkv_w, self.d_qkv, bias=lw.qkv_b, norm_w=lw.ln1_w, eps=cfg.rms_eps)
                 hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[li], self.vcache[li], self.step,
                                 self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
@@ -1232,12 +1241,12 @@ class Qwen2VLEngine:
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
 
-    def _ensure_graph(self, batch: int = 0) -> torch.cuda.CUDAGraph:
+    def _ensure_graph(self, batch: int = 0, chained: bool = False) -> torch.cuda.CUDAGraph:
         # sampling parameters (and the batch size) are kernel arguments baked into the graph
-        key = (self.temperature, self.seed, batch, self.batch_shared_len if batch else 0)
+        key = (self.temperature, self.seed, batch, self.batch_shared_len if batch else 0, bool(chained) and not batch)
         if key in self._graphs:
             return self._graphs[key]
-        step_fn = (lambda: self._decode_step_batched(batch)) if batch else self._decode_step
+        step_fn = (lambda: self._decode_step_batched(batch)) if batch else (lambda: self._decode_step(chained))
         # warm the kernels outside capture, then restore the counters the warm-up advanced
         saved = (self.step_b.clone(), self.cur_b.clone())
         side = torch.cuda.Stream(device=self.device)
@@ -1262,24 +1271,28 @@ class Qwen2VLEngine:
             raise ValueError("decode would overflow the KV cache")
         if self.prompt_len + self._decoded + n_steps > self.decode_limit:
             raise ValueError("decode beyond the rope rows prepared by prefill (pass max_new_tokens)")
+        base = self.prompt_len + self._decoded       # step k of this call sees base + k cached keys
         self._decoded += n_steps
-        if self.chain_sync is None:
-            return self._decode_steps(n_steps, use_graph)
+        n_chain = max(0, min(n_steps, self.chain_ctx_limit - base)) if self.chain_sync is not None else 0
+        if n_chain == 0:
+            return self._decode_steps(n_steps, use_graph, False)
         # Chained launches wait inside the grid for workgroups of the SAME launch, which only works while that launch can
         # have its whole grid resident (860 of the device's 1024 slots at 7B shapes).  Two engines decoding on two streams at
         # once could strand each other (each holding slots the other's producers need; the bounded waits would then raise).
         # So the chained decode calls of a device are ordered on the GPU: a call waits for the previous call's last launch
         # (an event, no host blocking), whatever streams or threads they come from.  Decode is HBM-bound: nothing is lost.
-        self._chain_epoch_guard(n_steps)
+        self._chain_epoch_guard(n_chain)
         with _chain_order_lock(self.device.index):
             cur = torch.cuda.current_stream(self.device)
             prev = _CHAIN_LAST.get(self.device.index)
             if prev is not None:
                 cur.wait_event(prev)
-            self._decode_steps(n_steps, use_graph)
+            self._decode_steps(n_chain, use_graph, True)
             ev = torch.cuda.Event()
             ev.record(cur)
             _CHAIN_LAST[self.device.index] = ev
+        if n_steps > n_chain:       # the context has outgrown the chained grid: the four launches from here on (same bits)
+            self._decode_steps(n_steps - n_chain, use_graph, False)
 
     def _chain_epoch_guard(self, n_steps: int) -> None:
         """The granule tag of a chained launch is the sync block's 32-bit launch counter + 1.  Long before it can wrap
@@ -1292,14 +1305,16 @@ class Qwen2VLEngine:
             self.chain_ws.zero_()
             self._chain_launches = n_steps * len(self.w.llm)
 
-    def _decode_steps(self, n_steps: int, use_graph: bool) -> None:
+    def _decode_steps(self, n_steps: int, use_graph: bool, chained: bool = False) -> None:
         if use_graph:
-            g = self._ensure_graph()
+            g = self._ensure_graph(0, chained)
+            if chained and self.chain_sync is None:      # the warm-up met a refusal: the captured step is the unchained one
+                g = self._ensure_graph(0, False)
             for _ in range(n_steps):
                 g.replay()
         else:
             for _ in range(n_steps):
-                self._decode_step()
+                self._decode_step(chained)
 
     def generated(self, n: int) -> List[int]:
         s = self.prompt_len - 1

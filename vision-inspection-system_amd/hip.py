@@ -44,7 +44,8 @@ _SIGS = {
     "vis_decode_attn_shared": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "i" + "p",
     "vis_decode_chain_sync_ints": "",
     "vis_decode_chain_ws_bytes": "iii",
-    "vis_decode_chain": "ppi" + "p" * 12 + "i" * 8 + "ff" + "p",
+    "vis_decode_chain_ctx_limit": "iii",
+    "vis_decode_chain": "ppi" + "p" * 12 + "i" * 9 + "ff" + "p",
     "vis_gemv_bf16_argmax": "pppp" + "iii" + "f" + "ppp" + "i" + "pp" + "fu" + "p",
     "vis_argmax_f32": "p" + "i" + "ppp" + "i" + "pp" + "fu" + "ii" + "p",
     "vis_gemm_decode_ksplit": "ii",
@@ -730,14 +731,24 @@ def decode_chain_supported(n_q: int, n_kv: int, head_dim: int, hidden: int) -> b
         and hidden % 8 == 0 and hidden <= 4096 and n_q * head_dim <= 4096 and hidden // 2 <= (n_q + 2 * n_kv) * head_dim // 2
 
 
+def decode_chain_ctx_limit(n_q: int, n_kv: int, hidden: int) -> int:
+    """Largest context (cached keys incl. the new one) for which the chained layer head is resident on the current device
+    (0: shape not covered).  Only the workgroups that wait count: projection and merge roles + the attention items of splits
+    the context reaches - so the limit does not depend on the cache size."""
+    return int(load().vis_decode_chain_ctx_limit(n_q, n_kv, hidden))
+
+
 def decode_chain(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: Optional[torch.Tensor], norm_w: torch.Tensor,
                  o_w: torch.Tensor, y: torch.Tensor, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
                  v_cache: torch.Tensor, step: torch.Tensor, ws: torch.Tensor, sync: torch.Tensor, n_q: int, n_kv: int,
-                 head_dim: int, nsplit: int, scale: float, eps: float, x_index: Optional[torch.Tensor] = None) -> None:
+                 head_dim: int, nsplit: int, scale: float, eps: float, x_index: Optional[torch.Tensor] = None,
+                 ctx_bound: int = 0) -> None:
     """qkv projection (+ RMSNorm, bias) -> rope / KV append / split attention + merge -> o projection (+ residual x) in ONE
     launch, bit-identical to gemv + decode_attn + gemv.  Single sequence: x [K], caches [Hkv, T, D], tables [T, D], step [1];
     ws / sync from decode_chain_state.  With ``x_index`` (device int32 [1]) ``x`` is an [rows, K] table and the layer input is
-    its row x_index[0] (the new token's embedding: no separate gather launch)."""
+    its row x_index[0] (the new token's embedding: no separate gather launch).  ``ctx_bound``: the caller's promise that no
+    launch with these arguments (a captured launch is replayed at growing positions) sees more cached keys than that; 0 =
+    the whole cache.  The launcher refuses (ChainRefused) when the bound exceeds decode_chain_ctx_limit."""
     for t, n in ((x, "x"), (qkv_w, "qkv_w"), (norm_w, "norm_w"), (o_w, "o_w"), (y, "y"), (k_cache, "k_cache"),
                  (v_cache, "v_cache")):
         _bf16(t, "decode_chain " + n)
@@ -764,7 +775,7 @@ def decode_chain(x: torch.Tensor, qkv_w: torch.Tensor, qkv_b: Optional[torch.Ten
         raise HipLibraryError("decode_chain: workspace too small")
     rc = lib.vis_decode_chain(_ptr(x), _ptr(x_index), x_rows, _ptr(qkv_w), _ptr(qkv_b), _ptr(norm_w), _ptr(o_w), _ptr(y), _ptr(cos_t), _ptr(sin_t),
                               _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(ws), _ptr(sync), n_q, n_kv, head_dim, K,
-                              qkv_w.stride(0), o_w.stride(0), T, nsplit, scale, eps, _stream())
+                              qkv_w.stride(0), o_w.stride(0), T, nsplit, ctx_bound, scale, eps, _stream())
     if rc == 3:
         raise ChainRefused(f"vis_decode_chain: {n_q}/{n_kv} heads, hidden {K}, {nsplit} context splits are outside the chained "
                            "form on this device (shape, or grid larger than the device holds resident); nothing was launched")

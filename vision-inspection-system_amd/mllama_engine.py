@@ -125,8 +125,8 @@ class MllamaEngine:
         self.cur_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
         self.nkeys_b = torch.zeros(Bm, dtype=torch.int32, device=dev)
         self.tokens_b = torch.zeros((Bm, self.max_ctx), dtype=torch.int32, device=dev)
-        self.ws_val = torch.empty(256 * Bm, dtype=torch.float32, device=dev)
-        self.ws_idx = torch.empty(256 * Bm, dtype=torch.int32, device=dev)
+        self.ws_val = torch.empty(max(256 * Bm, 2048), dtype=torch.float32, device=dev)
+        self.ws_idx = torch.empty(max(256 * Bm, 2048), dtype=torch.int32, device=dev)
         self.logits_b = torch.empty((Bm, cfg.vocab), dtype=torch.float32, device=dev)
         self.kcache, self.vcache, self.xk, self.xv = self.kcache_b[0], self.vcache_b[0], self.xk_b[0], self.xv_b[0]
         self.step, self.cur_token, self.nkeys_m1 = self.step_b[0:1], self.cur_b[0:1], self.nkeys_b[0:1]
@@ -165,9 +165,24 @@ class MllamaEngine:
         elif Bm > 1:
             self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
                                       device=dev)
+        # Single-sequence decode: the head of every SELF-attention layer (qkv projection -> rope / append / attention -> o
+        # projection) as ONE launch, the lm_head with the pick's first stage in its epilogue - the Inspector's chained step
+        # (csrc/decode_chain.hip, Qwen2VLEngine._decode_step; bit-identical to the launches it replaces); the eight
+        # cross-attention layers keep their launches.  It runs while the context stays within what the device holds resident
+        # for this head shape (11B: 768 projection + 32 merge workgroups + 8 attention items per 64 keys -> 1536 keys) and on
+        # the separate launches beyond.  VIS_DECODE_CHAIN=0 = A/B.
+        self.chain_sync: Optional[torch.Tensor] = None
+        self.chain_ctx_limit = 0
+        self._chain_launches = 0
+        if os.environ.get("VIS_DECODE_CHAIN", "1") != "0" and hip.decode_chain_supported(Hq, Hkv, D, H):
+            lim = hip.decode_chain_ctx_limit(Hq, Hkv, H)
+            if lim > 0:
+                self.chain_ws, self.chain_sync = hip.decode_chain_state(dev, Hq, Hkv, self.nsplit)
+                self.chain_ctx_limit = lim
         self.slot_prompt_len = [0] * Bm
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._graph_key = None
+        self._graphs: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self._graphs_b: Dict[tuple, torch.cuda.CUDAGraph] = {}
         self._vis_plans: Dict[tuple, "hip.AttnPlan"] = {}
         self.temperature, self.seed = 0.0, 0
@@ -571,14 +586,17 @@ class MllamaEngine:
                 self.decode_limit = self.max_ctx
 
     # ------------------------------------------------------------------ decode
-    def _decode_step(self) -> None:
+    def _decode_step(self, chained: bool = False) -> None:
         cfg, w = self.cfg, self.w
         Hq, Hkv, D = cfg.heads, cfg.kv_heads, cfg.head_dim
         scale = D ** -0.5
-        hip.gather_rows(w.embed, self.cur_token, self.d_x)
+        chained = chained and self.chain_sync is not None
+        embed_in_chain = chained and not w.layers[0].cross      # the first layer's launch reads the embedding row itself
+        if not embed_in_chain:
+            hip.gather_rows(w.embed, self.cur_token, self.d_x)
         x, x2 = self.d_x, self.d_x2
         si = ci = 0
-        for lw in w.layers:
+        for li, lw in enumerate(w.layers):
             if lw.cross:
                 if not self.has_image:
                     ci += 1
@@ -588,47 +606,96 @@ class MllamaEngine:
                 hip.decode_cross_attn(dq, lw.q_norm, self.xk[ci], self.xv[ci], self.nkeys_m1, self.part_o,
                                       self.part_ml, self.d_attn, Hq, Hkv, D, self.xsplit, scale, cfg.rms_eps)
                 ci += 1
+                hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
+            elif chained:
+                first = li == 0 and embed_in_chain
+                hip.decode_chain(w.embed if first else x[0], lw.qkv_w, None, lw.ln1_w, lw.o_w, x2[0], self.cos_t, self.sin_t,
+                                 self.kcache[si], self.vcache[si], self.step, self.chain_ws, self.chain_sync, Hq, Hkv, D,
+                                 self.nsplit, scale, cfg.rms_eps, x_index=self.cur_token if first else None,
+                                 ctx_bound=self.chain_ctx_limit)
+                si += 1
             else:
                 hip.gemv(x[0], lw.qkv_w, self.d_qkv, norm_w=lw.ln1_w, eps=cfg.rms_eps)
                 hip.decode_attn(self.d_qkv, self.cos_t, self.sin_t, self.kcache[si], self.vcache[si], self.step,
                                 self.part_o, self.part_ml, self.d_attn, Hq, Hkv, D, self.nsplit, scale)
                 si += 1
-            hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
+                hip.gemv(self.d_attn, lw.o_w, x2[0], residual=x[0])
             hip.gemv(x2[0], lw.gateup_w, self.d_act, norm_w=lw.ln2_w, act=hip.ACT_SWIGLU, eps=cfg.rms_eps)
             hip.gemv(self.d_act, lw.down_w, x[0], residual=x2[0])
+        if chained:     # the pick's first stage rides in the lm_head epilogue
+            hip.gemv_argmax(x[0], w.lm_head, self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step,
+                            norm_w=w.norm_w, eps=cfg.rms_eps, temperature=self.temperature, seed=self.seed)
+            return
         hip.gemv(x[0], w.lm_head, self.logits, norm_w=w.norm_w, eps=cfg.rms_eps)
         hip.argmax(self.logits, self.ws_val, self.ws_idx, self.tokens, self.cur_token, self.step, self.temperature,
                    self.seed)
 
-    def _ensure_graph(self) -> torch.cuda.CUDAGraph:
-        key = (self.temperature, self.seed, self.has_image)
-        if self._graph is not None and self._graph_key == key:
-            return self._graph
+    def _ensure_graph(self, chained: bool = False) -> torch.cuda.CUDAGraph:
+        chained = chained and self.chain_sync is not None
+        key = (self.temperature, self.seed, self.has_image, chained)
+        if key in self._graphs:
+            return self._graphs[key]
         snap = (self.step.clone(), self.cur_token.clone())
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            self._decode_step()                      # warm-up outside capture
+            self._decode_step(chained)               # warm-up outside capture
         torch.cuda.current_stream().wait_stream(s)
         self.step.copy_(snap[0]); self.cur_token.copy_(snap[1])
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):     # another agent's thread may be allocating
-            self._decode_step()
+            self._decode_step(chained)
         self.step.copy_(snap[0]); self.cur_token.copy_(snap[1])
-        self._graph, self._graph_key = g, key
+        if len(self._graphs) >= 6:
+            self._graphs.pop(next(iter(self._graphs)))
+        self._graphs[key] = g
         return g
 
-    def decode(self, n_steps: int, use_graph: bool = True) -> None:
-        if self.prompt_len + self._decoded + n_steps >= self.decode_limit:
-            raise ValueError("decode would run past the context window")
+    def _decode_steps(self, n_steps: int, use_graph: bool, chained: bool) -> None:
         if use_graph:
-            g = self._ensure_graph()
+            g = self._ensure_graph(chained)
             for _ in range(n_steps):
                 g.replay()
         else:
             for _ in range(n_steps):
-                self._decode_step()
+                self._decode_step(chained)
+
+    def decode(self, n_steps: int, use_graph: bool = True) -> None:
+        if self.prompt_len + self._decoded + n_steps >= self.decode_limit:
+            raise ValueError("decode would run past the context window")
+        base = self.prompt_len + self._decoded       # step k of this call sees base + k cached keys
+        n_chain = max(0, min(n_steps, self.chain_ctx_limit - base)) if self.chain_sync is not None else 0
+        if n_chain:
+            # chained launches wait inside the grid for workgroups of the SAME launch: one at a time per device, whatever
+            # engine, thread or stream it comes from (the Inspector's engine shares the GPU): ordered with an event, as in
+            # Qwen2VLEngine.decode
+            from .engine import _CHAIN_LAST, _chain_order_lock
+            n_self = sum(1 for lw in self.w.layers if not lw.cross)
+            self._chain_launches += n_chain * n_self
+            if self._chain_launches >= (1 << 31):     # long before the 32-bit launch counter can wrap (Qwen2VLEngine._chain_epoch_guard)
+                self.chain_sync.zero_()
+                self.chain_ws.zero_()
+                self._chain_launches = n_chain * n_self
+            with _chain_order_lock(self.device.index):
+                cur = torch.cuda.current_stream(self.device)
+                prev = _CHAIN_LAST.get(self.device.index)
+                if prev is not None:
+                    cur.wait_event(prev)
+                self._decode_steps(n_chain, use_graph, True)
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                _CHAIN_LAST[self.device.index] = ev
+        if n_steps > n_chain:
+            self._decode_steps(n_steps - n_chain, use_graph, False)
         self._decoded += n_steps
+
+    def check_chain(self) -> None:
+        """Raise hip.ChainStalled if a bounded wait inside a chained launch gave up (results invalid); see Qwen2VLEngine.check_chain."""
+        if self.chain_sync is not None and int(self.chain_sync[hip.CHAIN_STATUS_WORD].item()) != 0:
+            self.chain_sync.zero_()
+            self.chain_ws.zero_()
+            self._chain_launches = 0
+            raise hip.ChainStalled("vis_decode_chain: a hand-off wait inside the launch timed out (decode results invalid)")
 
     # ---- batched decode: B in-flight requests (slots 0..B-1, all with an image) share every weight read of a step
     def _decode_step_batched(self, B: int) -> None:
@@ -872,11 +939,25 @@ class MllamaEngine:
 
     def generated(self, n: int) -> List[int]:
         s = self.prompt_len - 1          # the token generated at step i is stored at index (its position - 1)
-        return self.tokens[s:s + n].cpu().tolist()
+        toks = self.tokens[s:s + n].cpu().tolist()
+        self.check_chain()
+        return toks
 
     def generate(self, input_ids: Sequence[int], frame: Optional[torch.Tensor] = None, max_new_tokens: int = 128,
                  temperature: float = 0.0, seed: int = 0, stop_on_eos: bool = True, use_graph: bool = True,
                  chunk: int = 32) -> List[int]:
+        try:
+            return self._generate(input_ids, frame, max_new_tokens, temperature, seed, stop_on_eos, use_graph, chunk)
+        except hip.ChainStalled as e:
+            # a chained launch could not get its waiting workgroups resident (another process on the GPU): the request is served
+            # again on the separate launches - identical tokens - and this engine stays on them
+            import logging
+            logging.getLogger("vision_inspection_system_amd.engine").warning("%s - continuing on the unchained decode step", e)
+            self.chain_sync = None
+            self._graphs.clear()
+            return self._generate(input_ids, frame, max_new_tokens, temperature, seed, stop_on_eos, use_graph, chunk)
+
+    def _generate(self, input_ids, frame, max_new_tokens, temperature, seed, stop_on_eos, use_graph, chunk) -> List[int]:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]      # per-stage device time, as in Qwen2VLEngine
         ev[0].record()
         self.prefill(input_ids, frame, temperature=temperature, seed=seed)
