@@ -263,10 +263,11 @@ int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* 
  * (nobody waits), then finished there:
  *   VIS_DP_PLAIN       C[b][n] = (x W^T)[b][n] * rs[b] + bias[n]         bf16, or f32 when out_f32 (q/k/v, lm_head)
  *   VIS_DP_SWIGLU      C[b][o] = silu(g * rs[b]) * (u * rs[b])           16-row interleaved gate/up weight, N / 2 outputs
- *   VIS_DP_RESID_NORMW C = y = bf16(x W^T + R), Cw = bf16(y * nw[n]), ssq_out[n / 128][b] = sum over the tile of y^2
+ *   VIS_DP_RESID_NORMW C = y = bf16(x W^T + R), Cw = bf16(y * nw[n]), ssq_out[n / 32][b] = sum over the 32-column unit of y^2
  * The RMSNorm in front of a projection (TF modeling_qwen2_vl.py:96-110) is applied in two exact halves: the PRODUCER of the
  * row multiplies by the norm weight (Cw, a per-column factor), the CONSUMER by rs[b] = rsqrt(sum_t ssq_in[t][b] / norm_dim +
- * eps) (a per-row factor that commutes with the projection); ssq_in == NULL means rs = 1.  ssq buffers: [tiles][64] f32.
+ * eps) (a per-row factor that commutes with the projection); ssq_in == NULL means rs = 1.  ssq buffers: [columns / 32][64]
+ * f32 (tiles_in = norm_dim / 32 <= 128 units).
  * ws: vis_decode_proj_ws_bytes(B, N, K, fp8) bytes, 256-byte aligned, zeroed once (the kernel leaves it reusable), one
  * launch at a time per workspace.  A row's result depends on that row alone (bitwise slot / batch-size invariance).
  * Cq / Cqs (SWIGLU, RESID_NORMW; may be NULL): the row the next projection consumes (act, or y * nw) as MX blocks: OCP
@@ -274,7 +275,7 @@ int vis_gemv_fp8w(const void* x, const void* Wq, const void* scale, const void* 
  * scale <= 448).  vis_decode_proj_fp8 (BASELINE configs[4]): A given as such blocks (Aq, As), Wq e4m3 [N][ldw] with
  * per-output-row f32 scales sw[N], on v_mfma_scale_f32_16x16x128_f8f6f4 with the block scale in the instruction's scale
  * operand; K % 128 == 0.  vis_decode_prep_rows: head of a step - x[b] = table[ids[b]] (clamped), xw = bf16(x * nw), the
- * MX copy of xw (xq / xqs, may be NULL) and ssq[n / 128][b]; H % 128 == 0. */
+ * MX copy of xw (xq / xqs, may be NULL) and ssq[n / 32][b]; H % 128 == 0. */
 #define VIS_DP_PLAIN 0
 #define VIS_DP_SWIGLU 1
 #define VIS_DP_RESID_NORMW 2
@@ -288,6 +289,25 @@ int vis_decode_proj_fp8(const void* Aq, const void* As, const void* Wq, const vo
                         const void* ssq_in, void* ssq_out, int B, int N, int K, int ldaq, int ldas, int ldw,
                         int ldc, int ldr, int ldcq, int ldcqs, int mode, int out_f32, int tiles_in,
                         int norm_dim, float eps, vis_stream_t stream);
+/* Column-parallel form of the same projection (csrc/decode_colpar.hip): every workgroup owns whole output columns - floor or
+ * ceil((N / 32) / workgroups) units of 32 columns, at most five, min(256, N / 32) workgroups - and the entire K, so nothing is
+ * reduced across workgroups: no workspace, no tickets, the epilogue runs on registers.  Each workgroup streams all of x
+ * (rows x K, from L2) next to its weight rows (from HBM): the form for projections whose x is small next to the weights a
+ * workgroup owns (everything but the long-K down projection at many sequences).  Arguments, epilogue modes and per-row
+ * results as vis_decode_proj_* (a row's sum runs over the K-steps in ascending order in both forms; tiles the stream-K form
+ * does not cut are bit-identical).  vis_decode_proj_colpar_covers: 1 when the form covers (N, mode, MX output wanted) - N %
+ * 32 == 0, N <= 40960, not SwiGLU with an MX output (an act block of 32 columns spans two units); otherwise the entry
+ * points return VIS_ERR_UNSUPPORTED and the caller uses vis_decode_proj_*. */
+int vis_decode_proj_colpar_covers(int N, int mode, int mx_out);
+int vis_decode_proj_colpar_bf16(const void* A, const void* W, void* C, void* Cw, void* Cq, void* Cqs, const void* bias,
+                                const void* R, const void* nw, const void* ssq_in, void* ssq_out, int B, int N, int K,
+                                int lda, int ldw, int ldc, int ldr, int ldcq, int ldcqs, int mode, int out_f32,
+                                int tiles_in, int norm_dim, float eps, vis_stream_t stream);
+int vis_decode_proj_colpar_fp8(const void* Aq, const void* As, const void* Wq, const void* sw, void* C, void* Cw,
+                               void* Cq, void* Cqs, const void* bias, const void* R, const void* nw,
+                               const void* ssq_in, void* ssq_out, int B, int N, int K, int ldaq, int ldas, int ldw,
+                               int ldc, int ldr, int ldcq, int ldcqs, int mode, int out_f32, int tiles_in,
+                               int norm_dim, float eps, vis_stream_t stream);
 int vis_decode_prep_rows(const void* table, const void* ids, const void* nw, void* x, void* xw, void* xq,
                          void* xqs, void* ssq, int B, int table_rows, int H, int ldx, int ldq, int ldqs,
                          vis_stream_t stream);

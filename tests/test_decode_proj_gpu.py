@@ -1,6 +1,7 @@
-"""vis_decode_proj_* (csrc/decode_stream.hip): the batched-decode projection with split-K reduction and row-wise epilogue in one
-launch, against fp32 PyTorch statements of the same arithmetic; bitwise repeatability and row independence; the fp8 form on MX
-blocks against oracle/mx_ref.py."""
+"""vis_decode_proj_* (csrc/decode_stream.hip: stream-K ranges + last-arriver reduction) and vis_decode_proj_colpar_*
+(csrc/decode_colpar.hip: whole-K column slabs, nothing reduced across workgroups): the batched-decode projection with its
+row-wise epilogue in one launch, against fp32 PyTorch statements of the same arithmetic; bitwise repeatability and row
+independence; the fp8 forms on MX blocks against oracle/mx_ref.py."""
 import pytest
 import torch
 
@@ -39,10 +40,10 @@ def _ref_epilogue(acc, mode, rs, bias, res, nw):
         return _rt(torch.nn.functional.silu(g) * u), None, None
     y = _rt(acc + res.float())
     yw = _rt(y * nw.float()[None, :])
-    tiles = (N + 127) // 128
-    pad = torch.zeros((B, tiles * 128), dtype=torch.float32)
+    units = (N + 31) // 32
+    pad = torch.zeros((B, units * 32), dtype=torch.float32)
     pad[:, :N] = y * y
-    return y, yw, pad.view(B, tiles, 128).sum(-1).T.contiguous()     # [tiles, B]
+    return y, yw, pad.view(B, units, 32).sum(-1).T.contiguous()     # [units, B]
 
 
 SHAPES = [  # (N, K, mode, what)
@@ -53,11 +54,18 @@ SHAPES = [  # (N, K, mode, what)
 ]
 
 
+def _covered(hip, form, N, mode, mx):
+    return form == "streamk" or bool(hip.load().vis_decode_proj_colpar_covers(N, mode, 1 if mx else 0))
+
+
+@pytest.mark.parametrize("form", ["streamk", "colpar"])
 @pytest.mark.parametrize("N,K,mode,what", SHAPES)
 @pytest.mark.parametrize("B", [1, 4, 16, 17, 33, 64])
-def test_decode_proj_bf16_matches_fp32(hip, device, N, K, mode, what, B):
+def test_decode_proj_bf16_matches_fp32(hip, device, N, K, mode, what, B, form):
     if N > 100000 and B not in (4, 64):
         pytest.skip("large-N shapes at two batch sizes only")
+    if not _covered(hip, form, N, mode, False):
+        pytest.skip("shape outside the column-parallel form (N % 32, or more than five units per workgroup)")
     seed = N + K + B
     x, w = _mk((B, K), seed, 1.0), _mk((N, K), seed + 1, K ** -0.5)
     f32_out = what.endswith("f32")
@@ -65,8 +73,8 @@ def test_decode_proj_bf16_matches_fp32(hip, device, N, K, mode, what, B):
     res = _mk((B, N), seed + 3) if mode == 2 else None
     nw = (1 + 0.1 * _mk((N,), seed + 4).float()).to(torch.bfloat16) if mode == 2 else None
     use_rs = mode != 2
-    tiles_in = (K + 127) // 128
-    ssq_in = (torch.rand((tiles_in, 64), generator=torch.Generator().manual_seed(seed + 5)) * 200 + 20) if use_rs else None
+    tiles_in = min(128, (K + 31) // 32)
+    ssq_in = (torch.rand((tiles_in, 64), generator=torch.Generator().manual_seed(seed + 5)) * 50 + 5) if use_rs else None
     rs = torch.rsqrt(ssq_in[:, :B].sum(0) / K + 1e-6) if use_rs else torch.ones(B)
     xd, wd = x.to(device), w.to(device)
     acc = (xd.float() @ wd.float().T).cpu()        # fp32 product of the bf16 operands (reference arithmetic, on the device for speed)
@@ -75,10 +83,10 @@ def test_decode_proj_bf16_matches_fp32(hip, device, N, K, mode, what, B):
     ws = hip.decode_proj_ws(device, B, N, K)
     out = torch.full((B, n_out), 7.0, dtype=torch.float32 if f32_out else torch.bfloat16, device=device)
     out_w = torch.full((B, n_out), 7.0, dtype=torch.bfloat16, device=device) if mode == 2 else None
-    ssq_out = torch.full(((N + 127) // 128, 64), -1.0, dtype=torch.float32, device=device) if mode == 2 else None
+    ssq_out = torch.full(((N + 31) // 32, 64), -1.0, dtype=torch.float32, device=device) if mode == 2 else None
     kw = dict(out=out, out_w=out_w, bias=bias.to(device) if bias is not None else None,
               residual=res.to(device) if res is not None else None, norm_w=nw.to(device) if nw is not None else None,
-              ssq_in=ssq_in.to(device) if use_rs else None, ssq_out=ssq_out, norm_dim=K if use_rs else 0, eps=1e-6)
+              ssq_in=ssq_in.to(device) if use_rs else None, ssq_out=ssq_out, norm_dim=K if use_rs else 0, eps=1e-6, form=form)
     hip.decode_proj(xd, wd, ws, mode, **kw)
     torch.cuda.synchronize()
     assert int(ws[:16384].view(torch.int32).abs().sum()) == 0, "arrival counters must be back at zero after the launch"
@@ -91,9 +99,9 @@ def test_decode_proj_bf16_matches_fp32(hip, device, N, K, mode, what, B):
         # the weighted copy is EXACTLY bf16(y * nw) of the y the kernel wrote
         assert torch.equal(out_w.float().cpu(), _rt(got * nw.float()[None, :]))
         s_ref = torch.zeros_like(ssq)
-        yy = torch.zeros((B, ((N + 127) // 128) * 128))
+        yy = torch.zeros((B, ((N + 31) // 32) * 32))
         yy[:, :N] = got * got
-        s_ref = yy.view(B, -1, 128).sum(-1).T
+        s_ref = yy.view(B, -1, 32).sum(-1).T
         assert torch.allclose(ssq_out[:, :B].cpu(), s_ref, rtol=1e-5, atol=1e-6), "tile sums of squares of the written y"
         assert bool((ssq_out[:, B:] == -1.0).all()), "rows >= B of the ssq buffer must not be touched"
     # bitwise repeatable on the same workspace, and a row's result does not depend on the batch it sits in
@@ -123,7 +131,7 @@ def test_decode_prep_rows(hip, device):
     ids = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
     ids[0], ids[1] = -5, V + 9                      # clamped like vis_gather_rows
     x = torch.empty((B, H), dtype=torch.bfloat16, device=device)
-    xw, ssq = torch.empty_like(x), torch.full((H // 128, 64), -1.0, dtype=torch.float32, device=device)
+    xw, ssq = torch.empty_like(x), torch.full((H // 32, 64), -1.0, dtype=torch.float32, device=device)
     xq = torch.zeros((B, H), dtype=torch.uint8, device=device)
     xqs = torch.zeros((B, H // 32), dtype=torch.uint8, device=device)
     hip.decode_prep_rows(table, ids.to(device), nw, x, xw, ssq, xq, xqs)
@@ -131,7 +139,7 @@ def test_decode_prep_rows(hip, device):
     assert torch.equal(x, rows)
     w_ref = _rt(rows.float().cpu() * nw.float().cpu()[None, :])
     assert torch.equal(xw.float().cpu(), w_ref)
-    s_ref = (rows.float().cpu() ** 2).view(B, H // 128, 128).sum(-1).T
+    s_ref = (rows.float().cpu() ** 2).view(B, H // 32, 32).sum(-1).T
     assert torch.allclose(ssq[:, :B].cpu(), s_ref, rtol=1e-5) and bool((ssq[:, B:] == -1).all())
     q_ref, s_bytes = mx_ref.mx_quant(w_ref)
     assert torch.equal(xqs.cpu(), s_bytes), "E8M0 block scales"
@@ -142,9 +150,10 @@ FP8_SHAPES = [(4608, 3584, 0, "qkv"), (37888, 3584, 1, "gate/up"), (3584, 18944,
               (512, 256, 0, "tiny qkv"), (256, 768, 2, "tiny down (K padded)"), (1408, 256, 1, "tiny gate/up")]
 
 
+@pytest.mark.parametrize("form", ["streamk", "colpar"])
 @pytest.mark.parametrize("N,K,mode,what", FP8_SHAPES)
 @pytest.mark.parametrize("B", [1, 4, 20, 64])
-def test_decode_proj_fp8_mx(hip, device, N, K, mode, what, B):
+def test_decode_proj_fp8_mx(hip, device, N, K, mode, what, B, form):
     """fp8 form: e4m3 weights with per-row scales, MX activation blocks with NON-trivial block scales (rows and blocks of
     very different magnitude: a wrong scale-to-lane mapping cannot hide) against the fp32 product of the de-quantised operands;
     MX outputs byte-exact against oracle/mx_ref.py applied to the kernel's own bf16 outputs."""
@@ -168,6 +177,8 @@ def test_decode_proj_fp8_mx(hip, device, N, K, mode, what, B):
     ssq_in = (torch.rand((tiles_in, 64), generator=g) * 200 + 20) if use_rs else None
     rs = torch.rsqrt(ssq_in[:, :B].sum(0) / 384 + 1e-6) if use_rs else torch.ones(B)
     main, weighted, _ = _ref_epilogue((xd.to(device) @ wdq.to(device).T).cpu(), mode, rs, bias, res, nw)
+    if not _covered(hip, form, N, mode, mode != 0):
+        pytest.skip("shape / output outside the column-parallel form")
     n_out = N // 2 if mode == 1 else N
     ws = hip.decode_proj_ws(device, B, N, K, fp8=True)
     out = torch.full((B, n_out), 7.0, dtype=torch.float32 if f32_out else torch.bfloat16, device=device)
@@ -175,11 +186,11 @@ def test_decode_proj_fp8_mx(hip, device, N, K, mode, what, B):
     want_q = mode != 0
     oq = torch.zeros((B, n_out), dtype=torch.uint8, device=device) if want_q else None
     oqs = torch.zeros((B, n_out // 32), dtype=torch.uint8, device=device) if want_q else None
-    ssq_out = torch.zeros(((N + 127) // 128, 64), dtype=torch.float32, device=device) if mode == 2 else None
+    ssq_out = torch.zeros(((N + 31) // 32, 64), dtype=torch.float32, device=device) if mode == 2 else None
     hip.decode_proj_fp8(xq.to(device), xs.to(device), wq, sw, ws, mode, out=out, out_w=out_w, out_q=oq, out_qs=oqs,
                         bias=bias.to(device) if bias is not None else None, residual=res.to(device) if res is not None else None,
                         norm_w=nw.to(device) if nw is not None else None, ssq_in=ssq_in.to(device) if use_rs else None,
-                        ssq_out=ssq_out, norm_dim=384 if use_rs else 0, eps=1e-6)
+                        ssq_out=ssq_out, norm_dim=384 if use_rs else 0, eps=1e-6, form=form)
     torch.cuda.synchronize()
     got = out.float().cpu()
     scale = float(main.abs().max())
@@ -198,7 +209,10 @@ def test_decode_proj_argument_checks(hip, device):
     out = torch.empty((4, 512), dtype=torch.bfloat16, device=device)
     with pytest.raises(hip.HipLibraryError):                       # residual mode without its operands
         hip.decode_proj(x, w, ws, hip.DP_RESID_NORMW, out=out)
-    with pytest.raises(hip.HipLibraryError):                       # workspace of another (smaller) shape
-        hip.decode_proj(x, w, ws[:20000], hip.DP_PLAIN, out=out)
+    with pytest.raises(hip.HipLibraryError):                       # workspace of another (smaller) shape (stream-K form)
+        hip.decode_proj(x, w, ws[:20000], hip.DP_PLAIN, out=out, form="streamk")
+    hip.decode_proj(x, w, None, hip.DP_PLAIN, out=out, form="colpar")       # the column-parallel form needs none
+    with pytest.raises(hip.HipLibraryError):                       # N outside the column-parallel form
+        hip.decode_proj(x, w[:500], None, hip.DP_PLAIN, out=out[:, :500], form="colpar")
     with pytest.raises(hip.HipLibraryError):                       # K not a multiple of the K-step
         hip.decode_proj(x[:, :200], w[:, :200], ws, hip.DP_PLAIN, out=out)

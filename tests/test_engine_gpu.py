@@ -176,10 +176,13 @@ def test_prompt_validation(setup):
         eng.prefill([256, cfg.image_token_id, 10], [])  # image token without an image
 
 
-def test_batched_generation_matches_single(device):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_batched_generation_matches_single(device, monkeypatch, fused):
     """Batched decode (skinny MFMA GEMM, one weight pass for all sequences) vs the single-sequence GEMV path:
     same prompts -> same greedy tokens up to genuine near-ties (different summation order), and the
-    first token (prefill path, identical code) must agree exactly."""
+    first token (prefill path, identical code) must agree exactly.  fused = 1: the opt-in r05 step, every projection one
+    launch (vis_decode_proj_*: in-kernel reduction or column slabs, RMSNorm split into column and row factors)."""
+    monkeypatch.setenv("VIS_DECODE_FUSED", fused)
     from oracle import qwen2vl_ref as R
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
@@ -232,16 +235,19 @@ def test_rows_gemv_decode_equals_single_sequence_decode(device, monkeypatch, wei
             assert torch.equal(eng.logits_b[b], logits[b].view(-1)), f"sequence {b}: logits differ from the single-sequence step"
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("weights", ["bf16", "fp8"])
-def test_batched_generation_more_than_16_sequences(device, weights):
+def test_batched_generation_more_than_16_sequences(device, weights, monkeypatch, fused):
     """17..32 (33..64) in-flight sequences use two (four) 16-row MFMA blocks in the batched projection: the tokens of a
     request are the same as in a batch of <= 16 (rows are independent; the stream-K slot order depends on (N, K) only)."""
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
     from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    monkeypatch.setenv("VIS_DECODE_FUSED", fused)
     cfg = Qwen2VLConfig.tiny()
     sd = synth_state_dict(cfg, seed=0)
     eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=64, decode_weights=weights)
+    assert eng.fused_proj == (fused == "1")
     g = load_golden()
     fa = [torch.from_numpy(g["frame_a"]).to(device)]
     fb = [torch.from_numpy(g["frame_b1"]).to(device), torch.from_numpy(g["frame_b2"]).to(device)]
@@ -395,18 +401,20 @@ def test_fp8_prefill_matches_oracle_with_fake_quant(setup, device, monkeypatch):
     assert len(toks) == 6
 
 
-def test_fp8_batched_decode(device):
-    """configs[4], batched decode on e4m3 weights + activations.  Invariants (the element-wise checks are the kernel
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_fp8_batched_decode(device, monkeypatch, fused):
+    """configs[4], batched decode on e4m3 weights + activations (fused = 1: the opt-in r05 step on MX activation blocks).  Invariants (the element-wise checks are the kernel
     tests): identical requests in different slots give identical tokens, graph replay == eager, the first token (bf16
     prefill + bf16-activation lm_head path of prefill) equals the single-sequence engine's, and the first batched step's
     logits stay within fp8 noise of the W8A16 single-sequence step (mean < 0.06, max < 0.4 on a +-3 logit range)."""
     from vision_inspection_system_amd.config import Qwen2VLConfig
     from vision_inspection_system_amd.engine import Qwen2VLEngine
     from vision_inspection_system_amd.weights import pack_device_weights, synth_state_dict
+    monkeypatch.setenv("VIS_DECODE_FUSED", fused)
     cfg = Qwen2VLConfig.tiny()
     sd = synth_state_dict(cfg, seed=0)
     eng = Qwen2VLEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=4, decode_weights="fp8")
-    assert eng.fp8_batched
+    assert eng.fp8_batched and eng.fused_proj == (fused == "1")
     g = load_golden()
     fa = [torch.from_numpy(g["frame_a"]).to(device)]
     reqs = [(g["ids_a"].tolist(), fa), ([256, 72, 105, 33], []), (g["ids_a"].tolist(), fa)]

@@ -143,11 +143,13 @@ def test_chained_self_layers_equal_separate_launches(setup, device, monkeypatch)
     assert eng.generate(tids, None, max_new_tokens=8, stop_on_eos=False) == plain.generate(tids, None, max_new_tokens=8, stop_on_eos=False)
 
 
-def test_batched_decode_matches_single_and_is_batch_invariant(device):
+@pytest.mark.parametrize("fused", ["0", "1"])
+def test_batched_decode_matches_single_and_is_batch_invariant(device, monkeypatch, fused):
     """verify_many path: several images share ONE decode loop (stream-K batched projections, batched
     self- and cross-attention).  A request's tokens do not depend on its slot, on the batch size or on what shares the
     batch (exact); graph replay == eager; against the single-sequence GEMV path the first token (same prompt pass) is
     exact and the rest agree up to genuine near-ties of the oracle (different f32 summation order)."""
+    monkeypatch.setenv("VIS_DECODE_FUSED", fused)      # 1: the opt-in r05 step (every projection one launch)
     from oracle import mllama_ref as R
     from test_oracle_mllama import ref_cfg
     from vision_inspection_system_amd.mllama_engine import MllamaEngine

@@ -224,22 +224,27 @@ def seam_block(engine, n_images=64, size=1024, new=128, model_id="synthetic:benc
     try:
         with tempfile.TemporaryDirectory() as d:
             t0 = time.perf_counter()
-            paths = []
-            for i in range(n_images):
+            paths = [os.path.join(d, f"frame{i:03d}.png") for i in range(n_images)]
+
+            def write(i):     # seeded uint8 frames, written as PNG so that the a3 encode does its JPEG round trip
                 rng = np.random.default_rng(1234 + i)
-                p = os.path.join(d, f"frame{i:03d}.png")
-                Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(p, compress_level=1)
-                paths.append(p)
+                Image.fromarray(rng.integers(0, 256, (size, size, 3), dtype=np.uint8)).save(paths[i], compress_level=1)
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:     # (zlib releases the GIL: untimed set-up)
+                list(pool.map(write, range(n_images)))
             t_files = time.perf_counter() - t0
             run_batch_inspection(paths[:4], "medium", "general")          # warm: graphs for this token budget, pool threads
             ingest.shutdown()
             clear_encode_cache()                                           # the measured run encodes its own images
             torch.cuda.synchronize()
             ingest.TRACE = []
+            from vision_inspection_system_amd import hip as _hip
+            _hip.call_trace_start()
             t0 = time.perf_counter()
             out = run_batch_inspection(paths, "medium", "general")
             torch.cuda.synchronize()
             t = time.perf_counter() - t0
+            calls = _hip.call_trace_stop()
             trace, ingest.TRACE = ingest.TRACE, None
         timing = dict(getattr(engine, "last_timing", {}))
         stages = {}
@@ -257,6 +262,10 @@ def seam_block(engine, n_images=64, size=1024, new=128, model_id="synthetic:benc
                 "ingest_threads": int(os.environ.get("VIS_INGEST_THREADS", "4")), "host_cpus": os.cpu_count(),
                 "engine_device_ms": {"prompt_passes": timing.get("prefill_ms"), "decode_loop": timing.get("decode_ms")},
                 "host_timeline": stages,
+                # the thread that launches the kernels: entry-point calls of the measured call and the time spent inside them
+                # (argument marshalling + hipLaunchKernel; the GIL is released during the C call) - against `seconds`
+                "launch_thread": (lambda c: {"library_calls": c[0], "inside_library_s": c[1]})(
+                    max(calls.values(), key=lambda c: c[0]) if calls else [0, 0.0]),
                 "write_png_files_s": t_files,
                 "what": "run_batch_inspection on PNG files: a3 encode (PIL thumbnail / JPEG q85 / base64) -> data-URI decode "
                         "(host Huffman + GPU IDCT) -> GPU resize -> tokenise -> per-image prompt pass + shared decode loop -> "
@@ -305,6 +314,15 @@ def run_all(cfg, weights, dev, frame, n_patches, n_img_tok, new, prompt_tokens, 
         guarded("seam64", lambda: seam_block(eng64, 64, 1024, new))
         if "error" not in out["seam64"] and "error" not in out["batch64"]:
             out["seam64"]["kernel_only_images_per_s"] = out["batch64"]["images_per_s"]
+
+        def n1():     # BASELINE configs[3] on ONE GPU: the measured N = 1 point of the strong-scaling curve
+            r = seam_block(eng64, 256, 1024, new)
+            r["workload"] = ("configs[3] at N = 1: run_batch_inspection over 256 x 1024x1024 PNG files on ONE GPU (four decode "
+                             "batches of 64), Inspector local, Auditor canned - the same call `bench.py --gpus 8 --workload "
+                             "batch256` shards over ranks; no 8-GPU run exists")
+            r.pop("host_timeline", None)
+            return r
+        guarded("batch256_n1", n1)
 
         def dual():
             mc = MW.MllamaConfig.mllama_11b()

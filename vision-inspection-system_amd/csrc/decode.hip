@@ -513,13 +513,12 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
       r.v[i] = *(const uint32_t*)(Vb + (size_t)row * HD + 2 * lane);
     }
   };
-  // FOUR register sets (static indexing): three steps of a wave are in flight while a fourth is consumed - 24 KB per wave,
-  // 192 KB per CU.  r02-r04 kept two sets (8 KB per wave in flight): at ~2 us of loaded latency that caps a CU at ~32 GB/s and
-  // the launch ran at 3.7 TB/s of HBM (profiles/r05_decode_step_b64.txt: 49 us per layer at 64 sequences, 26 % of the step).
-  StepRegs r0, r1, r2, r3;
+  // Two register sets.  (Negative, r05: FOUR sets - three steps = 24 KB per wave in flight instead of one - on the theory that
+  // 8 KB per wave at ~2 us of loaded latency caps a CU at ~32 GB/s: 49.1 -> 52.3 us per layer at 64 sequences, 226 VGPRs.  The
+  // launch is not short of bytes in flight; r03's counters say the texture addresser spends 45 % of its cycles stalled by the
+  // cache behind it: 16 half-line K requests and 16 two-line V requests per step and wave.)
+  StepRegs r0, r1;
   load_step(r0, wave);                   // issued before the position has even arrived (fixed rows)
-  load_step(r1, wave + NW);
-  load_step(r2, wave + 2 * NW);
 
   const int slot = min(*p.step_ptr, p.cache_tokens - 1);
   const int ctx = slot + 1;
@@ -622,19 +621,15 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
     }
   };
 
-  // wave w: steps w, w + 8, w + 16, ... in that order (the summation order of r02-r04: results are bit-identical); the four
-  // register sets rotate, the loads are unconditional (a step index past the context is clamped to the last step: hot lines,
-  // no extra HBM traffic - a predicated load would make hipcc drain vmcnt at every branch)
-  const int last = max(nsteps - 1, 0);
-  for (int j = wave; j < nsteps; j += 4 * NW) {
-    load_step(r3, min(j + 3 * NW, last));
+  // wave w: steps w, w + 8, w + 16, ...; two register sets alternate (static indexing): the loads of the next step are
+  // in flight while the current one is consumed, and two waves share each SIMD
+  for (int j = wave; j < nsteps; j += 2 * NW) {
+    if (j + NW < nsteps) load_step(r1, j + NW);
     step(r0, j);
-    load_step(r0, min(j + 4 * NW, last));
-    if (j + NW < nsteps) step(r1, j + NW);
-    load_step(r1, min(j + 5 * NW, last));
-    if (j + 2 * NW < nsteps) step(r2, j + 2 * NW);
-    load_step(r2, min(j + 6 * NW, last));
-    if (j + 3 * NW < nsteps) step(r3, j + 3 * NW);
+    if (j + NW < nsteps) {
+      if (j + 2 * NW < nsteps) load_step(r0, j + 2 * NW);
+      step(r1, j + NW);
+    }
   }
 
   // ---- merge the eight waves

@@ -28,63 +28,7 @@
 //    producer's epilogue (a wave owns 32 columns of every row of its tile: block maximum = 8 lane-local values + two
 //    permlane swaps).  The per-row activation scale of r02-r04 needed the whole row (hence a finalisation launch).
 //    Weights keep their per-output-row f32 scale sw[n], applied in the epilogue.
-#include "common.hip.h"
-
-#define DS_BN 128                      // tile columns
-#define DS_ROWB 128                    // bytes per tile row and K-step (64 bf16 / 128 e4m3)
-#define DS_MAX_WG 256                  // one per CU
-#define DS_MAX_SEGS 16                 // segments a tile may be cut into
-#define DS_SSQ_LD 64                   // row stride of the ssq tile partials
-#define DS_CNT_BYTES 16384             // arrival counters: the first 16 KB of every workspace, whatever the shape - one
-                                       // workspace serves all projections of a step (N <= 4096 x 128 columns)
-
-enum { DS_PLAIN = 0, DS_SWIGLU = 1, DS_RESID_NORMW = 2 };
-
-struct DsArgs {
-  const char* A;         // [M][lda] bf16, or e4m3 bytes (FP8)
-  const char* W;         // [N][ldw] bf16, or e4m3 bytes (FP8)
-  const uint8_t* As;     // FP8: E8M0 block scales of A, [M][ldas], one per 32 columns
-  const float* sw;       // FP8: per-output-row weight scales [N]
-  float* part;           // segment blocks of split tiles
-  int* cnt;              // [tiles] arrival counters, zero between launches
-  void* C;               // main output (PLAIN: bf16 or f32 [M][ldc]; SWIGLU: bf16 [M][ldc] of N/2 columns; RESID: y) or null
-  bf16_t* Cw;            // RESID_NORMW: bf16(y * nw[n]) or null
-  uint8_t* Cq;           // MX copy of the row the next projection consumes (RESID: y * nw, SWIGLU: act) or null
-  uint8_t* Cqs;          // its E8M0 scales [M][ldcqs]
-  const bf16_t* bias;    // PLAIN: [N] or null
-  const bf16_t* R;       // RESID_NORMW: [M][ldr]
-  const bf16_t* nw;      // RESID_NORMW: [N]
-  const float* ssq_in;   // [tiles_in][DS_SSQ_LD] partial sums of squares of the row A was derived from, or null (rs = 1)
-  float* ssq_out;        // RESID_NORMW: [tiles][DS_SSQ_LD]
-  int M, N, lda, ldw, ldas, ldc, ldr, ldcq, ldcqs;
-  int nk_all, total, spb, lcm;
-  int mode, out_f32, tiles_in;
-  float inv_norm_dim, eps;
-};
-
-// global index of the segment that starts at step s0 of the (tile, K-step) sequence: the sequence is cut at every multiple
-// of nk (tile seams) and of spb (workgroup seams)
-__device__ __forceinline__ int ds_seg_id(int s0, int nk, int spb, int lcm) { return s0 / nk + s0 / spb - s0 / lcm; }
-
-// ---- 16-byte agent-coherent (sc1) accesses to the segment blocks: buffer instructions with the cache-policy operand
-__device__ __forceinline__ void ds_store_sc1(const __amdgpu_buffer_rsrc_t rs, unsigned off, f32x4 v) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, off, 0, 16 /* sc1 */);
-}
-__device__ __forceinline__ f32x4 ds_load_sc1(const __amdgpu_buffer_rsrc_t rs, unsigned off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16 /* sc1 */));
-}
-
-// E8M0 byte of the smallest power of two X with amax / X <= 448 (the e4m3 maximum); amax == 0 -> 2^-127 (all codes 0)
-__device__ __forceinline__ int ds_mx_scale_byte(float amax) {
-  const uint32_t u = __float_as_uint(amax);
-  const int E = (int)((u >> 23) & 0xff);                 // biased exponent of amax (0 for zero / denormal)
-  const uint32_t man = u & 0x7fffffu;
-  int b = E - ((man <= 0x600000u) ? 8 : 7);              // mantissa <= 1.75 -> amax / 2^(E - 8) <= 448
-  return b < 0 ? 0 : (b > 254 ? 254 : b);
-}
-__device__ __forceinline__ float ds_mx_inv_scale(int byte) {   // 2^(127 - byte), exact
-  return __uint_as_float((uint32_t)(254 - byte) << 23);
-}
+#include "decode_proj_common.hip.h"
 
 template <bool FP8, int MB>
 struct DsGeom {
@@ -119,7 +63,7 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
   __shared__ int tick_s[NSEG];
   __shared__ int segt_s[NSEG];
   __shared__ float rs_s[64];
-  __shared__ float red_s[4][MB * 16];
+  __shared__ float red_s[4][64];
   const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
   const int s0 = blockIdx.x * p.spb;
@@ -260,158 +204,7 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
   // ------------------------------------------------------------------ the finished tile: lane holds
   // D[n = n0 + 32 wn + 16 j + 4 h + r][m = 16 mb + l15], r = 0..3
   auto epilogue = [&](f32x4 (&acc)[MB][2], int tile) __attribute__((always_inline)) {
-    const int nb = tile * DS_BN + wn * 32 + 4 * h;   // column of (j = 0, r = 0)
-    if (p.mode == DS_SWIGLU) {
-      // j = 0: 16 gate columns, j = 1: the matching up columns -> act column (tile * 64 + 16 wn + 4 h + r)
-      const int o = tile * (DS_BN / 2) + wn * 16 + 4 * h;
-      const bool live_n = nb + 16 < p.N;
-      f32x4 sg = (f32x4){1.f, 1.f, 1.f, 1.f}, su = sg;
-      if (FP8 && live_n) { sg = *(const f32x4*)(p.sw + nb); su = *(const f32x4*)(p.sw + nb + 16); }
-      float act[MB][4];
-      float amax[MB];
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        amax[mb] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float gq = acc[mb][0][r] * (FP8 ? sg[r] * rs[mb] : rs[mb]), uq = acc[mb][1][r] * (FP8 ? su[r] * rs[mb] : rs[mb]);
-          // the bf16 value the unfused path handed on (the MX copy quantises that value, so both outputs agree)
-          act[mb][r] = bf2f(f2bf(silu_fast(gq) * uq));
-          amax[mb] = fmaxf(amax[mb], fabsf(act[mb][r]));
-        }
-      }
-      if (p.C) {
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const int m = mb * 16 + l15;
-          if (m < p.M && live_n) {
-            u32x2 q;
-            q[0] = pack2bf(act[mb][0], act[mb][1]);
-            q[1] = pack2bf(act[mb][2], act[mb][3]);
-            *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + o) = q;
-          }
-        }
-      }
-      if (p.Cq) {   // MX block = 32 act columns = this wave's 16 and its neighbour's (wn ^ 1)
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          amax[mb] = hmax4(live_n ? amax[mb] : 0.f);
-          if (h == 0) red_s[wn][mb * 16 + l15] = amax[mb];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int mb = 0; mb < MB; ++mb) {
-          const int m = mb * 16 + l15;
-          const int sb = ds_mx_scale_byte(fmaxf(red_s[wn][mb * 16 + l15], red_s[wn ^ 1][mb * 16 + l15]));
-          const float inv = ds_mx_inv_scale(sb);
-          if (m < p.M && live_n) {
-            int w = 0;
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(act[mb][0] * inv, act[mb][1] * inv, w, false);
-            w = __builtin_amdgcn_cvt_pk_fp8_f32(act[mb][2] * inv, act[mb][3] * inv, w, true);
-            *(uint32_t*)(p.Cq + (size_t)m * p.ldcq + o) = (uint32_t)w;
-            if (h == 0 && (wn & 1) == 0) p.Cqs[(size_t)m * p.ldcqs + (o >> 5)] = (uint8_t)sb;
-          }
-        }
-        __syncthreads();   // red_s is reused by the next tile's epilogue
-      }
-      return;
-    }
-    // ---- PLAIN / RESID_NORMW: 8 values per (lane, mb): columns nb + 16 j + r
-    f32x4 swv[2] = {(f32x4){1.f, 1.f, 1.f, 1.f}, (f32x4){1.f, 1.f, 1.f, 1.f}};
-    u32x2 bb[2] = {(u32x2){0u, 0u}, (u32x2){0u, 0u}}, nwv[2] = {(u32x2){0u, 0u}, (u32x2){0u, 0u}};
-    bool live[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = nb + 16 * j;
-      live[j] = n < p.N;
-      const int nc = live[j] ? n : 0;
-      if (FP8) swv[j] = *(const f32x4*)(p.sw + nc);
-      if (p.bias) bb[j] = *(const u32x2*)(p.bias + nc);
-      if (p.mode == DS_RESID_NORMW) nwv[j] = *(const u32x2*)(p.nw + nc);
-    }
-    float ssq[MB], amax[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-      const int m = mb * 16 + l15;
-      const bool row_ok = m < p.M;
-      ssq[mb] = 0.f;
-      amax[mb] = 0.f;
-      float u8[2][4];   // the value the next projection consumes (RESID: y * nw)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = nb + 16 * j;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[mb][j][r] * (FP8 ? swv[j][r] * rs[mb] : rs[mb]);
-        if (p.mode == DS_PLAIN) {
-          if (p.bias) {
-            v[0] += __uint_as_float(bb[j][0] << 16); v[1] += __uint_as_float(bb[j][0] & 0xffff0000u);
-            v[2] += __uint_as_float(bb[j][1] << 16); v[3] += __uint_as_float(bb[j][1] & 0xffff0000u);
-          }
-          if (row_ok && live[j]) {
-            if (p.out_f32) {
-              *(f32x4*)((float*)p.C + (size_t)m * p.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
-            } else {
-              u32x2 q;
-              q[0] = pack2bf(v[0], v[1]);
-              q[1] = pack2bf(v[2], v[3]);
-              *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = q;
-            }
-          }
-          continue;
-        }
-        // RESID_NORMW: y = bf16(v + R); yw = bf16(y * nw)
-        u32x2 rr = (u32x2){0u, 0u};
-        if (row_ok && live[j]) rr = *(const u32x2*)(p.R + (size_t)m * p.ldr + n);
-        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
-        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
-        u32x2 q;
-        q[0] = pack2bf(v[0], v[1]);
-        q[1] = pack2bf(v[2], v[3]);
-        const float y[4] = {__uint_as_float(q[0] << 16), __uint_as_float(q[0] & 0xffff0000u), __uint_as_float(q[1] << 16),
-                            __uint_as_float(q[1] & 0xffff0000u)};
-        const float g[4] = {__uint_as_float(nwv[j][0] << 16), __uint_as_float(nwv[j][0] & 0xffff0000u),
-                            __uint_as_float(nwv[j][1] << 16), __uint_as_float(nwv[j][1] & 0xffff0000u)};
-        u32x2 qw;
-        qw[0] = pack2bf(y[0] * g[0], y[1] * g[1]);
-        qw[1] = pack2bf(y[2] * g[2], y[3] * g[3]);
-        u8[j][0] = __uint_as_float(qw[0] << 16); u8[j][1] = __uint_as_float(qw[0] & 0xffff0000u);
-        u8[j][2] = __uint_as_float(qw[1] << 16); u8[j][3] = __uint_as_float(qw[1] & 0xffff0000u);
-        if (row_ok && live[j]) {
-          if (p.C) *(u32x2*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = q;
-          if (p.Cw) *(u32x2*)(p.Cw + (size_t)m * p.ldc + n) = qw;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ssq[mb] += y[r] * y[r];
-            amax[mb] = fmaxf(amax[mb], fabsf(u8[j][r]));
-          }
-        }
-      }
-      if (p.mode == DS_RESID_NORMW && p.Cq) {   // MX block = this wave's 32 columns of row m
-        const int sb = ds_mx_scale_byte(hmax4(amax[mb]));
-        const float inv = ds_mx_inv_scale(sb);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (!(row_ok && live[j])) continue;
-          int w = 0;
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(u8[j][0] * inv, u8[j][1] * inv, w, false);
-          w = __builtin_amdgcn_cvt_pk_fp8_f32(u8[j][2] * inv, u8[j][3] * inv, w, true);
-          *(uint32_t*)(p.Cq + (size_t)m * p.ldcq + nb + 16 * j) = (uint32_t)w;
-        }
-        if (h == 0 && row_ok && live[0]) p.Cqs[(size_t)m * p.ldcqs + ((tile * DS_BN + wn * 32) >> 5)] = (uint8_t)sb;
-      }
-    }
-    if (p.mode == DS_RESID_NORMW) {   // the tile's partial sum of squares per row: lanes (h), then waves, fixed order
-#pragma unroll
-      for (int mb = 0; mb < MB; ++mb) {
-        const float s4 = hsum4(ssq[mb]);
-        if (h == 0) red_s[wn][mb * 16 + l15] = s4;
-      }
-      __syncthreads();
-      if (tid < MB * 16 && tid < p.M)
-        p.ssq_out[(size_t)tile * DS_SSQ_LD + tid] = ((red_s[0][tid] + red_s[1][tid]) + red_s[2][tid]) + red_s[3][tid];
-      __syncthreads();
-    }
+    ds_epilogue<FP8, MB>(p, acc, 0, tile * DS_BN + wn * 32, rs, lane, red_s, wn);
   };
 
   // ------------------------------------------------------------------ one segment of this workgroup's range is complete
@@ -487,14 +280,11 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
   // owns the tile or holds its last ticket.  The per-set part is ONE copy of the code working on a copy of the set (a
   // register array cannot be indexed by a run-time set number; 32 moves per set are nothing next to NSEG inlined epilogues)
   auto finish_sets = [&](int lo, int hi) __attribute__((always_inline)) {
-    // the deferred RMSNorm's row factors: wave 0, lane = row, every tile's partial requested at once (coalesced 256-byte
-    // rows); the round trip hides under the partial stores' drain below.  (A first version computed rs in the kernel's
-    // prologue, 8 tiles per round trip: 4 dependent round trips = ~8 us in front of the weight stream.)
-    float sq[32];
-    if (p.ssq_in && wn == 0) {
-#pragma unroll
-      for (int t = 0; t < 32; ++t) sq[t] = p.ssq_in[(size_t)min(t, p.tiles_in - 1) * DS_SSQ_LD + lane];
-    }
+    // the deferred RMSNorm's row factors: every unit partial of a row requested at once (lane = row, coalesced 256-byte rows);
+    // the round trip hides under the partial stores' drain below.  (A first version computed rs in the kernel's prologue,
+    // 8 tiles per round trip: 4 dependent round trips = ~8 us in front of the weight stream.)
+    DsRowLoads sq;
+    ds_row_factor_loads(p, sq, wn, lane);
 #pragma unroll
     for (int sg = 0; sg < NSEG; ++sg)
       if (sg >= lo && sg < hi) {
@@ -502,17 +292,8 @@ __global__ __launch_bounds__(256, 1) void decode_proj_kernel(DsArgs p) {
         if (tid == 0) segt_s[sg] = seg_tile[sg];
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave's stores are out (write-through) ...
-    if (wn == 0) {
-      float tot = 0.f;
-      if (p.ssq_in) {
-#pragma unroll
-        for (int t = 0; t < 32; ++t)
-          if (t < p.tiles_in) tot += sq[t];
-        for (int t = 32; t < p.tiles_in; ++t) tot += p.ssq_in[(size_t)t * DS_SSQ_LD + lane];   // (norm dims > 4096: none today)
-      }
-      rs_s[lane] = p.ssq_in ? rsqrtf(tot * p.inv_norm_dim + p.eps) : 1.0f;
-    }
-    __syncthreads();                                    // ... before the lanes that signal for all of them
+    ds_row_factors(p, sq, red_s, rs_s, wn, lane);       // (two barriers: the second one is ...)
+                                                        // ... before the lanes that signal for all of them
     if (tid >= lo && tid < hi) {                        // one lane per set: the tickets travel together (one round trip)
       const int tile = segt_s[tid];
       int first, ns;
@@ -665,32 +446,11 @@ static int ds_launch(DsArgs p, int B, int K, void* ws, hipStream_t stream) {
   return vis_check_launch();
 }
 
-static int ds_check_common(const DsArgs& p, int B, int K, const void* ws, int mode, bool fp8) {
-  if (!p.A || !p.W || !ws || B <= 0 || B > 64 || p.N <= 0 || K <= 0) return VIS_ERR_ARG;
-  if (K % (fp8 ? 128 : 64) != 0 || p.N % 4 != 0) return VIS_ERR_ARG;
-  if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)ws) & 15) return VIS_ERR_ARG;
-  if (mode != DS_PLAIN && mode != DS_SWIGLU && mode != DS_RESID_NORMW) return VIS_ERR_ARG;
-  if (mode == DS_PLAIN && (!p.C || p.R || p.nw || p.Cw || p.Cq || p.ssq_out || p.ldc % 4 != 0)) return VIS_ERR_ARG;
-  if (mode == DS_SWIGLU && (p.N % 64 != 0 || p.bias || p.R || p.nw || p.Cw || p.ssq_out || p.out_f32 || (!p.C && !p.Cq) || p.ldc % 4 != 0))
-    return VIS_ERR_ARG;
-  if (mode == DS_RESID_NORMW && (!p.R || !p.nw || !p.ssq_out || p.bias || p.out_f32 || (!p.C && !p.Cw && !p.Cq) ||
-                                 p.ldc % 4 != 0 || p.ldr % 4 != 0))
-    return VIS_ERR_ARG;
-  if ((p.Cq != nullptr) != (p.Cqs != nullptr) || (p.Cq && (p.ldcq % 4 != 0 || ((uintptr_t)p.Cq & 3)))) return VIS_ERR_ARG;
-  if (p.Cq && mode == DS_PLAIN) return VIS_ERR_ARG;
-  if (p.Cq && (mode == DS_RESID_NORMW ? p.N % 32 : p.N % 64) != 0) return VIS_ERR_ARG;
-  if (((uintptr_t)p.C | (uintptr_t)p.Cw | (uintptr_t)p.bias | (uintptr_t)p.R | (uintptr_t)p.nw) & 7) return VIS_ERR_ARG;
-  if (p.out_f32 && ((uintptr_t)p.C & 15)) return VIS_ERR_ARG;
-  if (p.ssq_in && p.tiles_in <= 0) return VIS_ERR_ARG;
-  if (((uintptr_t)p.ssq_in | (uintptr_t)p.ssq_out) & 3) return VIS_ERR_ARG;
-  return VIS_OK;
-}
-
 // Batched decode projection with its epilogue in the same launch (see the top of this file).
 //   mode VIS_DP_PLAIN       C[b][n]   = (x W^T)[b][n] * rs[b] + bias[n]                      bf16, or f32 when out_f32
 //   mode VIS_DP_SWIGLU      C[b][o]   = silu(g * rs[b]) * (u * rs[b]) over the 16-row interleaved gate/up weight (N / 2 outputs)
-//   mode VIS_DP_RESID_NORMW C = y = bf16(x W^T + R);  Cw = bf16(y * nw[n]);  ssq_out[n / 128][b] = sum of y^2 over the tile
-// rs[b] = rsqrt(sum_t ssq_in[t][b] / norm_dim + eps) when ssq_in != NULL (tiles_in tiles), else 1.
+//   mode VIS_DP_RESID_NORMW C = y = bf16(x W^T + R);  Cw = bf16(y * nw[n]);  ssq_out[n / 32][b] = sum of y^2 over the 32-column unit
+// rs[b] = rsqrt(sum_u ssq_in[u][b] / norm_dim + eps) when ssq_in != NULL (tiles_in = norm_dim / 32 units <= 128), else 1.
 // Cq / Cqs (SWIGLU, RESID_NORMW; may be NULL): the row the NEXT projection consumes (act, or y * nw) as MX blocks - e4m3
 // bytes [B][ldcq] + one E8M0 scale byte per 32 columns [B][ldcqs] - for a following vis_decode_proj_fp8.
 extern "C" int vis_decode_proj_bf16(const void* A, const void* W, void* ws, void* C, void* Cw, void* Cq, void* Cqs,
@@ -735,8 +495,8 @@ extern "C" int vis_decode_proj_fp8(const void* Aq, const void* As, const void* W
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Head of a batched decode step: x[b] = table[ids[b]] (embedding lookup, clamped like vis_gather_rows); xw = bf16(x * nw);
-// ssq[n / 128][b] = the tile's sum of x^2 - the operands the first projection (vis_decode_proj_*) expects; optionally the
-// MX copy of xw.  One workgroup per sequence.
+// ssq[n / 32][b] = the 32-column unit's sum of x^2 - the operands the first projection (vis_decode_proj_*) expects; optionally
+// the MX copy of xw.  One workgroup per sequence.
 struct PrepArgs {
   const bf16_t* table;
   const int* ids;
@@ -753,7 +513,7 @@ __global__ __launch_bounds__(256) void decode_prep_rows_kernel(PrepArgs p) {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int id = min(max(p.ids[b], 0), p.rows - 1);
   const bf16_t* src = p.table + (size_t)id * p.H;
-  // 8 columns per thread and pass; a 128-column tile = 16 consecutive threads, an MX block = 4
+  // 8 columns per thread and pass; a 32-column unit (= an MX block) = 4 consecutive threads
   for (int c0 = 0; c0 < p.H; c0 += 256 * 8) {
     const int c = c0 + tid * 8;
     const bool ok = c < p.H;
@@ -773,12 +533,10 @@ __global__ __launch_bounds__(256) void decode_prep_rows_kernel(PrepArgs p) {
       *(u32x4*)(p.x + (size_t)b * p.ldx + c) = raw;
       if (p.xw) *(u32x4*)(p.xw + (size_t)b * p.ldx + c) = pack8(o);
     }
-    // tile sums: 16 lanes of one DPP row
+    // unit sums (32 columns = 4 lanes of one quad)
     ss += VIS_DPP(ss, 0xB1);
     ss += VIS_DPP(ss, 0x4E);
-    ss += VIS_DPP(ss, 0x141);
-    ss += VIS_DPP(ss, 0x140);
-    if (ok && (tid & 15) == 0) p.ssq[(size_t)(c >> 7) * DS_SSQ_LD + b] = ss;
+    if (ok && (tid & 3) == 0) p.ssq[(size_t)(c >> 5) * DS_SSQ_LD + b] = ss;
     if (p.xq) {
       am = fmaxf(am, VIS_DPP(am, 0xB1));
       am = fmaxf(am, VIS_DPP(am, 0x4E));

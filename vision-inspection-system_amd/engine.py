@@ -198,16 +198,21 @@ class Qwen2VLEngine:
             self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
             self.b_xn = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_xn2 = torch.empty((Bm, H), dtype=bf, device=dev)
-        # Batched decode, r05: every projection is ONE launch (vis_decode_proj_*: stream + split-K reduction + epilogue, the
-        # RMSNorm split into the producer's per-column and the consumer's per-row factor; csrc/decode_stream.hip).
-        # VIS_DECODE_FUSED=0 keeps the r02-r04 pair of launches per projection (stream kernel + finalisation) for A/B.
-        self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "1") != "0"
+        # Batched decode, r05 experiment (VIS_DECODE_FUSED=1, OFF by default): every projection as ONE launch - stream + split-K
+        # reduction + epilogue (vis_decode_proj_*: stream-K ranges with a last-arriver reduction, or whole-K column slabs), the
+        # RMSNorm split into the producer's per-column and the consumer's per-row factor; csrc/decode_stream.hip,
+        # csrc/decode_colpar.hip.  Correct and tested, but NOT faster: a cross-CU reduction costs three dependent memory round
+        # trips wherever it runs, and the finalisation launch it replaces already sits at the ~5 us floor of a dependent
+        # load -> store kernel (profiles/r05_decode_step_*.txt: 64 sequences 5.37 -> 6.4 ms per step).
+        self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "0") == "1"
         if self.fused_proj:
             self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)        # x * ln1_w of the next layer (A operand of qkv / lm_head)
             self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)       # x2 * ln2_w (A operand of gate/up)
-            self.b_ssq1 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
-            self.b_ssq2 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
-        elif Bm > 1:
+            self.b_ssq1 = torch.zeros((H // hip.SSQ_UNIT, hip.SSQ_LD), dtype=torch.float32, device=dev)
+            self.b_ssq2 = torch.zeros((H // hip.SSQ_UNIT, hip.SSQ_LD), dtype=torch.float32, device=dev)
+        if Bm > 1 and not (self.fused_proj and decode_weights == "fp8"):
+            # split-K slabs of the r02-r04 pair of launches: the whole step with VIS_DECODE_FUSED=0, and the bf16 down
+            # projection at many sequences in the fused step (_decode_step_fused)
             self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
                                       device=dev)   # 16 stream-K slots x (16 or 32) rows
         self.decode_weights = decode_weights
@@ -1135,9 +1140,21 @@ class Qwen2VLEngine:
         if fp8:
             xq, xqs, x2q, x2qs = self.b_xq[:B], self.b_xqs[:B], self.b_x2q[:B], self.b_x2qs[:B]
             aq, aqs = self.b_actq[:B], self.b_actqs[:B]
+        # Long-K, few-column projections at many sequences (7B down at 33+ sequences: K = 18944, 28 column tiles) keep the
+        # r02-r04 pair - stream-K slabs + the row-owning finalisation, which then also applies the next RMSNorm itself (xw holds
+        # the NORMALISED row, its consumer takes no row factor): a column slab per workgroup would stream 2.4 MB of x each, and
+        # the in-kernel reduction of the stream-K form costs more than the finalisation launch it saves (64 vs 33 + 5 us,
+        # profiles/r05_decode_step_b64_streamk.txt).  VIS_DOWN_PAIR=0 forces the single launch (A/B).
+        down_pair = (not fp8) and hasattr(self, "b_part") and os.environ.get("VIS_DOWN_PAIR", "1") != "0" and \
+            hip.decode_proj_form(B, H, cfg.intermediate, hip.DP_RESID_NORMW, False, False) == "streamk"
+        s1_in = None if down_pair else s1
         if not projections_only:
-            hip.decode_prep_rows(w.embed, self.cur_b[:B], w.llm[0].ln1_w, x, None if fp8 else xw, s1,
-                                 xq if fp8 else None, xqs if fp8 else None)
+            if down_pair:
+                hip.gather_rows(w.embed, self.cur_b[:B], x)
+                hip.rmsnorm(x, w.llm[0].ln1_w, eps, out=xw)
+            else:
+                hip.decode_prep_rows(w.embed, self.cur_b[:B], w.llm[0].ln1_w, x, None if fp8 else xw, s1,
+                                     xq if fp8 else None, xqs if fp8 else None)
         n_layers = len(w.llm)
         for li, lw in enumerate(w.llm):
             next_norm = w.llm[li + 1].ln1_w if li + 1 < n_layers else w.final_norm_w
@@ -1145,7 +1162,7 @@ class Qwen2VLEngine:
                 q8 = self.q8[li]
                 hip.decode_proj_fp8(xq, xqs, *q8["qkv_w"], ws, hip.DP_PLAIN, out=qkv, bias=lw.qkv_b, ssq_in=s1, norm_dim=H, eps=eps)
             else:
-                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=qkv, bias=lw.qkv_b, ssq_in=s1, norm_dim=H, eps=eps)
+                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=qkv, bias=lw.qkv_b, ssq_in=s1_in, norm_dim=H, eps=eps)
             if not projections_only:
                 hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
                                 self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
@@ -1160,12 +1177,17 @@ class Qwen2VLEngine:
             else:
                 hip.decode_proj(att, lw.o_w, ws, hip.DP_RESID_NORMW, out=x2, out_w=x2w, residual=x, norm_w=lw.ln2_w, ssq_out=s2)
                 hip.decode_proj(x2w, lw.gateup_w, ws, hip.DP_SWIGLU, out=act, ssq_in=s2, norm_dim=H, eps=eps)
-                hip.decode_proj(act, lw.down_w, ws, hip.DP_RESID_NORMW, out=x, out_w=xw, residual=x2, norm_w=next_norm,
-                                ssq_out=s1)
+                if down_pair:
+                    ks = hip.decode_gemm(act, lw.down_w, part=self.b_part)
+                    if not projections_only:
+                        hip.skinny_finalize(self.b_part, ks, x, H, residual=x2, norm_w=next_norm, yn=xw, eps=eps)
+                else:
+                    hip.decode_proj(act, lw.down_w, ws, hip.DP_RESID_NORMW, out=x, out_w=xw, residual=x2, norm_w=next_norm,
+                                    ssq_out=s1)
         if fp8:
             hip.decode_proj_fp8(xq, xqs, *self.q8_lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1, norm_dim=H, eps=eps)
         else:
-            hip.decode_proj(xw, w.lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1, norm_dim=H, eps=eps)
+            hip.decode_proj(xw, w.lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1_in, norm_dim=H, eps=eps)
         if not projections_only:
             hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                        self.temperature, self.seed)

@@ -58,6 +58,9 @@ _SIGS = {
     "vis_decode_proj_bf16": "p" * 12 + "i" * 13 + "f" + "p",
     "vis_decode_proj_fp8": "p" * 14 + "i" * 14 + "f" + "p",
     "vis_decode_prep_rows": "p" * 8 + "i" * 6 + "p",
+    "vis_decode_proj_colpar_covers": "iii",
+    "vis_decode_proj_colpar_bf16": "p" * 11 + "i" * 13 + "f" + "p",
+    "vis_decode_proj_colpar_fp8": "p" * 13 + "i" * 14 + "f" + "p",
     "vis_patchify_u8": "pp" + "iiii" + "pp" + "p",
     "vis_resize_rgb_u8": "ppp" + "iiii" + "ppi" + "ppi" + "p",
     "vis_jpeg_to_rgb": "pppp" + "i" * 11 + "p",
@@ -116,6 +119,56 @@ class ChainStalled(HipLibraryError):
 
 _lib: Optional[ctypes.CDLL] = None
 
+# Optional host-side accounting of the time a thread spends INSIDE the library's entry points (launch + argument marshalling;
+# the GIL is released during the C call): hip.call_trace_start() / call_trace_stop() -> {thread id: [calls, seconds]}.  Used
+# by the seam blocks of bench.py to tell "the launch thread is busy launching" from "the launch thread is waiting" (VERDICT r4
+# item 6b); off by default (one global read per call).
+_CALL_TRACE: Optional[dict] = None
+
+
+class _Entry:
+    """ctypes function + the optional per-thread call accounting."""
+    __slots__ = ("fn",)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, *args):
+        tr = _CALL_TRACE
+        if tr is None:
+            return self.fn(*args)
+        import threading
+        import time
+        t0 = time.perf_counter()
+        rc = self.fn(*args)
+        e = tr.setdefault(threading.get_ident(), [0, 0.0])
+        e[0] += 1
+        e[1] += time.perf_counter() - t0
+        return rc
+
+
+class _Lib:
+    """Attribute access to the wrapped entry points (same spelling as the ctypes.CDLL it replaces)."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        e = _Entry(getattr(self._cdll, name))
+        object.__setattr__(self, name, e)
+        return e
+
+
+def call_trace_start() -> None:
+    global _CALL_TRACE
+    _CALL_TRACE = {}
+
+
+def call_trace_stop() -> dict:
+    global _CALL_TRACE
+    tr, _CALL_TRACE = _CALL_TRACE, None
+    return tr or {}
+
 
 def exported_symbols() -> list:
     return list(_SIGS)
@@ -137,8 +190,8 @@ def load() -> ctypes.CDLL:
         fn.argtypes = [_CT[c] for c in sig]
     lib.vis_decode_chain_ws_bytes.restype = ctypes.c_longlong
     lib.vis_decode_proj_ws_bytes.restype = ctypes.c_longlong
-    _lib = lib
-    return lib
+    _lib = _Lib(lib)
+    return _lib
 
 
 def _check(rc: int, name: str) -> None:
@@ -828,7 +881,8 @@ def argmax(logits: torch.Tensor, ws_val: torch.Tensor, ws_idx: torch.Tensor, tok
 
 
 DP_PLAIN, DP_SWIGLU, DP_RESID_NORMW = 0, 1, 2
-SSQ_LD = 64      # row stride of the [tiles][64] f32 sum-of-squares partials (csrc/decode_stream.hip: DS_SSQ_LD)
+SSQ_LD = 64      # row stride of the [units][64] f32 sum-of-squares partials, one per 32 columns (csrc/decode_proj_common.hip.h)
+SSQ_UNIT = 32
 
 
 def decode_proj_ws(device, B: int, N: int, K: int, fp8: bool = False) -> torch.Tensor:
@@ -838,6 +892,20 @@ def decode_proj_ws(device, B: int, N: int, K: int, fp8: bool = False) -> torch.T
     if n <= 0:
         raise HipLibraryError(f"decode_proj_ws: unsupported shape B={B} N={N} K={K} fp8={fp8}")
     return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def decode_proj_form(B: int, N: int, K: int, mode: int, mx_out: bool, fp8: bool) -> str:
+    """'colpar' or 'streamk' for one batched-decode projection.  The column-parallel form (no cross-workgroup reduction) needs
+    every workgroup to stream all of x: taken when it covers the shape and a workgroup's x traffic (K-steps x the x tile) stays
+    under 1.5 MB - i.e. everything but long-K projections at many sequences (7B down: K = 18944, 2.4 MB at 64 sequences)."""
+    forced = os.environ.get("VIS_DECODE_PROJ_FORM", "")
+    if forced in ("colpar", "streamk") and (forced == "streamk" or load().vis_decode_proj_colpar_covers(N, mode, 1 if mx_out else 0)):
+        return forced
+    if not load().vis_decode_proj_colpar_covers(N, mode, 1 if mx_out else 0):
+        return "streamk"
+    steps = K // (128 if fp8 else 64)
+    x_tile = 8192 if B > 32 else 4096
+    return "colpar" if steps * x_tile <= 1536 * 1024 else "streamk"
 
 
 def _dp_common(name, B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm_w, ssq_in, ssq_out, ws, need):
@@ -859,12 +927,12 @@ def _dp_common(name, B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm
         raise HipLibraryError(f"{name}: bad bias")
     if norm_w is not None and (norm_w.dtype != torch.bfloat16 or norm_w.numel() != N):
         raise HipLibraryError(f"{name}: bad norm_w")
-    for t, tiles in ((ssq_in, None), (ssq_out, (N + 127) // 128)):
+    for t, tiles in ((ssq_in, None), (ssq_out, (N + SSQ_UNIT - 1) // SSQ_UNIT)):
         if t is not None and (t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != SSQ_LD or not t.is_contiguous()
                               or (tiles is not None and t.shape[0] < tiles)):
-            raise HipLibraryError(f"{name}: ssq buffers are f32 [tiles, {SSQ_LD}]")
-    if ws.dtype != torch.uint8 or ws.numel() < need:
-        raise HipLibraryError(f"{name}: workspace too small ({ws.numel()} < {need})")
+            raise HipLibraryError(f"{name}: ssq buffers are f32 [columns / 32, {SSQ_LD}]")
+    if need and (ws is None or ws.dtype != torch.uint8 or ws.numel() < need):
+        raise HipLibraryError(f"{name}: workspace too small ({0 if ws is None else ws.numel()} < {need})")
 
 
 def decode_proj(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, mode: int = DP_PLAIN,
@@ -872,25 +940,34 @@ def decode_proj(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, mode: int = 
                 out_q: Optional[torch.Tensor] = None, out_qs: Optional[torch.Tensor] = None,
                 bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                 norm_w: Optional[torch.Tensor] = None, ssq_in: Optional[torch.Tensor] = None,
-                ssq_out: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6) -> None:
-    """Batched-decode projection with its epilogue in the same launch (vis_decode_proj_bf16; include/vis_hip.h): x [B, K] bf16,
-    w [N, K] bf16.  DP_PLAIN: out = x w^T * rs + bias (bf16 / f32).  DP_SWIGLU: out [B, N/2].  DP_RESID_NORMW: out = y =
-    x w^T + residual, out_w = y * norm_w, ssq_out = per-tile sums of y^2.  rs from ssq_in (norm_dim columns) or 1."""
+                ssq_out: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6, form: str = "auto") -> None:
+    """Batched-decode projection with its epilogue in the same launch (vis_decode_proj_bf16 / vis_decode_proj_colpar_bf16;
+    include/vis_hip.h): x [B, K] bf16, w [N, K] bf16.  DP_PLAIN: out = x w^T * rs + bias (bf16 / f32).  DP_SWIGLU: out [B, N/2].
+    DP_RESID_NORMW: out = y = x w^T + residual, out_w = y * norm_w, ssq_out = per-unit (32 columns) sums of y^2.  rs from
+    ssq_in (norm_dim columns) or 1.  form: "colpar" (whole-K column slabs, no workspace), "streamk" (needs ws) or "auto"."""
     _bf16(x, "decode_proj x"); _bf16(w, "decode_proj w")
     B, K = x.shape
     N = w.shape[0]
     if w.shape[1] != K or x.stride(1) != 1 or w.stride(1) != 1:
         raise HipLibraryError("decode_proj: bad operand shapes")
     lib = load()
+    if form == "auto":
+        form = decode_proj_form(B, N, K, mode, out_q is not None, False)
+    colpar = form == "colpar"
     _dp_common("decode_proj", B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm_w, ssq_in, ssq_out, ws,
-               int(lib.vis_decode_proj_ws_bytes(B, N, K, 0)))
+               0 if colpar else int(lib.vis_decode_proj_ws_bytes(B, N, K, 0)))
     ldc = out.stride(0) if out is not None else 0
+    tail = (B, N, K, x.stride(0), w.stride(0), ldc, residual.stride(0) if residual is not None else 0,
+            out_q.stride(0) if out_q is not None else 0, out_qs.stride(0) if out_qs is not None else 0,
+            mode, 1 if (out is not None and out.dtype == torch.float32) else 0,
+            ssq_in.shape[0] if ssq_in is not None else 0, norm_dim, eps, _stream())
+    if colpar:
+        rc = lib.vis_decode_proj_colpar_bf16(_ptr(x), _ptr(w), _ptr(out), _ptr(out_w), _ptr(out_q), _ptr(out_qs), _ptr(bias),
+                                             _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), *tail)
+        _check(rc, "vis_decode_proj_colpar_bf16")
+        return
     rc = lib.vis_decode_proj_bf16(_ptr(x), _ptr(w), _ptr(ws), _ptr(out), _ptr(out_w), _ptr(out_q), _ptr(out_qs), _ptr(bias),
-                                  _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), B, N, K, x.stride(0), w.stride(0),
-                                  ldc, residual.stride(0) if residual is not None else 0,
-                                  out_q.stride(0) if out_q is not None else 0, out_qs.stride(0) if out_qs is not None else 0,
-                                  mode, 1 if (out is not None and out.dtype == torch.float32) else 0,
-                                  ssq_in.shape[0] if ssq_in is not None else 0, norm_dim, eps, _stream())
+                                  _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), *tail)
     _check(rc, "vis_decode_proj_bf16")
 
 
@@ -899,7 +976,7 @@ def decode_proj_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, sw: to
                     out_q: Optional[torch.Tensor] = None, out_qs: Optional[torch.Tensor] = None,
                     bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                     norm_w: Optional[torch.Tensor] = None, ssq_in: Optional[torch.Tensor] = None,
-                    ssq_out: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6) -> None:
+                    ssq_out: Optional[torch.Tensor] = None, norm_dim: int = 0, eps: float = 1e-6, form: str = "auto") -> None:
     """fp8 form: xq [B, K] e4m3 bytes + xs [B, >= K/32] E8M0 block scales (MX blocks of 32 columns), wq [N, K] e4m3 + sw [N] f32."""
     B, K = xq.shape
     N = wq.shape[0]
@@ -908,16 +985,23 @@ def decode_proj_fp8(xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, sw: to
             or sw.dtype != torch.float32 or sw.numel() != N:
         raise HipLibraryError("decode_proj_fp8: bad operands")
     lib = load()
+    if form == "auto":
+        form = decode_proj_form(B, N, K, mode, out_q is not None, True)
+    colpar = form == "colpar"
     _dp_common("decode_proj_fp8", B, N, mode, out, out_w, out_q, out_qs, bias, residual, norm_w, ssq_in, ssq_out, ws,
-               int(lib.vis_decode_proj_ws_bytes(B, N, K, 1)))
+               0 if colpar else int(lib.vis_decode_proj_ws_bytes(B, N, K, 1)))
     ldc = out.stride(0) if out is not None else 0
+    tail = (B, N, K, xq.stride(0), xs.stride(0), wq.stride(0), ldc, residual.stride(0) if residual is not None else 0,
+            out_q.stride(0) if out_q is not None else 0, out_qs.stride(0) if out_qs is not None else 0,
+            mode, 1 if (out is not None and out.dtype == torch.float32) else 0,
+            ssq_in.shape[0] if ssq_in is not None else 0, norm_dim, eps, _stream())
+    if colpar:
+        rc = lib.vis_decode_proj_colpar_fp8(_ptr(xq), _ptr(xs), _ptr(wq), _ptr(sw), _ptr(out), _ptr(out_w), _ptr(out_q),
+                                            _ptr(out_qs), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), *tail)
+        _check(rc, "vis_decode_proj_colpar_fp8")
+        return
     rc = lib.vis_decode_proj_fp8(_ptr(xq), _ptr(xs), _ptr(wq), _ptr(sw), _ptr(ws), _ptr(out), _ptr(out_w), _ptr(out_q),
-                                 _ptr(out_qs), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), B, N, K,
-                                 xq.stride(0), xs.stride(0), wq.stride(0), ldc,
-                                 residual.stride(0) if residual is not None else 0,
-                                 out_q.stride(0) if out_q is not None else 0, out_qs.stride(0) if out_qs is not None else 0,
-                                 mode, 1 if (out is not None and out.dtype == torch.float32) else 0,
-                                 ssq_in.shape[0] if ssq_in is not None else 0, norm_dim, eps, _stream())
+                                 _ptr(out_qs), _ptr(bias), _ptr(residual), _ptr(norm_w), _ptr(ssq_in), _ptr(ssq_out), *tail)
     _check(rc, "vis_decode_proj_fp8")
 
 
@@ -931,7 +1015,7 @@ def decode_prep_rows(table: torch.Tensor, ids: torch.Tensor, norm_w: torch.Tenso
     if table.dim() != 2 or table.shape[1] != H or not table.is_contiguous() or ids.dtype != torch.int32 or ids.numel() != B \
             or x.stride(1) != 1 or norm_w.numel() != H or (xw is not None and (xw.shape != x.shape or xw.stride() != x.stride()
                                                                                  or xw.dtype != torch.bfloat16)) \
-            or ssq.dtype != torch.float32 or ssq.dim() != 2 or ssq.shape[1] != SSQ_LD or ssq.shape[0] * 128 < H \
+            or ssq.dtype != torch.float32 or ssq.dim() != 2 or ssq.shape[1] != SSQ_LD or ssq.shape[0] * SSQ_UNIT < H \
             or not ssq.is_contiguous():
         raise HipLibraryError("decode_prep_rows: bad shapes")
     if (xq is None) != (xqs is None) or (xq is not None and (xq.dtype != torch.uint8 or xqs.dtype != torch.uint8

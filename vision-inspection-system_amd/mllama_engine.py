@@ -148,21 +148,21 @@ class MllamaEngine:
             self.b_qkv = torch.empty((Bm, nq), dtype=bf, device=dev)
             self.b_attn = torch.empty((Bm, Hq * D), dtype=bf, device=dev)
             self.b_act = torch.empty((Bm, cfg.intermediate), dtype=bf, device=dev)
-        # r05: every batched-decode projection is ONE launch (vis_decode_proj_bf16: stream + split-K reduction + epilogue;
-        # Qwen2VLEngine._decode_step_fused).  VIS_DECODE_FUSED=0 keeps the r02-r04 pair of launches per projection (A/B).
-        self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "1") != "0"
+        # r05 experiment, OFF by default (VIS_DECODE_FUSED=1): every batched-decode projection as ONE launch (vis_decode_proj_bf16:
+        # stream + split-K reduction + epilogue; Qwen2VLEngine.__init__ says why it is not the default).
+        self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "0") == "1"
         if self.fused_proj:
             self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)
-            self.b_ssq1 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
-            self.b_ssq2 = torch.zeros((H // 128, hip.SSQ_LD), dtype=torch.float32, device=dev)
+            self.b_ssq1 = torch.zeros((H // hip.SSQ_UNIT, hip.SSQ_LD), dtype=torch.float32, device=dev)
+            self.b_ssq2 = torch.zeros((H // hip.SSQ_UNIT, hip.SSQ_LD), dtype=torch.float32, device=dev)
             lib = hip.load()
             need = max(int(lib.vis_decode_proj_ws_bytes(Bm, n, k, 0)) for n, k in
                        ((nq, H), (H, Hq * D), (2 * cfg.intermediate, H), (H, cfg.intermediate), (cfg.vocab, H)))
             if need <= 0:
                 raise ValueError("vis_decode_proj_ws_bytes refused a projection shape of this model")
             self.b_proj_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
-        elif Bm > 1:
+        if Bm > 1:      # split-K slabs: the whole step with VIS_DECODE_FUSED=0, the long-K down projection at many sequences otherwise
             self.b_part = torch.empty(16 * hip.part_rows(Bm) * max(nq, H, 2 * cfg.intermediate), dtype=torch.float32,
                                       device=dev)
         # Single-sequence decode: the head of every SELF-attention layer (qkv projection -> rope / append / attention -> o
@@ -754,26 +754,39 @@ class MllamaEngine:
         s1, s2, ws = self.b_ssq1, self.b_ssq2, self.b_proj_ws
         cosb = self.cos_t.unsqueeze(0).expand(B, -1, -1)          # batch stride 0: the rope table is shared
         sinb = self.sin_t.unsqueeze(0).expand(B, -1, -1)
-        hip.decode_prep_rows(w.embed, self.cur_b[:B], w.layers[0].ln1_w, x, xw, s1)
+        # the long-K down projection at many sequences keeps the r02-r04 pair of launches (Qwen2VLEngine._decode_step_fused)
+        down_pair = os.environ.get("VIS_DOWN_PAIR", "1") != "0" and \
+            hip.decode_proj_form(B, H, cfg.intermediate, hip.DP_RESID_NORMW, False, False) == "streamk"
+        s1_in = None if down_pair else s1
+        if down_pair:
+            hip.gather_rows(w.embed, self.cur_b[:B], x)
+            hip.rmsnorm(x, w.layers[0].ln1_w, eps, out=xw)
+        else:
+            hip.decode_prep_rows(w.embed, self.cur_b[:B], w.layers[0].ln1_w, x, xw, s1)
         n_layers = len(w.layers)
         si = ci = 0
         for li, lw in enumerate(w.layers):
             if lw.cross:
                 q = qkv[:, :Hq * D]
-                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=q, ssq_in=s1, norm_dim=H, eps=eps)
+                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=q, ssq_in=s1_in, norm_dim=H, eps=eps)
                 hip.decode_cross_attn_batch(q, lw.q_norm, self.xk_b[:B, ci], self.xv_b[:B, ci], self.nkeys_b[:B],
                                             self.part_o, self.part_ml, att, Hq, Hkv, D, self.xsplit, scale, eps)
                 ci += 1
             else:
-                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=qkv, ssq_in=s1, norm_dim=H, eps=eps)
+                hip.decode_proj(xw, lw.qkv_w, ws, hip.DP_PLAIN, out=qkv, ssq_in=s1_in, norm_dim=H, eps=eps)
                 hip.decode_attn(qkv, cosb, sinb, self.kcache_b[:B, si], self.vcache_b[:B, si], self.step_b[:B],
                                 self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
                 si += 1
             hip.decode_proj(att, lw.o_w, ws, hip.DP_RESID_NORMW, out=x2, out_w=x2w, residual=x, norm_w=lw.ln2_w, ssq_out=s2)
             hip.decode_proj(x2w, lw.gateup_w, ws, hip.DP_SWIGLU, out=act, ssq_in=s2, norm_dim=H, eps=eps)
             next_norm = w.layers[li + 1].ln1_w if li + 1 < n_layers else w.norm_w
-            hip.decode_proj(act, lw.down_w, ws, hip.DP_RESID_NORMW, out=x, out_w=xw, residual=x2, norm_w=next_norm, ssq_out=s1)
-        hip.decode_proj(xw, w.lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1, norm_dim=H, eps=eps)
+            if down_pair:
+                ks = hip.decode_gemm(act, lw.down_w, part=self.b_part)
+                hip.skinny_finalize(self.b_part, ks, x, H, residual=x2, norm_w=next_norm, yn=xw, eps=eps)
+            else:
+                hip.decode_proj(act, lw.down_w, ws, hip.DP_RESID_NORMW, out=x, out_w=xw, residual=x2, norm_w=next_norm,
+                                ssq_out=s1)
+        hip.decode_proj(xw, w.lm_head, ws, hip.DP_PLAIN, out=self.logits_b[:B], ssq_in=s1_in, norm_dim=H, eps=eps)
         hip.argmax(self.logits_b[:B], self.ws_val, self.ws_idx, self.tokens_b[:B], self.cur_b[:B], self.step_b[:B],
                    self.temperature, self.seed)
 
