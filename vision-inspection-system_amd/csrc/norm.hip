@@ -9,66 +9,78 @@
 
 #define NORM_MAX_CHUNKS 10  // per lane: supports N <= 64*8*10 = 5120
 
-template <bool LAYERNORM>
+// r05: every load of a row is UNCONDITIONAL (clamped chunk / row index, contributions masked afterwards)
+// and issued before the first use - the r01-r04 kernels guarded each 16-byte load with `if (c < nch)`, which makes hipcc drain
+// vmcnt at every guard (the loads of a row went out one round trip at a time: 2.7 - 4.6 TB/s).  CH = chunks per lane is a
+// template parameter (1280 columns: 3, 3584: 7), ROWS rows per wave keep more bytes in flight on short rows.
+template <bool LAYERNORM, int CH, int ROWS>
 __global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict__ x,
                                                         const bf16_t* __restrict__ w,
                                                         const bf16_t* __restrict__ b,
                                                         bf16_t* __restrict__ y, int rows, int N,
                                                         int ldx, int ldy, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= rows) return;
   const int nch = N >> 3;  // 16-byte chunks per row
-  const bf16_t* xr = x + (size_t)row * ldx;
-  float v[NORM_MAX_CHUNKS][8];
-  float s = 0.f, ss = 0.f;
+  u32x4 raw[ROWS][CH], wraw[CH], braw[CH];
 #pragma unroll
-  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
-    const int c = lane + i * 64;
-    if (c < nch) {
-      const u32x4 raw = *(const u32x4*)(xr + c * 8);
-      unpack8(raw, v[i]);
+  for (int r = 0; r < ROWS; ++r) {
+    const bf16_t* xr = x + (size_t)min(row0 + r, rows - 1) * ldx;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        s += v[i][e];
-        ss += v[i][e] * v[i][e];
-      }
-    }
+    for (int i = 0; i < CH; ++i) raw[r][i] = *(const u32x4*)(xr + min(lane + i * 64, nch - 1) * 8);
   }
-  s = wave_sum(s);
-  ss = wave_sum(ss);
-  const float inv_n = 1.0f / (float)N;
-  float mean = 0.f, rstd;
-  if (LAYERNORM) {
-    mean = s * inv_n;
-    // two-pass variance from registers (no cancellation)
-    float d2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
+  for (int i = 0; i < CH; ++i) {
+    wraw[i] = *(const u32x4*)(w + min(lane + i * 64, nch - 1) * 8);
+    if (LAYERNORM) braw[i] = *(const u32x4*)(b + min(lane + i * 64, nch - 1) * 8);
+  }
+  const float inv_n = 1.0f / (float)N;
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    float v[CH][8];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      unpack8(raw[r][i], v[i]);
+      if (lane + i * 64 < nch) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float d = v[i][e] - mean;
-          d2 += d * d;
+          s += v[i][e];
+          ss += v[i][e] * v[i][e];
         }
       }
     }
-    d2 = wave_sum(d2);
-    rstd = rsqrtf(d2 * inv_n + eps);
-  } else {
-    rstd = rsqrtf(ss * inv_n + eps);
-  }
-  bf16_t* yr = y + (size_t)row * ldy;
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    float mean = 0.f, rstd;
+    if (LAYERNORM) {
+      mean = s * inv_n;
+      float d2 = 0.f;   // two-pass variance from registers (no cancellation)
 #pragma unroll
-  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
-    const int c = lane + i * 64;
-    if (c < nch) {
+      for (int i = 0; i < CH; ++i)
+        if (lane + i * 64 < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[i][e] - mean;
+            d2 += d * d;
+          }
+        }
+      d2 = wave_sum(d2);
+      rstd = rsqrtf(d2 * inv_n + eps);
+    } else {
+      rstd = rsqrtf(ss * inv_n + eps);
+    }
+    if (row0 + r >= rows) continue;   // (wave-uniform)
+    bf16_t* yr = y + (size_t)(row0 + r) * ldy;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int c = lane + i * 64;
       float wv[8], o[8];
-      unpack8(*(const u32x4*)(w + c * 8), wv);
+      unpack8(wraw[i], wv);
       if (LAYERNORM) {
         float bv[8];
-        unpack8(*(const u32x4*)(b + c * 8), bv);
+        unpack8(braw[i], bv);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
       } else {
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[i][e] * rstd)) * wv[e];
       }
-      *(u32x4*)(yr + c * 8) = pack8(o);
+      if (c < nch) *(u32x4*)(yr + c * 8) = pack8(o);
     }
   }
 }
@@ -86,8 +98,9 @@ __global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict
 //   y[m] = norm(x[m]) * w (+ b)                         (statistics of the ROUNDED x, exactly what a separate
 //                                                         vis_rmsnorm_bf16 / vis_layernorm_bf16 of x would compute)
 // replaces gemm_splitk_finalize_kernel + norm_rows_kernel: one pass over the partials instead of a pass over the
-// partials and a read-modify-write pass over x.  y == NULL: finalisation only.
-template <bool LAYERNORM>
+// partials and a read-modify-write pass over x.  y == NULL: finalisation only.  KS = slices (2: every use in the engines;
+// 0: run-time count), CH = chunks per lane; all loads of the row issued up front (see norm_rows_kernel).
+template <bool LAYERNORM, int CH, int KS>
 __global__ __launch_bounds__(256) void finalize_norm_rows_kernel(const float* __restrict__ part, int ksplit, size_t slice,
                                                                  const bf16_t* __restrict__ bias,
                                                                  const bf16_t* __restrict__ R, int ldr,
@@ -100,35 +113,56 @@ __global__ __launch_bounds__(256) void finalize_norm_rows_kernel(const float* __
   if (row >= rows) return;
   const int nch = N >> 3;
   const float* pr = part + (size_t)row * N;
-  float v[NORM_MAX_CHUNKS][8];
+  constexpr int KSL = KS > 0 ? KS : 1;
+  f32x4 plo[KSL][CH], phi[KSL][CH];
+  u32x4 braw[CH], rraw[CH], wraw[CH], nbraw[CH];
+  const u32x4 z = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = min(lane + i * 64, nch - 1);
+#pragma unroll
+    for (int k = 0; k < KSL; ++k) {
+      plo[k][i] = *(const f32x4*)(pr + k * slice + c * 8);
+      phi[k][i] = *(const f32x4*)(pr + k * slice + c * 8 + 4);
+    }
+    braw[i] = bias ? *(const u32x4*)(bias + c * 8) : z;                    // (pointer tests are kernel-uniform)
+    rraw[i] = R ? *(const u32x4*)(R + (size_t)row * ldr + c * 8) : z;
+    if (y) {
+      wraw[i] = *(const u32x4*)(w + c * 8);
+      nbraw[i] = LAYERNORM ? *(const u32x4*)(b + c * 8) : z;
+    }
+  }
+  float v[CH][8];
   float s = 0.f, ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < CH; ++i) {
     const int c = lane + i * 64;
-    if (c < nch) {
-      float a[8];
-      *(f32x4*)a = *(const f32x4*)(pr + c * 8);
-      *(f32x4*)(a + 4) = *(const f32x4*)(pr + c * 8 + 4);
+    float a[8], f[8];
+    *(f32x4*)a = plo[0][i];
+    *(f32x4*)(a + 4) = phi[0][i];
+#pragma unroll
+    for (int k = 1; k < KSL; ++k) {
+      a[0] += plo[k][i][0]; a[1] += plo[k][i][1]; a[2] += plo[k][i][2]; a[3] += plo[k][i][3];
+      a[4] += phi[k][i][0]; a[5] += phi[k][i][1]; a[6] += phi[k][i][2]; a[7] += phi[k][i][3];
+    }
+    if (KS == 0) {
       for (int ks = 1; ks < ksplit; ++ks) {
-        const f32x4 lo = *(const f32x4*)(pr + ks * slice + c * 8), hi = *(const f32x4*)(pr + ks * slice + c * 8 + 4);
+        const int cc = min(c, nch - 1);
+        const f32x4 lo = *(const f32x4*)(pr + ks * slice + cc * 8), hi = *(const f32x4*)(pr + ks * slice + cc * 8 + 4);
         a[0] += lo[0]; a[1] += lo[1]; a[2] += lo[2]; a[3] += lo[3];
         a[4] += hi[0]; a[5] += hi[1]; a[6] += hi[2]; a[7] += hi[3];
       }
-      if (bias) {
-        float f[8];
-        unpack8(*(const u32x4*)(bias + c * 8), f);
+    }
+    unpack8(braw[i], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += f[e];
-      }
-      if (R) {
-        float f[8];
-        unpack8(*(const u32x4*)(R + (size_t)row * ldr + c * 8), f);
+    for (int e = 0; e < 8; ++e) a[e] += f[e];      // (+ 0 without a bias: a + 0.0f == a)
+    unpack8(rraw[i], f);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] += f[e];
-      }
-      const u32x4 packed = pack8(a);
-      *(u32x4*)(xo + (size_t)row * ldxo + c * 8) = packed;
-      unpack8(packed, v[i]);                    // the norm sees the rounded values
+    for (int e = 0; e < 8; ++e) a[e] += f[e];
+    const u32x4 packed = pack8(a);
+    if (c < nch) *(u32x4*)(xo + (size_t)row * ldxo + c * 8) = packed;
+    unpack8(packed, v[i]);                    // the norm sees the rounded values
+    if (c < nch) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         s += v[i][e];
@@ -145,16 +179,14 @@ __global__ __launch_bounds__(256) void finalize_norm_rows_kernel(const float* __
     mean = s * inv_n;
     float d2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
+    for (int i = 0; i < CH; ++i)
+      if (lane + i * 64 < nch) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = v[i][e] - mean;
           d2 += d * d;
         }
       }
-    }
     d2 = wave_sum(d2);
     rstd = rsqrtf(d2 * inv_n + eps);
   } else {
@@ -162,22 +194,20 @@ __global__ __launch_bounds__(256) void finalize_norm_rows_kernel(const float* __
   }
   bf16_t* yr = y + (size_t)row * ldy;
 #pragma unroll
-  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+  for (int i = 0; i < CH; ++i) {
     const int c = lane + i * 64;
-    if (c < nch) {
-      float wv[8], o[8];
-      unpack8(*(const u32x4*)(w + c * 8), wv);
-      if (LAYERNORM) {
-        float bv[8];
-        unpack8(*(const u32x4*)(b + c * 8), bv);
+    float wv[8], o[8];
+    unpack8(wraw[i], wv);
+    if (LAYERNORM) {
+      float bv[8];
+      unpack8(nbraw[i], bv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
-      } else {
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+    } else {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[i][e] * rstd)) * wv[e];
-      }
-      *(u32x4*)(yr + c * 8) = pack8(o);
+      for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[i][e] * rstd)) * wv[e];
     }
+    if (c < nch) *(u32x4*)(yr + c * 8) = pack8(o);
   }
 }
 
@@ -194,15 +224,23 @@ extern "C" int vis_splitk_finalize_norm(const void* part, int ksplit, const void
     return VIS_ERR_ARG;
   const dim3 grid((M + 3) / 4), block(256);
   const size_t slice = (size_t)M * N;
+  const int ch = (N / 8 + 63) / 64;   // chunks per lane
   vis_clear_error();
-  if (norm_b)
-    hipLaunchKernelGGL(finalize_norm_rows_kernel<true>, grid, block, 0, stream, (const float*)part, ksplit, slice,
-                       (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)x, ldx, (const bf16_t*)norm_w,
-                       (const bf16_t*)norm_b, (bf16_t*)y, ldy, M, N, eps);
-  else
-    hipLaunchKernelGGL(finalize_norm_rows_kernel<false>, grid, block, 0, stream, (const float*)part, ksplit, slice,
-                       (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)x, ldx, (const bf16_t*)norm_w,
-                       (const bf16_t*)nullptr, (bf16_t*)y, ldy, M, N, eps);
+#define FIN_LAUNCH(LN, CH, KS)                                                                                              \
+  hipLaunchKernelGGL((finalize_norm_rows_kernel<LN, CH, KS>), grid, block, 0, stream, (const float*)part, ksplit, slice,        \
+                     (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)x, ldx, (const bf16_t*)norm_w, (const bf16_t*)norm_b, \
+                     (bf16_t*)y, ldy, M, N, eps)
+#define FIN_PICK(LN)                                                        \
+  do {                                                                      \
+    if (ksplit == 2 && ch <= 3) FIN_LAUNCH(LN, 3, 2);                       \
+    else if (ksplit == 2 && ch <= 7) FIN_LAUNCH(LN, 7, 2);                  \
+    else if (ksplit == 2) FIN_LAUNCH(LN, NORM_MAX_CHUNKS, 2);               \
+    else FIN_LAUNCH(LN, NORM_MAX_CHUNKS, 0);                                \
+  } while (0)
+  if (norm_b) FIN_PICK(true);
+  else FIN_PICK(false);
+#undef FIN_PICK
+#undef FIN_LAUNCH
   return vis_check_launch();
 }
 
@@ -212,14 +250,23 @@ static int norm_launch(bool ln, const void* x, const void* w, const void* b, voi
   if (N % 8 != 0 || N > 64 * 8 * NORM_MAX_CHUNKS || ldx % 8 != 0 || ldy % 8 != 0) return VIS_ERR_ARG;
   if (ln && !b) return VIS_ERR_ARG;
   if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)b) & 15) return VIS_ERR_ARG;
-  const dim3 grid((rows + 3) / 4), block(256);
+  const int ch = (N / 8 + 63) / 64;   // chunks per lane
+  const int rpw = ch <= 3 ? 2 : 1;    // rows per wave
+  const dim3 grid((rows + 4 * rpw - 1) / (4 * rpw)), block(256);
   vis_clear_error();
-  if (ln)
-    hipLaunchKernelGGL(norm_rows_kernel<true>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w,
-                       (const bf16_t*)b, (bf16_t*)y, rows, N, ldx, ldy, eps);
-  else
-    hipLaunchKernelGGL(norm_rows_kernel<false>, grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w,
-                       (const bf16_t*)nullptr, (bf16_t*)y, rows, N, ldx, ldy, eps);
+#define NORM_LAUNCH(LN, CH, ROWS)                                                                                         \
+  hipLaunchKernelGGL((norm_rows_kernel<LN, CH, ROWS>), grid, block, 0, stream, (const bf16_t*)x, (const bf16_t*)w,          \
+                     (const bf16_t*)b, (bf16_t*)y, rows, N, ldx, ldy, eps)
+#define NORM_PICK(LN)                                  \
+  do {                                                 \
+    if (ch <= 3) NORM_LAUNCH(LN, 3, 2);                \
+    else if (ch <= 7) NORM_LAUNCH(LN, 7, 1);           \
+    else NORM_LAUNCH(LN, NORM_MAX_CHUNKS, 1);          \
+  } while (0)
+  if (ln) NORM_PICK(true);
+  else NORM_PICK(false);
+#undef NORM_PICK
+#undef NORM_LAUNCH
   return vis_check_launch();
 }
 

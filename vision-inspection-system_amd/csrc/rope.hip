@@ -78,21 +78,38 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p, int n_r
       for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 1.f; sa[e] = 0.f; sb[e] = 0.f; }
     }
     const bf16_t* row = p.qkv + (size_t)s * p.ld_qkv;
-    for (int head = hg; head < p.Hq + p.Hkv; head += HG) {
-      const bool is_q = head < p.Hq;
-      const int hh = is_q ? head : head - p.Hq;
-      float a[8], b[8], oa[8], ob[8];
-      unpack8(*(const u32x4*)(row + head * HD + d0), a);
-      unpack8(*(const u32x4*)(row + head * HD + HALF + d0), b);
+    // four heads per round trip: their eight 16-byte loads are issued before the first is used (unconditional, clamped head
+    // index; r01-r04 walked one head per iteration - one dependent load round trip per head: 11 of them in a row for the ViT's
+    // 32 q / k heads on three head groups, 4.2 TB/s)
+    constexpr int UNR = 4;
+    const int nh = p.Hq + p.Hkv;
+    for (int h0 = hg; h0 < nh; h0 += HG * UNR) {
+      u32x4 ra[UNR], rb[UNR];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        oa[e] = a[e] * ca[e] - b[e] * sa[e];  // first half: rotate_half gives -x2
-        ob[e] = b[e] * cb[e] + a[e] * sb[e];  // second half: rotate_half gives +x1
+      for (int u = 0; u < UNR; ++u) {
+        const int head = min(h0 + u * HG, nh - 1);
+        ra[u] = *(const u32x4*)(row + head * HD + d0);
+        rb[u] = *(const u32x4*)(row + head * HD + HALF + d0);
       }
-      bf16_t* dst = is_q ? p.q + ((size_t)hh * p.S + s) * HD
-                         : p.k + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD;
-      *(u32x4*)(dst + d0) = pack8(oa);
-      *(u32x4*)(dst + HALF + d0) = pack8(ob);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const int head = h0 + u * HG;
+        if (head >= nh) break;
+        const bool is_q = head < p.Hq;
+        const int hh = is_q ? head : head - p.Hq;
+        float a[8], b[8], oa[8], ob[8];
+        unpack8(ra[u], a);
+        unpack8(rb[u], b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          oa[e] = a[e] * ca[e] - b[e] * sa[e];  // first half: rotate_half gives -x2
+          ob[e] = b[e] * cb[e] + a[e] * sb[e];  // second half: rotate_half gives +x1
+        }
+        bf16_t* dst = is_q ? p.q + ((size_t)hh * p.S + s) * HD
+                           : p.k + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD;
+        *(u32x4*)(dst + d0) = pack8(oa);
+        *(u32x4*)(dst + HALF + d0) = pack8(ob);
+      }
     }
     return;
   }
@@ -104,12 +121,23 @@ __global__ __launch_bounds__(256) void qkv_rope_split_kernel(RopeArgs p, int n_r
   const int s0 = (vb - hh * nblk) * 64;
   const int head = p.Hq + p.Hkv + hh;
   const int ntok = min(64, p.S - s0);
-  for (int it = tid; it < 64 * CH; it += 256) {
+  constexpr int VIT = (64 * CH + 255) / 256;   // 16-byte chunks per thread: 4 (head_dim 128) / 3 (80)
+  u32x4 vraw[VIT];
+#pragma unroll
+  for (int i = 0; i < VIT; ++i) {               // every load of the thread before the first use (clamped: always a valid row)
+    const int it = min(tid + i * 256, 64 * CH - 1);
+    const int t = it / CH, c = it - t * CH;
+    vraw[i] = *(const u32x4*)(p.qkv + (size_t)(s0 + min(t, ntok - 1)) * p.ld_qkv + head * HD + c * 8);
+  }
+#pragma unroll
+  for (int i = 0; i < VIT; ++i) {
+    const int it = tid + i * 256;
+    if (it >= 64 * CH) break;
     const int t = it / CH, c = it - t * CH;
     u32x4 raw = (u32x4){0u, 0u, 0u, 0u};
     if (t < ntok) {
       const int s = s0 + t;
-      raw = *(const u32x4*)(p.qkv + (size_t)s * p.ld_qkv + head * HD + c * 8);
+      raw = vraw[i];
       if (p.v) *(u32x4*)(p.v + ((size_t)hh * p.k_tokens + p.k_pos0 + s) * HD + c * 8) = raw;
     }
     if (p.vt) {
