@@ -591,35 +591,24 @@ __global__ __launch_bounds__(256, 3) void attn_vit32_kernel(AttnArgs p) {
     dv_off[i] = (uint32_t)d * (uint32_t)(p.vt_ld * 2) + ((cv ^ ((d >> 1) & 7)) << 4);
   }
   const int dma_base = wave * 1024;
+  // LDS-DMA through BUFFER instructions (r05): the per-lane offsets above are loop constants in VGPRs, the tile's position is
+  // the instruction's SCALAR offset, the head's base lives in the resource descriptor - no per-tile vector address arithmetic
+  // (the global_load_lds form rebuilt a 64-bit address per piece and tile: 14 v_lshl_add_u64 + ~40 other VALU / SALU
+  // instructions per tile, profiles/r05_vit_attention_isa.txt), and rows past the head's last key read as zeros by the
+  // descriptor's range check (the ragged last tile needed a second code path with clamped rows; its scores are masked anyway).
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, p.k_tokens * (HD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, HD * p.vt_ld * 2, 0x00020000);
   auto load_tile = [&](int kt, int buf) {
-    char* base = lds + buf * BUF + dma_base;
-    const char* vbase = (const char*)(Vh + kt);
-    if (kt + 64 <= p.k_tokens) {
-      const char* kbase = (const char*)Kh + (size_t)kt * (HD * 2);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if (i < 2 || wave < 2)
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + dk_off[i]),
-                                           (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
-    } else {        // ragged last tile of a head: rows past k_tokens re-read the last key (masked below)
-      const char* kbase = (const char*)Kh;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-        if (i < 2 || wave < 2) {
-          const int ps = min(i * 256 + tid, 639);
-          const int row = (ps * 6554) >> 16;
-          const int c = ps - row * 10;
-          const int key = min(kt + row, p.k_tokens - 1);
-          const uint32_t off = (uint32_t)key * (HD * 2) + ((c ^ ((row >> 3) & 1)) << 4);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + off),
-                                           (__attribute__((address_space(3))) void*)(base + i * 4096), 16, 0, 0);
-        }
-    }
+    __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)(lds + buf * BUF + dma_base);
+    const int ko = kt * (HD * 2), vo = kt * 2;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
       if (i < 2 || wave < 2)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + dv_off[i]),
-                                         (__attribute__((address_space(3))) void*)(base + K_BYTES + i * 4096), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(base + i * 4096), 16, dk_off[i], ko, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      if (i < 2 || wave < 2)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)(base + K_BYTES + i * 4096), 16, dv_off[i], vo, 0, 0);
   };
 
   // fragment read addresses: one per-lane base for K (the chunk XOR only touches bit 0: (2 ks + hh) ^ sw = 2 ks + (hh ^ sw)),
@@ -888,35 +877,32 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
     for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = att_scaled_q8(qp + ds * 32 + 8 * h, p.scale_log2);
   }
 
-  // staging: K tile 64 rows x 16 chunks, V^T tile 128 rows x 8 chunks = 1024 16-byte slots each, 2 per thread
-  int k_goff[2], k_loff[2], k_row[2], v_goff[2], v_loff[2];
-  u32x4 kreg[2], vreg[2];
+  // staging (r05: LDS-DMA through buffer instructions, as attn_vit32_kernel; r02-r04 went global -> registers -> ds_write, the
+  // loads of tile t + 1 parked in 16 VGPRs over the whole body of tile t and written behind it): K tile 64 rows x 16 chunks,
+  // V^T tile 128 rows x 8 chunks = 1024 16-byte slots each = two 8 KiB pieces per image (512 threads x 16 B).  The LDS images
+  // are lane-linear, so the XOR swizzles sit on the per-lane SOURCE offsets (loop constants); the tile's position is the
+  // instruction's scalar offset; rows past the head's last key read as zeros by the descriptor's range check (masked below).
+  uint32_t dk_off[2], dv_off[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int it = tid + i * 512;
     const int row = it >> 4, c = it & 15;
-    k_row[i] = row;
-    k_goff[i] = c * 8;
-    k_loff[i] = row * KROW + ((c ^ (row & 15)) << 4);
+    dk_off[i] = (uint32_t)row * (HD * 2) + ((c ^ (row & 15)) << 4);
     const int d = it >> 3, cv = it & 7;
-    v_goff[i] = d * p.vt_ld + cv * 8;
-    v_loff[i] = K_BYTES + d * 128 + ((cv ^ ((d >> 1) & 7)) << 4);
+    dv_off[i] = (uint32_t)d * (uint32_t)(p.vt_ld * 2) + ((cv ^ ((d >> 1) & 7)) << 4);
   }
-  auto load_tile = [&](int kt) {
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)Kh, 0, p.k_tokens * (HD * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)Vh, 0, HD * p.vt_ld * 2, 0x00020000);
+  const int dma_base = __builtin_amdgcn_readfirstlane(wave) * 1024;
+  auto dma_tile = [&](int kt, int buf) {
+    __attribute__((address_space(3))) char* base = (__attribute__((address_space(3))) char*)(lds + buf * BUF + dma_base);
+    const int ko = kt * (HD * 2), vo = kt * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int key = min(kt + k_row[i], p.k_tokens - 1);
-      kreg[i] = *(const u32x4*)(Kh + (size_t)key * HD + k_goff[i]);
-    }
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(base + i * 8192), 16, dk_off[i], ko, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) vreg[i] = *(const u32x4*)(Vh + v_goff[i] + kt);
-  };
-  auto store_tile = [&](int buf) {
-    char* base = lds + buf * BUF;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *(u32x4*)(base + k_loff[i]) = kreg[i];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) *(u32x4*)(base + v_loff[i]) = vreg[i];
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (__attribute__((address_space(3))) void*)(base + K_BYTES + i * 8192), 16, dv_off[i], vo, 0, 0);
   };
 
   f32x4 oacc[2][ND + 1];
@@ -928,17 +914,15 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
   const uint32_t one2 = (l15 == 0) ? 0x3f803f80u : 0u;
   const bf16x8 ones_frag = __builtin_bit_cast(bf16x8, (u32x4){one2, one2, one2, one2});
 
-  if (nt > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
+  if (nt > 0) dma_tile(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
     const int kt = t * 64;
     const bool more = (t + 1 < nt);
-    if (more) load_tile(kt + 64);
+    if (more) dma_tile(kt + 64, cur ^ 1);   // the other buffer: last read in iteration t - 1, behind that iteration's barrier
 
     // a 16-row block of this wave is live while the tile starts at or below its last row
     const bool live0 = have[0] && kt <= wrow0[0] + 15;
@@ -1046,7 +1030,7 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
     if (live1) tile_body(std::integral_constant<int, 2>{});        // A live implies B live (A lies before B)
     else if (live0) tile_body(std::integral_constant<int, 1>{});
 
-    if (more) store_tile(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
   }

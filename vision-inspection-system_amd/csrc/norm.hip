@@ -211,6 +211,105 @@ __global__ __launch_bounds__(256) void finalize_norm_rows_kernel(const float* __
   }
 }
 
+// Rows wider than 3 chunks per lane (LLM hidden 3584: 7) keep the r02 form: loads per chunk inside the loop, up to ten chunks of
+// registers.  The all-loads-up-front form above needs 242 VGPRs at 7 chunks x 2 slices (two waves per SIMD) and measured
+// SLOWER there (cold-cache microbench tools/rowpass_bench.py: 43.9 vs 39.7 us at 2249 x 3584, 28.7 vs 24.9 at 1289 rows), while
+// the 1280-column ViT rows gain (30.6 vs 32.6 us): occupancy, not the number of loads in flight per wave, is what these row
+// passes live on.
+template <bool LAYERNORM>
+__global__ __launch_bounds__(256) void finalize_norm_rows_wide_kernel(const float* __restrict__ part, int ksplit, size_t slice,
+                                                                 const bf16_t* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ R, int ldr,
+                                                                 bf16_t* __restrict__ xo, int ldxo,
+                                                                 const bf16_t* __restrict__ w,
+                                                                 const bf16_t* __restrict__ b, bf16_t* __restrict__ y,
+                                                                 int ldy, int rows, int N, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = N >> 3;
+  const float* pr = part + (size_t)row * N;
+  float v[NORM_MAX_CHUNKS][8];
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float a[8];
+      *(f32x4*)a = *(const f32x4*)(pr + c * 8);
+      *(f32x4*)(a + 4) = *(const f32x4*)(pr + c * 8 + 4);
+      for (int ks = 1; ks < ksplit; ++ks) {
+        const f32x4 lo = *(const f32x4*)(pr + ks * slice + c * 8), hi = *(const f32x4*)(pr + ks * slice + c * 8 + 4);
+        a[0] += lo[0]; a[1] += lo[1]; a[2] += lo[2]; a[3] += lo[3];
+        a[4] += hi[0]; a[5] += hi[1]; a[6] += hi[2]; a[7] += hi[3];
+      }
+      if (bias) {
+        float f[8];
+        unpack8(*(const u32x4*)(bias + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += f[e];
+      }
+      if (R) {
+        float f[8];
+        unpack8(*(const u32x4*)(R + (size_t)row * ldr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += f[e];
+      }
+      const u32x4 packed = pack8(a);
+      *(u32x4*)(xo + (size_t)row * ldxo + c * 8) = packed;
+      unpack8(packed, v[i]);                    // the norm sees the rounded values
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        s += v[i][e];
+        ss += v[i][e] * v[i][e];
+      }
+    }
+  }
+  if (!y) return;
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const float inv_n = 1.0f / (float)N;
+  float mean = 0.f, rstd;
+  if (LAYERNORM) {
+    mean = s * inv_n;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mean;
+          d2 += d * d;
+        }
+      }
+    }
+    d2 = wave_sum(d2);
+    rstd = rsqrtf(d2 * inv_n + eps);
+  } else {
+    rstd = rsqrtf(ss * inv_n + eps);
+  }
+  bf16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < NORM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float wv[8], o[8];
+      unpack8(*(const u32x4*)(w + c * 8), wv);
+      if (LAYERNORM) {
+        float bv[8];
+        unpack8(*(const u32x4*)(b + c * 8), bv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * wv[e] + bv[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[i][e] * rstd)) * wv[e];
+      }
+      *(u32x4*)(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
 // part [ksplit][M][N] f32 (vis_gemm_bf16_splitk_part) -> x [M][ldx] bf16 = sum + bias + R, and (y != NULL)
 // y [M][ldy] = RMSNorm (norm_b == NULL) or LayerNorm of x.
 extern "C" int vis_splitk_finalize_norm(const void* part, int ksplit, const void* bias, const void* R, void* x,
@@ -233,9 +332,9 @@ extern "C" int vis_splitk_finalize_norm(const void* part, int ksplit, const void
 #define FIN_PICK(LN)                                                        \
   do {                                                                      \
     if (ksplit == 2 && ch <= 3) FIN_LAUNCH(LN, 3, 2);                       \
-    else if (ksplit == 2 && ch <= 7) FIN_LAUNCH(LN, 7, 2);                  \
-    else if (ksplit == 2) FIN_LAUNCH(LN, NORM_MAX_CHUNKS, 2);               \
-    else FIN_LAUNCH(LN, NORM_MAX_CHUNKS, 0);                                \
+    else hipLaunchKernelGGL(finalize_norm_rows_wide_kernel<LN>, grid, block, 0, stream, (const float*)part, ksplit, slice,   \
+                            (const bf16_t*)bias, (const bf16_t*)R, ldr, (bf16_t*)x, ldx, (const bf16_t*)norm_w,              \
+                            (const bf16_t*)norm_b, (bf16_t*)y, ldy, M, N, eps);                                              \
   } while (0)
   if (norm_b) FIN_PICK(true);
   else FIN_PICK(false);

@@ -14,7 +14,7 @@ from typing import Optional
 import torch  # imported BEFORE the library is dlopen-ed: libvis_hip.so must bind to the HIP runtime torch loaded
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libvis_hip.so")
+LIB_PATH = os.environ.get("VIS_HIP_LIB") or os.path.join(_CSRC, "libvis_hip.so")     # VIS_HIP_LIB: another build of the same ABI (A/B runs)
 
 ACT_NONE, ACT_QUICKGELU, ACT_GELU_ERF, ACT_SWIGLU = 0, 1, 2, 3
 DECODE_KEYS_PER_SPLIT = 64   # DA_MAXKEYS of csrc/decode.hip: a decode-attention split owns this many cached keys
