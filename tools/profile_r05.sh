@@ -6,12 +6,14 @@
 #  dual    configs[2] at 32 images per step: kernel stats + the Auditor's decode step by kernel (r05_dual_decode_step.csv)
 #  fp8     fp8 prompt-pass table (4 images per step)
 #  b64     per-image prompt-pass table at 64 images per step (r05_prefill_breakdown_b64.csv)
+#  traffic FETCH_SIZE / WRITE_SIZE passes of the batched decode projection at 64 sequences: the default pair's stream kernel
+#          (r05_decode_stream_traffic.json) and the opt-in single-launch stream-K form (r05_decode_proj_fused_traffic.json)
 R=r05
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof_$R
 P=$O/profiles
 mkdir -p $P
-PARTS="${@:-head seam dual fp8 b64}"
+PARTS="${@:-head seam dual fp8 b64 traffic}"
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 fail() { echo "$1 failed" >> $O/errors.txt; }
 trace() {  # name, program args...
@@ -50,6 +52,20 @@ if has b64; then
   python3 tools/trace_breakdown.py $O/pre64 128 $P/${R}_prefill_breakdown_b64.csv \
       --exclude "at::native,__amd_rocclr,Custom_Cijk,gemm_decode,skinny_,decode_attn,argmax_,gemv_,decode_proj,decode_colpar,decode_prep" > $O/pre64_table.log 2>> $O/errors.txt
   echo "b64 done"; date
+fi
+if has traffic; then
+  pmc() { local name=$1; shift; local ctr=$1; shift
+    rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$name -o p -- python3 "$@" > $O/$name.log 2>&1 || fail "pmc $name"; }
+  B64="bench.py --batch 64 --prompt-order text-first --steps 1 --warmup 0 --new-tokens 4 --no-extras --no-blocks --no-cpu-baseline --no-graph"
+  pmc b64_fetch FETCH_SIZE $B64
+  pmc b64_write WRITE_SIZE $B64
+  python3 tools/summarize_profile.py --round $R --fetch $O/b64_fetch --write $O/b64_write --out $P \
+      --traffic-kernel gemm_decode_stream_kernel --traffic-name decode_stream || fail "b64 traffic summary"
+  VIS_DECODE_FUSED=1 VIS_DOWN_PAIR=0 VIS_DECODE_PROJ_FORM=streamk pmc b64f_fetch FETCH_SIZE $B64
+  VIS_DECODE_FUSED=1 VIS_DOWN_PAIR=0 VIS_DECODE_PROJ_FORM=streamk pmc b64f_write WRITE_SIZE $B64
+  python3 tools/summarize_profile.py --round $R --fetch $O/b64f_fetch --write $O/b64f_write --out $P \
+      --traffic-kernel decode_proj_kernel --traffic-name decode_proj_fused || fail "fused traffic summary"
+  echo "traffic done"; date
 fi
 find gpurun_out -name "*.csv" -size +2M -delete
 ls -la $P; cat $O/errors.txt 2>/dev/null; true
