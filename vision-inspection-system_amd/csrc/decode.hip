@@ -479,7 +479,8 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   __shared__ __attribute__((aligned(16))) bf16_t q_s[16][HD];   // heads >= G are zero
   __shared__ __attribute__((aligned(16))) bf16_t knew_s[HD];
   __shared__ __attribute__((aligned(16))) bf16_t vnew_s[HD];
-  __shared__ __attribute__((aligned(16))) float pbuf[NW][G][16];   // wave-private probabilities of the current step
+  __shared__ __attribute__((aligned(16))) uint32_t pbuf[NW][G][8];   // wave-private probabilities of the current step: bf16 pairs
+                                                                     // (keys 2 j, 2 j + 1) - the B operand of v_dot2_f32_bf16
   __shared__ float pal[NW][G];                                     // wave-private rescale factors of the current step
   __shared__ float red_o[NW][G][HD];
   __shared__ float red_ml[NW][G][2];
@@ -589,31 +590,37 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
     float pe[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) pe[e] = exp2f(sv[e] - m_new);
-    l_run = l_run * al + hsum4((pe[0] + pe[1]) + (pe[2] + pe[3]));
+    // r05: P * V on v_dot2_f32_bf16 - the probabilities are rounded to bf16 (as the prefill attention's P is; exact products,
+    // f32 accumulation) and two keys go through one instruction: 112 dot2 + 16 v_perm per step and wave instead of 224 FMAs + 32
+    // unpacking shifts / masks.  This kernel is bound by its instruction stream, not by memory: with every key of every sequence
+    // served from L2 it ran 45 of 62 us (r03 probe), and four register sets in flight instead of two made it slower (above).
+    // The denominator sums the ROUNDED values, so numerator and denominator stay consistent.
+    const uint32_t p01 = pack2bf(pe[0], pe[1]), p23 = pack2bf(pe[2], pe[3]);
+    l_run = l_run * al + hsum4((__uint_as_float(p01 << 16) + __uint_as_float(p01 & 0xffff0000u)) +
+                               (__uint_as_float(p23 << 16) + __uint_as_float(p23 & 0xffff0000u)));
     if (l15 < G) {
-      *(f32x4*)(&pbuf[wave][l15][4 * h]) = (f32x4){pe[0], pe[1], pe[2], pe[3]};
+      *(u32x2*)(&pbuf[wave][l15][2 * h]) = (u32x2){p01, p23};     // keys 4 h .. 4 h + 3 = pairs 2 h, 2 h + 1
       if (h == 0) pal[wave][l15] = al;
     }
     // ---- O[g][d] = O[g][d] * alpha[g] + sum_key p[g][key] V[key][d]; lane owns d = 2 lane, 2 lane + 1
-    float v0[16], v1[16];
+    bf16x2 va[8], vb[8];     // per key pair: dim 2 lane of both keys / dim 2 lane + 1 of both keys
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const uint32_t raw = (k0 + i == new_row) ? vnew : r.v[i];
-      v0[i] = __uint_as_float(raw << 16);
-      v1[i] = __uint_as_float(raw & 0xffff0000u);
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t r0 = (k0 + 2 * j == new_row) ? vnew : r.v[2 * j];
+      const uint32_t r1 = (k0 + 2 * j + 1 == new_row) ? vnew : r.v[2 * j + 1];
+      va[j] = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(r1, r0, 0x05040100u));   // {r0.lo, r1.lo}
+      vb[j] = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(r1, r0, 0x07060302u));   // {r0.hi, r1.hi}
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const float ag = pal[wave][g];
       float a0 = acc0[g] * ag, a1 = acc1[g] * ag;
+      const u32x4 pq0 = *(const u32x4*)(&pbuf[wave][g][0]), pq1 = *(const u32x4*)(&pbuf[wave][g][4]);   // broadcast reads
 #pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const f32x4 pw = *(const f32x4*)(&pbuf[wave][g][4 * q4]);      // broadcast read: keys k0 + 4 q4 .. + 3
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          a0 += pw[e] * v0[4 * q4 + e];      // keys past the context carry p = 0 (masked scores)
-          a1 += pw[e] * v1[4 * q4 + e];
-        }
+      for (int j = 0; j < 8; ++j) {       // keys past the context carry p = 0 (masked scores)
+        const bf16x2 pp = __builtin_bit_cast(bf16x2, j < 4 ? pq0[j] : pq1[j - 4]);
+        a0 = __builtin_amdgcn_fdot2_f32_bf16(va[j], pp, a0, false);
+        a1 = __builtin_amdgcn_fdot2_f32_bf16(vb[j], pp, a1, false);
       }
       acc0[g] = a0;
       acc1[g] = a1;
