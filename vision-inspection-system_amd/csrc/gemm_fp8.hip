@@ -32,7 +32,8 @@
 #define F8_STAGE_BYTES (2 * F8_B * F8_BK)          // 65536
 #define F8_LDS_BYTES (2 * F8_STAGE_BYTES)          // 131072
 
-enum { F8_ACT_NONE = 0, F8_ACT_QUICKGELU = 1, F8_ACT_GELU_ERF = 2, F8_ACT_SWIGLU = 3 };
+#include "gemm_epilogue.hip.h"
+enum { F8_ACT_NONE = ACT_NONE, F8_ACT_QUICKGELU = ACT_QUICKGELU, F8_ACT_GELU_ERF = ACT_GELU_ERF, F8_ACT_SWIGLU = ACT_SWIGLU };
 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
@@ -47,6 +48,8 @@ struct GemmF8Args {
   int M, N, K, lda, ldw, ldc, ldr, act, tiles_m, tiles_n;
   float* part;   // split-K: f32 partial sums [ksplit][M][N] (unscaled), or null
   int ksplit;
+  int wide;      // host-checked preconditions of gemm_epilogue_wide (gemm_epilogue.hip.h) hold
+  int nt;        // wide epilogue: non-temporal C stores
 };
 
 __device__ __forceinline__ float f8_act(float x, int act) {
@@ -116,6 +119,25 @@ __device__ __forceinline__ void f8_epilogue(const GemmF8Args& p, f32x4 (&acc)[4]
     }
   }
 }
+
+// Wide form (r05): the accumulators take their two scales - (acc * sa[m]) * sw[n], the direct epilogue's order - on
+// their way into the LDS-staged 16-byte-per-lane epilogue of the bf16 kernels (same accumulator layout), which
+// applies bias / activation / residual exactly as f8_epilogue does.  tools/gemm_kscan.py, KS_FP8=1, M = 19600 N = 5120: the
+// direct form's store tail (8-byte pieces of 16 rows per instruction) cost 14 us per round of 256 tiles against 5.4 us for bf16.
+template <int MI>
+struct F8Scale {
+  float sam[MI];
+  f32x4 s4[4];
+  __device__ __forceinline__ F8Scale(const GemmF8Args& p, int mbase, int nbase, int l15, int h) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) sam[i] = p.sa[min(mbase + i * 16 + l15, p.M - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s4[j] = *(const f32x4*)(p.sw + min(nbase + j * 16 + 4 * h, p.N - 4));
+  }
+  __device__ __forceinline__ f32x4 operator()(const f32x4& v, int i, int j) const {
+    return (f32x4){v[0] * sam[i] * s4[j][0], v[1] * sam[i] * s4[j][1], v[2] * sam[i] * s4[j][2], v[3] * sam[i] * s4[j][3]};
+  }
+};
 
 // 128 x 128 x 128 tile, 4 waves (2 x 2) x 64 x 64, two workgroups per CU (2 x 32 KiB LDS): the small-grid / remainder
 // companion of the 256x256 kernel (ViT-sized problems, the ragged last columns of the gate/up projection).
@@ -191,6 +213,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_128x128_kernel(GemmF8Args p) 
                                                                      0x7f7f7f7f);
     __syncthreads();  // also drains the in-flight global_load_lds (vmcnt(0))
     cur ^= 1;
+  }
+  if (p.wide) {   // the loop's last __syncthreads: every read of the operand buffers is done, no LDS-DMA in flight
+    gemm_epilogue_wide_dispatch<4, 4>(p, acc, m0 + wm * 64, n0 + wn * 64, lane, lds + wave * 16384,
+                                      F8Scale<4>(p, m0 + wm * 64, n0 + wn * 64, l15, h));
+    return;
   }
   f8_epilogue(p, acc, m0 + wm * 64, n0 + wn * 64, l15, h);
 }
@@ -317,6 +344,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_kernel(GemmF8Args p) 
         if (n < p.N) *(f32x4*)(dst + (size_t)m * p.N + n) = acc[i][j];
       }
     }
+    return;
+  }
+  if (p.wide) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // slower waves may still be reading fragments of the last K-step
+    gemm_epilogue_wide_dispatch<8, 4>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, lds8 + wave * 16384,
+                                      F8Scale<8>(p, m0 + wm * 128, n0 + wn * 64, l15, h));
     return;
   }
   // epilogue: two 64-row halves through the shared 4x4 epilogue
@@ -497,6 +531,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_pp_kernel(GemmF8Args 
     }
     return;
   }
+  if (p.wide) {
+    // as in gemm_bf16_256x256_pp_kernel: own LDS-DMA drained (vmcnt(0) above), one more barrier so that no wave stages
+    // over a half-tile another wave's trailing stage is still landing in or a slower wave has yet to read
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    gemm_epilogue_wide_dispatch<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane, lds9 + wave * 16384,
+                                      F8Scale<8>(p, m0 + wr * 128, n0 + wc * 64, l15, h));
+    return;
+  }
 #pragma unroll
   for (int hm = 0; hm < 2; ++hm) {
     f32x4 sub[4][4];
@@ -575,6 +618,11 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
   p.tiles_m = (M + F8_B - 1) / F8_B;
   p.tiles_n = (N + F8_B - 1) / F8_B;
   p.part = nullptr; p.ksplit = 1;
+  static const int wide_env = [] { const char* e = getenv("VIS_GEMM_WIDE"); return e ? atoi(e) : 1; }();   // 0: direct epilogue (A/B)
+  p.wide = wide_env && N % 8 == 0 && ldc % 8 == 0 && (!R || ldr % 8 == 0) && !(((uintptr_t)C | (uintptr_t)R) & 15) &&
+           !(act == F8_ACT_SWIGLU && N % 16 != 0);
+  static const int nt_env = [] { const char* e = getenv("VIS_GEMM_NT"); return e ? atoi(e) : 1; }();
+  p.nt = nt_env == 2 || (nt_env == 1 && (size_t)M * (act == F8_ACT_SWIGLU ? N / 2 : N) * 2 >= ((size_t)64 << 20));
   if (work) {
     if (ksplit < 2 || ksplit > 8 || K / F8_BK < 2 * ksplit || N % 8 != 0 || ldc % 8 != 0 || (R && ldr % 8 != 0) ||
         act == F8_ACT_SWIGLU || ((uintptr_t)work & 15) || (((uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 15))
