@@ -30,7 +30,8 @@
 #endif
 #define F8_BK 128                                  // K elements = bytes per tile row per K-step
 #define F8_STAGE_BYTES (2 * F8_B * F8_BK)          // 65536
-#define F8_LDS_BYTES (2 * F8_STAGE_BYTES)          // 131072
+#define F8_SCALE_BYTES 2048                        // ping-pong kernel: the tile's row + column scales
+#define F8_LDS_BYTES (2 * F8_STAGE_BYTES + F8_SCALE_BYTES)
 
 #include "gemm_epilogue.hip.h"
 enum { F8_ACT_NONE = ACT_NONE, F8_ACT_QUICKGELU = ACT_QUICKGELU, F8_ACT_GELU_ERF = ACT_GELU_ERF, F8_ACT_SWIGLU = ACT_SWIGLU };
@@ -133,6 +134,13 @@ struct F8Scale {
     for (int i = 0; i < MI; ++i) sam[i] = p.sa[min(mbase + i * 16 + l15, p.M - 1)];
 #pragma unroll
     for (int j = 0; j < 4; ++j) s4[j] = *(const f32x4*)(p.sw + min(nbase + j * 16 + 4 * h, p.N - 4));
+  }
+  // from the tile's LDS copy (ping-pong kernel): lsa = the wave's 128 row scales, lsw = its 64 column scales
+  __device__ __forceinline__ F8Scale(const float* lsa, const float* lsw, int l15, int h) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) sam[i] = lsa[i * 16 + l15];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s4[j] = *(const f32x4*)(lsw + j * 16 + 4 * h);
   }
   __device__ __forceinline__ f32x4 operator()(const f32x4& v, int i, int j) const {
     return (f32x4){v[0] * sam[i] * s4[j][0], v[1] * sam[i] * s4[j][1], v[2] * sam[i] * s4[j][2], v[3] * sam[i] * s4[j][3]};
@@ -389,6 +397,16 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_pp_kernel(GemmF8Args 
   const int tn = id / p.tiles_m, tm = id - tn * p.tiles_m;
   const int m0 = tm * F8_B, n0 = tn * F8_B;
 
+  // The tile's 256 row scales and 256 column scales go to LDS behind the operand buffers by LDS-DMA (4 bytes per lane, the
+  // oldest entry of the prologue's vmcnt queue): the epilogue then starts without a global round trip of its own
+  // (tools/gemm_kscan.py KS_FP8=1: the fixed cost per round of tiles is what a 10-step K = 1280 tower projection feels).
+  float* const lds_sc = (float*)(lds9 + 2 * F8P_BUF_BYTES);
+  if (!p.part) {
+    const float* src = (tid < 256) ? p.sa + min(m0 + tid, p.M - 1) : p.sw + min(n0 + tid - 256, p.N - 1);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds_sc + wave * 64), 4, 0, 0);
+  }
+
   uint32_t a_off[2][2], w_off[2][2];   // [half][instruction]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
@@ -536,8 +554,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_256x256_pp_kernel(GemmF8Args 
     // over a half-tile another wave's trailing stage is still landing in or a slower wave has yet to read
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    gemm_epilogue_wide_dispatch<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane, lds9 + wave * 16384,
-                                      F8Scale<8>(p, m0 + wr * 128, n0 + wc * 64, l15, h));
+    const F8Scale<8> sc(lds_sc + wr * 128, lds_sc + 256 + wc * 64, l15, h);   // (behind the buffers: staging does not touch them)
+    gemm_epilogue_wide_dispatch<8, 4>(p, acc, m0 + wr * 128, n0 + wc * 64, lane, lds9 + wave * 16384, sc);
     return;
   }
 #pragma unroll
@@ -630,24 +648,40 @@ extern "C" int vis_gemm_fp8(const void* Aq, const void* sa, const void* Wq, cons
     p.part = (float*)work; p.ksplit = ksplit;
   }
   vis_clear_error();
-  // tile choice (same reasoning as gemm_dispatch for bf16; VIS_GEMM8_TILE=1|4 forces): 256x256 when its last round of
-  // 256 CUs is at least half full, whole rounds + a 128x128 remainder for wide problems, 128x128 (2 WG/CU) otherwise
+  // tile choice by a cost model in us, fitted to tools/gemm_kscan.py KS_FP8=1 on the r05 kernels (VIS_GEMM8_TILE=1|4 forces):
+  //   256 x 256 ping-pong, one workgroup per CU : a round of 256 tiles costs 8.2 + 1.27 per 128-wide K-step
+  //   128 x 128, two workgroups per CU          : a round of 512 tiles costs 4.5 + 1.06 per K-step
+  // candidates: everything on one kernel, or whole rounds of the big tile + the remaining columns on the small one (a
+  // second launch: + 2 us).  r04's rule ("256 only when the last round is at least half full") sent the LLM's qkv / o
+  // projections at 4 images (378 / 294 big tiles) to the small kernel: 121 / 118 us where two big rounds take ~88.
   static const int forced = [] { const char* e = getenv("VIS_GEMM8_TILE"); return e ? atoi(e) : 0; }();
-  const int t4 = p.tiles_m * p.tiles_n, last = t4 % 256;
+  const int t4 = p.tiles_m * p.tiles_n;
+  const int nk = K / F8_BK;
+  const float c256 = 8.2f + 1.27f * nk, c128 = 4.5f + 1.06f * nk;
+  auto rounds = [](long long tiles, int per) { return (float)((tiles + per - 1) / per); };
+  auto tiles128 = [&](int n) { return (long long)((M + 127) / 128) * ((n + 127) / 128); };
+  const float cost_big = rounds(t4, 256) * c256, cost_small = rounds(tiles128(N), 512) * c128;
+  const int cols4 = (t4 / 256) * 256 / p.tiles_m;  // columns of big tiles in whole rounds only
+  const int n_off = cols4 * F8_B;
+  const float cost_mixed = (cols4 > 0 && n_off < N)
+                               ? rounds((long long)cols4 * p.tiles_m, 256) * c256 + rounds(tiles128(N - n_off), 512) * c128 + 2.f
+                               : 1e30f;
+  int choice;   // 4: big, 1: small, 5: mixed
+  if (work || forced == 4) choice = 4;
+  else if (forced == 1 || M < 1024) choice = 1;
+  else choice = (cost_big <= cost_small && cost_big <= cost_mixed) ? 4 : (cost_mixed < cost_small ? 5 : 1);
   auto launch128 = [&](GemmF8Args q) {
     q.tiles_m = (q.M + 127) / 128;
     q.tiles_n = (q.N + 127) / 128;
     hipLaunchKernelGGL(gemm_fp8_128x128_kernel, dim3(q.tiles_m * q.tiles_n), dim3(256), 0, stream, q);
   };
-  if (work || forced == 4 || (!forced && M >= 1024 && t4 >= 384 && (last == 0 || last >= 128))) {
+  if (choice == 4) {
     hipLaunchKernelGGL(k256, dim3(t4, p.ksplit), dim3(512), F8_LDS_BYTES, stream, p);
-  } else if (!forced && M >= 1024 && t4 >= 768) {
-    const int cols4 = (t4 / 256) * 256 / p.tiles_m;  // whole rounds only
+  } else if (choice == 5) {
     GemmF8Args q = p;
     q.N = cols4 * F8_B;
     q.tiles_n = cols4;
     hipLaunchKernelGGL(k256, dim3(q.tiles_m * q.tiles_n, 1), dim3(512), F8_LDS_BYTES, stream, q);
-    const int n_off = cols4 * F8_B;
     const int c_off = (act == F8_ACT_SWIGLU) ? n_off / 2 : n_off;
     GemmF8Args r = p;
     r.W += (size_t)n_off * ldw;
