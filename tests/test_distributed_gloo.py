@@ -74,6 +74,7 @@ def _worker_failure(rank, world, port, paths, outdir, mode):
     from vision_inspection_system_amd import config as C
     from vision_inspection_system_amd.batch import run_multi_image_inspection
     C.set_config(C.Config(vlm_inspector_provider="mock", vlm_auditor_provider="mock"))
+    dist.barrier()      # every rank has finished its imports (seconds apart on a cold page cache): the 5 s below time the exchange only
     if rank == world - 1:
         if mode == "dead":
             os._exit(0)
@@ -131,6 +132,7 @@ def _worker_degraded(rank, world, port, outdir):
     calls = []
     real = B._all_gather_bytes
     B._all_gather_bytes = lambda d, p: (calls.append(1), real(d, p))[1]
+    dist.barrier()      # imports done on every rank before anything is timed against VIS_RANK_TIMEOUT_S
     first, miss0 = B.gather_records_ft([{"r": rank, "n": 0}])            # clean: the collective
     if rank == 1:
         B._DEGRADED[0] = True       # what the except branch leaves behind when an exchange raised on this rank only
