@@ -132,6 +132,16 @@ int vis_decode_attn_shared(const void* qkv, const void* cos_t, const void* sin_t
                            int cache_tokens, int nsplit, float scale, int batch, long long qkv_bs, long long cache_bs,
                            long long tab_bs, int shared_len, vis_stream_t stream);
 
+/* vis_decode_attn_shared with the qkv row finalised inside the attention launch: `part` = the ksplit f32 partial slabs
+ * [slab_rows][(Hq + 2 Hkv) * 128] the batched qkv projection (vis_gemm_decode_bf16 / _fp8) left (slab_rows = 16 / 32 / 64 for batch
+ * <= 16 / <= 32 / beyond), `bias` [n] or NULL, `sx` [batch] / `sw` [n] the e4m3 scales of fp8 partials or both NULL.  Column n of
+ * sequence b = bf16(sum_k part[k][b][n] (* sx[b] * sw[n]) + bias[n]): vis_skinny_finalize's arithmetic bit for bit, i.e. the pair
+ * (vis_skinny_finalize[_fp8], vis_decode_attn_shared) as ONE launch.  shared_len as above (0: none). */
+int vis_decode_attn_parts(const void* part, int ksplit, int slab_rows, const void* bias, const void* sx, const void* sw,
+                          const void* cos_t, const void* sin_t, void* k_cache, void* v_cache, const void* step_ptr,
+                          void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD, int cache_tokens, int nsplit,
+                          float scale, int batch, long long cache_bs, long long tab_bs, int shared_len, vis_stream_t stream);
+
 /* K10 + K4 + K11 + K10 (single-sequence decode)  the head of a decoder layer as ONE launch:
  *   qkv = W_qkv rmsnorm(x) + b ; attn = attention(rope(q), cache + rope(k), v) ; y = x + W_o attn
  * i.e. vis_gemv_bf16 (norm fused) + vis_decode_attn (split + combine launches) + vis_gemv_bf16 (residual), bit-identical to

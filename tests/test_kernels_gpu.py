@@ -1374,3 +1374,63 @@ def test_decode_attn_shared_prefix_is_bit_identical(hip, device, Hq, Hkv, B, T, 
         assert torch.equal(res[name][1], res["own"][1]) and torch.equal(res[name][2], res["own"][2]), f"{name}: KV append differs"
     with pytest.raises(hip.HipLibraryError):
         hip.decode_attn(qkv, cos_t, sin_t, kc, vc, step, po, pml, out, Hq, Hkv, HD, ns, HD ** -0.5, shared_len=100)   # not x 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Hq,Hkv,B,fp8,bias,P", [(28, 4, 64, False, True, 192), (28, 4, 40, False, True, 0), (28, 4, 4, False, True, 0),
+                                                (28, 4, 4, True, True, 0), (28, 4, 64, True, True, 128), (32, 8, 17, False, False, 0),
+                                                (32, 8, 32, True, False, 64), (32, 8, 8, False, False, 0)])
+def test_decode_attn_parts_equals_finalise_then_attention(hip, device, Hq, Hkv, B, fp8, bias, P):
+    """vis_decode_attn_parts (r05): the attention launch finalises the qkv columns it reads from the batched projection's partial
+    slabs.  Outputs and appended K / V rows must equal skinny_finalize[_fp8] + decode_attn bit for bit - split form (small batch)
+    and streaming form, 16- / 32- / 64-row slabs, bf16 and raw-e4m3 partials, with and without bias and shared prefix."""
+    HD, K, T = 128, 1024, 448
+    nq = (Hq + 2 * Hkv) * HD
+    x = _randn((B, K), device, 710, 1.5)
+    w = _randn((nq, K), device, 711, 1.0 / math.sqrt(K))
+    b = _randn((nq,), device, 712) if bias else None
+    part = torch.full((16 * hip.part_rows(B) * nq,), float("nan"), dtype=torch.float32, device=device)
+    if fp8:
+        xq, sx = hip.quant_rows_fp8(x)
+        wq, sw = hip.quantize_fp8_rows(w)
+        ks = hip.decode_gemm_fp8(xq, sx, wq, sw, part=part)
+    else:
+        sx = sw = None
+        ks = hip.decode_gemm(x, w, part=part)
+    rng = np.random.default_rng(713)
+    ctx = [int(c) for c in rng.integers(max(P, 1), T - 1, B)]
+    ctx[0], ctx[-1] = max(P, 1), T - 2
+    kc = _randn((B, Hkv, T, HD), device, 714)
+    vc = _randn((B, Hkv, T, HD), device, 715)
+    if P:
+        kc[:, :, :P] = kc[0:1, :, :P]
+        vc[:, :, :P] = vc[0:1, :, :P]
+    g = torch.Generator().manual_seed(716)
+    ang = torch.rand((T, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos_t = emb.cos().to(device).unsqueeze(0).expand(B, -1, -1)
+    sin_t = emb.sin().to(device).unsqueeze(0).expand(B, -1, -1)
+    step = torch.tensor(ctx, dtype=torch.int32, device=device)
+    ns = -(-T // hip.DECODE_KEYS_PER_SPLIT)
+    po = torch.empty(B * Hq * ns * HD, dtype=torch.float32, device=device)
+    pml = torch.empty(B * Hq * ns * 2, dtype=torch.float32, device=device)
+    # the pair
+    qkv = torch.empty((B, nq), dtype=torch.bfloat16, device=device)
+    if fp8:
+        hip.skinny_finalize_fp8(part, ks, qkv, nq, sx=sx, sw=sw, bias=b)
+    else:
+        hip.skinny_finalize(part, ks, qkv, nq, bias=b)
+    k1, v1 = kc.clone(), vc.clone()
+    out1 = torch.full((B, Hq * HD), 7.0, dtype=torch.bfloat16, device=device)
+    hip.decode_attn(qkv, cos_t, sin_t, k1, v1, step, po, pml, out1, Hq, Hkv, HD, ns, HD ** -0.5, shared_len=P)
+    # one launch
+    k2, v2 = kc.clone(), vc.clone()
+    out2 = torch.full((B, Hq * HD), -3.0, dtype=torch.bfloat16, device=device)
+    hip.decode_attn_parts(part, ks, cos_t, sin_t, k2, v2, step, po, pml, out2, Hq, Hkv, HD, ns, HD ** -0.5, bias=b, sx=sx, sw=sw,
+                          shared_len=P)
+    assert torch.isfinite(out1.float()).all()
+    assert torch.equal(out1, out2), f"max diff {(out1.float() - out2.float()).abs().max().item()}"
+    assert torch.equal(k1, k2) and torch.equal(v1, v2), "appended K / V rows differ"
+    with pytest.raises(hip.HipLibraryError):      # scales come in pairs
+        hip.decode_attn_parts(part, ks, cos_t, sin_t, k2, v2, step, po, pml, out2, Hq, Hkv, HD, ns, HD ** -0.5,
+                              sx=torch.ones(B, dtype=torch.float32, device=device))

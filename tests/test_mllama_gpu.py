@@ -226,3 +226,25 @@ def test_max_batch_one_engine_serves_callable_requests(device):
     assert len(out) == 1 and isinstance(out[0], OSError)
     with pytest.raises(ValueError):
         eng.generate_batch([(ids, fr), (ids, fr)], max_new_tokens=4)      # two requests do not fit max_batch = 1
+
+
+def test_mllama_folded_qkv_finalisation_changes_nothing(device, monkeypatch):
+    """VIS_QKV_FOLD on the Auditor: in the batched step its self-attention layers read the qkv projection's partial slabs directly
+    (vis_decode_attn_parts: no bias, the rope table shared by the batch = stride 0).  Tokens and last-step logits equal to the
+    two-launch step bit for bit."""
+    from vision_inspection_system_amd.mllama_engine import MllamaEngine
+    from vision_inspection_system_amd.mllama_weights import MllamaConfig, pack_device_weights, synth_state_dict
+    cfg = MllamaConfig.tiny()
+    sd = synth_state_dict(cfg, seed=0)
+    g = np.load(os.path.join(HERE, "golden", "mllama_tiny.npz"))
+    reqs = [(g[f"{c}_ids"].tolist(), torch.from_numpy(g[f"{c}_image"]).to(device)) for c in "abc"]
+    res = {}
+    for fold in ("0", "1"):
+        monkeypatch.setenv("VIS_QKV_FOLD", fold)
+        eng = MllamaEngine(cfg, pack_device_weights(cfg, sd, device), device, max_ctx=256, max_batch=5)
+        assert eng.fold_qkv == (fold == "1")
+        toks = eng.generate_batch(reqs + [reqs[0], reqs[2]], max_new_tokens=10, stop_on_eos=False)
+        res[fold] = (toks, eng.logits_b[:5].clone())
+        del eng
+    assert res["0"][0] == res["1"][0]
+    assert torch.equal(res["0"][1], res["1"][1])

@@ -52,6 +52,18 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
+// One column of a finalised split-K projection row: the fixed-order sum `a` of its f32 partials, times the e4m3 scales
+// (fp8 form: sxb * swn), plus the bias - the arithmetic of skinny_finalize_kernel's plain mode, shared with the decode attention
+// kernels that finalise the qkv row themselves (vis_decode_attn_parts), so both produce the same bits.  Contraction is off:
+// whether `a * s + bias` becomes an FMA must not depend on the kernel the expression is inlined into.
+__device__ __forceinline__ float fin_plain_value(float a, bool scaled, float sxb, float swn, bool has_bias, float bias) {
+#pragma clang fp contract(off)
+  float v = a;
+  if (scaled) v = v * (sxb * swn);
+  if (has_bias) v = v + bias;
+  return v;
+}
+
 // x * sigmoid(k x) = x / (1 + e^(-k x)) with ONE v_exp_f32 and ONE v_rcp_f32 (each 1 ulp): the IEEE division the
 // plain expression compiles to costs ~10 VALU instructions per element, which made the activation epilogues of the
 // prefill GEMMs (128 elements per thread on a 256 x 256 tile) 16 us per tile round (tools/gemm_kscan.py: fixed cost

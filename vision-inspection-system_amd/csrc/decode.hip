@@ -531,7 +531,9 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
     for (int it = tid; it < (G + 1) * HALF; it += 512) {
       const int g = it / HALF, d = it - g * HALF;
       const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
-      const float a = bf2f(p.qkv[head * HD + d]), b = bf2f(p.qkv[head * HD + HALF + d]);
+      bf16_t qa, qb;
+      da_qkv2(p, seq, head * HD + d, head * HD + HALF + d, qa, qb);
+      const float a = bf2f(qa), b = bf2f(qb);
       const bf16_t oa = f2bf(a * cr[d] - b * sr[d]);
       const bf16_t ob = f2bf(b * cr[HALF + d] + a * sr[HALF + d]);
       bf16_t* dst = (g < G) ? q_s[g] : knew_s;
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
       dst[HALF + d] = ob;
     }
     for (int it = tid; it < (16 - G) * HD; it += 512) q_s[G + it / HD][it % HD] = 0;
-    if (tid < HD) vnew_s[tid] = p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid];
+    if (tid < HD) vnew_s[tid] = da_qkv(p, seq, (p.Hq + p.Hkv + hkv) * HD + tid);
     __syncthreads();
     if (tid < HD) {  // KV-cache append: this workgroup is the only reader and writer of the row in this launch
       Kh[(size_t)slot * HD + tid] = knew_s[tid];
@@ -775,6 +777,7 @@ extern "C" int vis_decode_attn(const void* qkv, const void* cos_t, const void* s
   p.qkv_bs = qkv_bs; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
   p.q_norm_w = nullptr; p.q_eps = 0.f;
   p.shared_len = 0;
+  da_no_parts(p);
   return decode_attn_launch(p, out, batch, stream);
 }
 
@@ -808,6 +811,43 @@ extern "C" int vis_decode_attn_shared(const void* qkv, const void* cos_t, const 
   p.qkv_bs = qkv_bs; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
   p.q_norm_w = nullptr; p.q_eps = 0.f;
   p.shared_len = shared_len;
+  da_no_parts(p);
+  return decode_attn_launch(p, out, batch, stream);
+}
+
+// vis_decode_attn_shared without the qkv finalisation launch in front of it: the batched qkv projection (vis_gemm_decode_bf16 /
+// _fp8) leaves `ksplit` f32 partial slabs of `slab_rows` x n_qkv (slab_rows = 16 / 32 / 64 for batch <= 16 / <= 32 / beyond, as
+// vis_skinny_finalize assumes); every (kv head, sequence) workgroup sums the 1152 columns it needs itself - fixed order, * sx[b] *
+// sw[n] for fp8 partials, + bias, one rounding to bf16: skinny_finalize_kernel's arithmetic (fin_plain_value), so results are
+// bit-identical to vis_skinny_finalize(..) + vis_decode_attn_shared(..), one launch and one ~5 us dependent kernel per layer less.
+extern "C" int vis_decode_attn_parts(const void* part, int ksplit, int slab_rows, const void* bias, const void* sx,
+                                     const void* sw, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                                     const void* step_ptr, void* part_o, void* part_ml, void* out, int Hq, int Hkv, int HD,
+                                     int cache_tokens, int nsplit, float scale, int batch, long long cache_bs,
+                                     long long tab_bs, int shared_len, hipStream_t stream) {
+  if (!part || !cos_t || !sin_t || !k_cache || !v_cache || !step_ptr || !part_o || !part_ml || !out) return VIS_ERR_ARG;
+  if (shared_len < 0 || shared_len % 64 != 0 || shared_len >= cache_tokens) return VIS_ERR_ARG;
+  if (batch <= 0 || batch > 64 || (batch > 1 && (cache_bs <= 0 || tab_bs < 0)) || (cache_bs % 8)) return VIS_ERR_ARG;
+  if (ksplit < 1 || ksplit > 16 || slab_rows < batch || (slab_rows != 16 && slab_rows != 32 && slab_rows != 64)) return VIS_ERR_ARG;
+  if ((sx != nullptr) != (sw != nullptr)) return VIS_ERR_ARG;
+  if (HD != 128 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0) return VIS_ERR_ARG;
+  const int G = Hq / Hkv;
+  if (G != 1 && G != 2 && G != 4 && G != 7 && G != 8) return VIS_ERR_ARG;
+  if (nsplit <= 0 || nsplit > 256 || cache_tokens <= 0 || (long long)nsplit * DA_MAXKEYS < cache_tokens) return VIS_ERR_ARG;
+  if (((uintptr_t)k_cache | (uintptr_t)v_cache) & 15 || ((uintptr_t)part | (uintptr_t)sx | (uintptr_t)sw) & 3 || ((uintptr_t)bias & 1))
+    return VIS_ERR_ARG;
+  DecAttnArgs p;
+  p.qkv = nullptr; p.cos_t = (const float*)cos_t; p.sin_t = (const float*)sin_t;
+  p.k_cache = (bf16_t*)k_cache; p.v_cache = (bf16_t*)v_cache; p.step_ptr = (const int*)step_ptr;
+  p.part_o = (float*)part_o; p.part_ml = (float*)part_ml;
+  p.Hq = Hq; p.Hkv = Hkv; p.cache_tokens = cache_tokens; p.nsplit = nsplit;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.qkv_bs = 0; p.cache_bs = cache_bs; p.tab_bs = tab_bs;
+  p.q_norm_w = nullptr; p.q_eps = 0.f;
+  p.shared_len = shared_len;
+  p.part_n = (Hq + 2 * Hkv) * 128;
+  p.qkv_part = (const float*)part; p.part_stride = (long long)slab_rows * p.part_n; p.part_ks = ksplit;
+  p.qkv_bias = (const bf16_t*)bias; p.part_sx = (const float*)sx; p.part_sw = (const float*)sw;
   return decode_attn_launch(p, out, batch, stream);
 }
 
@@ -834,6 +874,7 @@ static int decode_cross_attn_impl(const void* q, const void* q_norm_w, const voi
   p.qkv_bs = q_bs; p.cache_bs = kv_bs; p.tab_bs = 0;
   p.q_norm_w = (const bf16_t*)q_norm_w; p.q_eps = eps;
   p.shared_len = 0;
+  da_no_parts(p);
   return decode_attn_launch(p, out, batch, stream);
 }
 

@@ -88,19 +88,15 @@ __global__ __launch_bounds__(FIN_THREADS) void skinny_finalize_kernel(FinArgs p)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = silu_fast(ga[r]) * ua[r];
     } else {
-      f32x4 a = fin_sum_dyn(pb + o, stride, p.ksplit);
-      if (p.sx) {
-        const float sxb = p.sx[b];
-        const f32x4 s4 = *(const f32x4*)(p.sw + o);
+      const f32x4 a = fin_sum_dyn(pb + o, stride, p.ksplit);
+      const bool scaled = p.sx != nullptr, has_b = p.bias != nullptr;
+      const float sxb = scaled ? p.sx[b] : 0.f;
+      const f32x4 s4 = scaled ? *(const f32x4*)(p.sw + o) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const u32x2 bb = has_b ? *(const u32x2*)(p.bias + o) : (u32x2){0u, 0u};
+      const float bf[4] = {__uint_as_float(bb[0] << 16), __uint_as_float(bb[0] & 0xffff0000u), __uint_as_float(bb[1] << 16),
+                           __uint_as_float(bb[1] & 0xffff0000u)};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a[r] *= sxb * s4[r];
-      }
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3];
-      if (p.bias) {
-        const u32x2 bb = *(const u32x2*)(p.bias + o);
-        v[0] += __uint_as_float(bb[0] << 16); v[1] += __uint_as_float(bb[0] & 0xffff0000u);
-        v[2] += __uint_as_float(bb[1] << 16); v[3] += __uint_as_float(bb[1] & 0xffff0000u);
-      }
+      for (int r = 0; r < 4; ++r) v[r] = fin_plain_value(a[r], scaled, sxb, s4[r], has_b, bf[r]);   // (common.hip.h)
       if (p.R) {
         const u32x2 rr = *(const u32x2*)(p.R + (size_t)b * p.ldr + o);
         v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);

@@ -432,6 +432,7 @@ extern "C" int vis_decode_chain(const void* x, const void* x_idx, int x_rows, co
   p.att.qkv_bs = 0; p.att.cache_bs = 0; p.att.tab_bs = 0;
   p.att.q_norm_w = nullptr; p.att.q_eps = 0.f;
   p.att.shared_len = 0;
+  da_no_parts(p.att);
   p.qkv_g = (gran_t*)ws;
   p.attn_g = p.qkv_g + Nqkv / 2;
   p.part_g = p.attn_g + Hq * 64;

@@ -293,7 +293,56 @@ struct DecAttnArgs {
   // text prefix a batch inspection shares, copied into every slot by the prompt passes) and are read from sequence 0's
   // copy - same values, so the same result bit for bit, but one HBM read + L2 hits instead of one HBM read per sequence
   int shared_len;
+  // vis_decode_attn_parts: `qkv` is null and the projection row is finalised HERE from the split-K partials of the batched
+  // qkv projection (vis_gemm_decode_*): column n of sequence b = bf16(sum_k part[k * part_stride + b * part_n + n] (* sx[b] *
+  // sw[n]) + bias[n]) - skinny_finalize_kernel's arithmetic bit for bit (fin_plain_value), minus its launch
+  const float* qkv_part;
+  long long part_stride;   // floats between two partial slabs
+  int part_ks, part_n;
+  const bf16_t* qkv_bias;  // [part_n] or null
+  const float* part_sx;    // [batch] or null (fp8 partials: raw sums of e4m3 products)
+  const float* part_sw;    // [part_n]
 };
+
+static inline void da_no_parts(DecAttnArgs& p) {
+  p.qkv_part = nullptr; p.part_stride = 0; p.part_ks = 0; p.part_n = 0; p.qkv_bias = nullptr; p.part_sx = nullptr; p.part_sw = nullptr;
+}
+
+// the bf16 values of columns `col0` and `col1` of sequence `seq`'s projection row (p.qkv already points at the sequence's row).
+// Partial mode: every slab's word is requested before the first add (ONE memory round trip, like the bf16 read it replaces - a
+// load -> add -> load chain over ksplit slabs cost more than the finalisation launch it removes); slabs past ksplit are read
+// at a clamped index and dropped by a select, so the sum keeps skinny_finalize_kernel's order exactly.
+#define DA_PART_UNROLL 8
+__device__ __forceinline__ void da_qkv2(const DecAttnArgs& p, int seq, int col0, int col1, bf16_t& v0, bf16_t& v1) {
+  if (!p.qkv_part) { v0 = p.qkv[col0]; v1 = p.qkv[col1]; return; }
+  const float* b0 = p.qkv_part + (size_t)seq * p.part_n + col0;
+  const float* b1 = p.qkv_part + (size_t)seq * p.part_n + col1;
+  float t0[DA_PART_UNROLL], t1[DA_PART_UNROLL];
+#pragma unroll
+  for (int k = 0; k < DA_PART_UNROLL; ++k) {
+    const size_t o = (size_t)min(k, p.part_ks - 1) * p.part_stride;
+    t0[k] = b0[o];
+    t1[k] = b1[o];
+  }
+  const bool scaled = p.part_sx != nullptr, has_b = p.qkv_bias != nullptr;
+  const float sxb = scaled ? p.part_sx[seq] : 0.f;
+  const float sw0 = scaled ? p.part_sw[col0] : 0.f, sw1 = scaled ? p.part_sw[col1] : 0.f;
+  const float bi0 = has_b ? bf2f(p.qkv_bias[col0]) : 0.f, bi1 = has_b ? bf2f(p.qkv_bias[col1]) : 0.f;
+  float a0 = t0[0], a1 = t1[0];
+#pragma unroll
+  for (int k = 1; k < DA_PART_UNROLL; ++k) {
+    a0 = (k < p.part_ks) ? a0 + t0[k] : a0;
+    a1 = (k < p.part_ks) ? a1 + t1[k] : a1;
+  }
+  for (int k = DA_PART_UNROLL; k < p.part_ks; ++k) { a0 += b0[(size_t)k * p.part_stride]; a1 += b1[(size_t)k * p.part_stride]; }
+  v0 = f2bf(fin_plain_value(a0, scaled, sxb, sw0, has_b, bi0));
+  v1 = f2bf(fin_plain_value(a1, scaled, sxb, sw1, has_b, bi1));
+}
+__device__ __forceinline__ bf16_t da_qkv(const DecAttnArgs& p, int seq, int col) {
+  bf16_t v0, v1;
+  da_qkv2(p, seq, col, col, v0, v1);
+  return v0;
+}
 
 // Structure (no cross-lane reductions inside a wave):
 //   scores : S^T[key][head] = K * Q^T on the MFMA (v_mfma_f32_16x16x32_bf16): a K row group of 16 keys x 128
@@ -440,7 +489,10 @@ __device__ __forceinline__ int decode_attn_split_body(DecAttnArgs p, DecAttnLds<
       if (it >= (G + 1) * HALF) break;
       const int g = it / HALF, d = it - g * HALF;
       const int head = (g < G) ? hkv * G + g : p.Hq + hkv;
-      const float a = bf2f(CHAIN ? L.raw[g][d] : p.qkv[head * HD + d]), b = bf2f(CHAIN ? L.raw[g][HALF + d] : p.qkv[head * HD + HALF + d]);
+      bf16_t qa, qb;
+      if constexpr (CHAIN) { qa = L.raw[g][d]; qb = L.raw[g][HALF + d]; }
+      else da_qkv2(p, seq, head * HD + d, head * HD + HALF + d, qa, qb);
+      const float a = bf2f(qa), b = bf2f(qb);
       const bf16_t oa = f2bf(a * rc0[k] - b * rs0[k]);
       const bf16_t ob = f2bf(b * rc1[k] + a * rs1[k]);
       bf16_t* dst = (g < G) ? q_s[g] : knew_s;
@@ -448,7 +500,7 @@ __device__ __forceinline__ int decode_attn_split_body(DecAttnArgs p, DecAttnLds<
       dst[HALF + d] = ob;
     }
     for (int it = tid; it < (16 - G) * HD; it += 256) q_s[G + it / HD][it % HD] = 0;
-    if (tid < HD) vnew_s[tid] = CHAIN ? L.raw[G + 1][tid] : p.qkv[(p.Hq + p.Hkv + hkv) * HD + tid];
+    if (tid < HD) vnew_s[tid] = CHAIN ? L.raw[G + 1][tid] : da_qkv(p, seq, (p.Hq + p.Hkv + hkv) * HD + tid);
     __syncthreads();
     owner = (slot >= ks) && (slot < ke);
     if (owner && tid < HD) {  // KV-cache append (no other block reads this row in this launch)

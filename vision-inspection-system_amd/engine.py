@@ -205,6 +205,9 @@ class Qwen2VLEngine:
         # trips wherever it runs, and the finalisation launch it replaces already sits at the ~5 us floor of a dependent
         # load -> store kernel (profiles/r05_decode_step_*.txt: 64 sequences 5.37 -> 6.4 ms per step).
         self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "0") == "1"
+        # batched decode: the self-attention launch finalises the qkv projection's partial slabs itself (vis_decode_attn_parts,
+        # bit-identical to skinny_finalize + decode_attn); VIS_QKV_FOLD=0 keeps the two launches (A/B)
+        self.fold_qkv = os.environ.get("VIS_QKV_FOLD", "1") == "1"
         if self.fused_proj:
             self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)        # x * ln1_w of the next layer (A operand of qkv / lm_head)
             self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)       # x2 * ln2_w (A operand of gate/up)
@@ -1108,10 +1111,15 @@ class Qwen2VLEngine:
         n_layers = len(w.llm)
         for li, lw in enumerate(w.llm):
             ks = hip.decode_gemm(xn, lw.qkv_w, part=part)
-            hip.skinny_finalize(part, ks, qkv, nq, bias=lw.qkv_b, eps=eps)
-            hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
-                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
-                            shared_len=self.batch_shared_len)
+            if self.fold_qkv:     # the attention workgroups finalise the qkv columns they read (same bits, one launch less)
+                hip.decode_attn_parts(part, ks, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                                      self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                                      bias=lw.qkv_b, shared_len=self.batch_shared_len)
+            else:
+                hip.skinny_finalize(part, ks, qkv, nq, bias=lw.qkv_b, eps=eps)
+                hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                                self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                                shared_len=self.batch_shared_len)
             ks = hip.decode_gemm(att, lw.o_w, part=part)
             hip.skinny_finalize(part, ks, x2, cfg.hidden, residual=x, norm_w=lw.ln2_w, yn=xn2, eps=eps)
             ks = hip.decode_gemm(xn2, lw.gateup_w, part=part)
@@ -1244,10 +1252,15 @@ class Qwen2VLEngine:
         for li, lw in enumerate(w.llm):
             q8 = self.q8[li]
             ks = hip.decode_gemm_fp8(xq, sxq, *q8["qkv_w"], part=part)
-            hip.skinny_finalize_fp8(part, ks, qkv, nq, sx=sxq, sw=q8["qkv_w"][1], bias=lw.qkv_b, eps=eps)
-            hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
-                            self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
-                            shared_len=self.batch_shared_len)
+            if self.fold_qkv:
+                hip.decode_attn_parts(part, ks, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                                      self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                                      bias=lw.qkv_b, sx=sxq, sw=q8["qkv_w"][1], shared_len=self.batch_shared_len)
+            else:
+                hip.skinny_finalize_fp8(part, ks, qkv, nq, sx=sxq, sw=q8["qkv_w"][1], bias=lw.qkv_b, eps=eps)
+                hip.decode_attn(qkv, self.cos_b[:B], self.sin_b[:B], self.kcache_b[:B, li], self.vcache_b[:B, li],
+                                self.step_b[:B], self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale,
+                                shared_len=self.batch_shared_len)
             ks = hip.decode_gemm(att, lw.o_w, part=part)
             hip.skinny_finalize_fp8(part, ks, x2, cfg.hidden, residual=x, norm_w=lw.ln2_w, yn=xn2, yq=x2q,
                                     yq_scale=sx2q, eps=eps)

@@ -42,6 +42,7 @@ _SIGS = {
     "vis_gemv_fp8w_rows": "ppppppp" + "iiiiiiiii" + "f" + "p",
     "vis_decode_attn": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "p",
     "vis_decode_attn_shared": "ppppppppp" + "iiiii" + "f" + "i" + "lll" + "i" + "p",
+    "vis_decode_attn_parts": "p" + "ii" + "p" * 11 + "iiiii" + "f" + "i" + "ll" + "i" + "p",
     "vis_decode_chain_sync_ints": "",
     "vis_decode_chain_ws_bytes": "iii",
     "vis_decode_chain_ctx_limit": "iii",
@@ -717,6 +718,49 @@ def gemv_fp8_rows(x: torch.Tensor, wq: torch.Tensor, scale: torch.Tensor, out: t
                                    residual.stride(0) if residual is not None else 0, act,
                                    1 if out.dtype == torch.float32 else 0, eps, _stream())
     _check(rc, "vis_gemv_fp8w_rows")
+    return out
+
+
+def decode_attn_parts(part: torch.Tensor, ksplit: int, cos_t: torch.Tensor, sin_t: torch.Tensor, k_cache: torch.Tensor,
+                      v_cache: torch.Tensor, step: torch.Tensor, part_o: torch.Tensor, part_ml: torch.Tensor,
+                      out: torch.Tensor, n_q: int, n_kv: int, head_dim: int, nsplit: int, scale: float,
+                      bias: Optional[torch.Tensor] = None, sx: Optional[torch.Tensor] = None,
+                      sw: Optional[torch.Tensor] = None, shared_len: int = 0) -> torch.Tensor:
+    """``skinny_finalize[_fp8](part, ksplit, qkv, ..)`` + ``decode_attn(qkv, ..)`` of a batch as ONE launch: the attention
+    workgroups finalise the qkv columns they need from the projection's partial slabs (same bits as the pair).
+    Batch of B: caches [B,Hkv,T,D], tables [B,T,D], step [B], out [B, Hq*D]; ``part`` as decode_gemm[_fp8] left it."""
+    _bf16(k_cache, "k_cache")
+    if step.dtype != torch.int32 or cos_t.dtype != torch.float32 or sin_t.dtype != torch.float32 or part.dtype != torch.float32:
+        raise HipLibraryError("decode_attn_parts: step int32 / cos,sin,part f32 required")
+    if k_cache.dim() != 4:
+        raise HipLibraryError("decode_attn_parts: batched caches [B, Hkv, T, D] required")
+    B = k_cache.shape[0]
+    kc = k_cache[0]
+    if kc.shape[0] != n_kv or kc.shape[2] != head_dim or v_cache.shape != k_cache.shape \
+            or kc.stride(2) != 1 or kc.stride(1) != head_dim or kc.stride(0) != kc.shape[1] * head_dim:
+        raise HipLibraryError("decode_attn_parts: bad cache shape")
+    T = kc.shape[1]
+    if cos_t[0].shape != (T, head_dim) or sin_t.shape != cos_t.shape or not cos_t[0].is_contiguous():
+        raise HipLibraryError("decode_attn_parts: cos/sin tables must be [B, cache_tokens, head_dim]")
+    nq = (n_q + 2 * n_kv) * head_dim
+    rows = part_rows(B)
+    if part.numel() < ksplit * rows * nq or step.numel() != B:
+        raise HipLibraryError("decode_attn_parts: partial buffer too small / bad step shape")
+    if part_o.dtype != torch.float32 or part_o.numel() < B * n_q * nsplit * head_dim \
+            or part_ml.numel() < B * n_q * nsplit * 2 or out.numel() != B * n_q * head_dim:
+        raise HipLibraryError("decode_attn_parts: workspace/output too small")
+    if bias is not None and (bias.dtype != torch.bfloat16 or bias.numel() != nq):
+        raise HipLibraryError("decode_attn_parts: bad bias")
+    if (sx is None) != (sw is None) or (sx is not None and (sx.dtype != torch.float32 or sw.dtype != torch.float32
+                                                          or sx.numel() < B or sw.numel() != nq)):
+        raise HipLibraryError("decode_attn_parts: bad scales")
+    if v_cache.stride(0) != k_cache.stride(0) or cos_t.stride(0) != sin_t.stride(0):
+        raise HipLibraryError("decode_attn_parts: k/v caches (cos/sin tables) must share their batch stride")
+    rc = load().vis_decode_attn_parts(_ptr(part), int(ksplit), rows, _ptr(bias), _ptr(sx), _ptr(sw), _ptr(cos_t), _ptr(sin_t),
+                                      _ptr(k_cache), _ptr(v_cache), _ptr(step), _ptr(part_o), _ptr(part_ml), _ptr(out),
+                                      n_q, n_kv, head_dim, T, nsplit, scale, B, k_cache.stride(0), cos_t.stride(0),
+                                      int(shared_len), _stream())
+    _check(rc, "vis_decode_attn_parts")
     return out
 
 

@@ -151,6 +151,9 @@ class MllamaEngine:
         # r05 experiment, OFF by default (VIS_DECODE_FUSED=1): every batched-decode projection as ONE launch (vis_decode_proj_bf16:
         # stream + split-K reduction + epilogue; Qwen2VLEngine.__init__ says why it is not the default).
         self.fused_proj = Bm > 1 and H % 128 == 0 and os.environ.get("VIS_DECODE_FUSED", "0") == "1"
+        # batched decode: the self-attention launch finalises the qkv projection's partial slabs itself (vis_decode_attn_parts,
+        # bit-identical to skinny_finalize + decode_attn); VIS_QKV_FOLD=0 keeps the two launches (A/B)
+        self.fold_qkv = os.environ.get("VIS_QKV_FOLD", "1") == "1"
         if self.fused_proj:
             self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)
             self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)
@@ -726,9 +729,13 @@ class MllamaEngine:
                 ci += 1
             else:
                 ks = hip.decode_gemm(xn, lw.qkv_w, part=part)
-                hip.skinny_finalize(part, ks, qkv, nq, eps=eps)
-                hip.decode_attn(qkv, cosb, sinb, self.kcache_b[:B, si], self.vcache_b[:B, si], self.step_b[:B],
-                                self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                if self.fold_qkv:      # the attention workgroups finalise the qkv columns they read (same bits, one launch less)
+                    hip.decode_attn_parts(part, ks, cosb, sinb, self.kcache_b[:B, si], self.vcache_b[:B, si], self.step_b[:B],
+                                          self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
+                else:
+                    hip.skinny_finalize(part, ks, qkv, nq, eps=eps)
+                    hip.decode_attn(qkv, cosb, sinb, self.kcache_b[:B, si], self.vcache_b[:B, si], self.step_b[:B],
+                                    self.part_o, self.part_ml, att, Hq, Hkv, D, self.nsplit, scale)
                 si += 1
             ks = hip.decode_gemm(att, lw.o_w, part=part)
             hip.skinny_finalize(part, ks, x2, H, residual=x, norm_w=lw.ln2_w, yn=xn2, eps=eps)
