@@ -71,6 +71,15 @@ int vis_qkv_rope_split(const void* qkv, const void* cosv, const void* sinv, void
                        void* vt, int S, int ld_qkv, int Hq, int Hkv, int HD, int k_tokens, int k_pos0,
                        int vt_ld, vis_stream_t stream);
 
+/* vis_qkv_rope_split for the nreq (<= 8) requests of one prompt-pass group as ONE launch (the engine's stacked suffix pass,
+ * replacing the per-image loop of /root/reference/src/orchestration/graph.py:308-357 one level down): request r reads the S rows at
+ * qkv + r * qkv_bs (same cos / sin rows for all: the requests share their prompt structure) and writes q + r * q_bs,
+ * k + kv_off[r] and v + kv_off[r] (element offsets of its cache slot; HOST array of nreq values), vt + r * vt_bs.  Strides and
+ * offsets in elements, multiples of 8.  Per request bit-identical to vis_qkv_rope_split. */
+int vis_qkv_rope_split_many(const void* qkv, const void* cosv, const void* sinv, void* q, void* k, void* v, void* vt, int S,
+                            int ld_qkv, int Hq, int Hkv, int HD, int k_tokens, int k_pos0, int vt_ld, int nreq,
+                            long long qkv_bs, long long q_bs, long long vt_bs, const long long* kv_off, vis_stream_t stream);
+
 /* K6/K7  flash-style prefill attention over a host-built work list of
  * {q0, qn<=128, k0, k1} int4 tiles (device memory): ViT varlen segments (cu_seqlens,
  * TF modeling_qwen2_vl.py:356-423) and LLM causal GQA prefill (:508-556).
@@ -92,6 +101,13 @@ int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O,
 int vis_attn_prefill_pairs(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
                            int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, float scale,
                            int q_row0, vis_stream_t stream);
+
+/* vis_attn_prefill_pairs for the nreq (<= 8) requests of one prompt-pass group as ONE launch (same work list): request r reads
+ * Q + r * q_bs, K + kv_off[r] (HOST array, element offsets), Vt + r * vt_bs and writes O + r * o_bs.  Per request bit-identical to
+ * vis_attn_prefill_pairs; the grid grows from Hq x n_work (168 workgroups for a 1289-row suffix) to Hq x n_work x nreq. */
+int vis_attn_prefill_pairs_many(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work, int Hq,
+                                int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, float scale, int q_row0, int nreq,
+                                long long q_bs, long long vt_bs, long long o_bs, const long long* kv_off, vis_stream_t stream);
 
 /* K6, key-split form (HD = 80, non-causal: the ViT towers).  Work items as in vis_attn_prefill plus SPLIT items, whose
  * y field is qn | (1 | part << 1 | pair << 2) << 8: parts 0 and 1 of pair `pair` cover the same query rows and the two

@@ -1434,3 +1434,50 @@ def test_decode_attn_parts_equals_finalise_then_attention(hip, device, Hq, Hkv, 
     with pytest.raises(hip.HipLibraryError):      # scales come in pairs
         hip.decode_attn_parts(part, ks, cos_t, sin_t, k2, v2, step, po, pml, out2, Hq, Hkv, HD, ns, HD ** -0.5,
                               sx=torch.ones(B, dtype=torch.float32, device=device))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,Hq,Hkv,S,P", [(4, 28, 4, 1289, 960), (3, 8, 2, 200, 64), (8, 4, 4, 77, 0), (1, 28, 4, 300, 128)])
+def test_group_rope_split_and_pair_attention_equal_per_request_launches(hip, device, k, Hq, Hkv, S, P):
+    """vis_qkv_rope_split_many / vis_attn_prefill_pairs_many (r05): the requests of a stacked prompt-pass group as ONE launch each.
+    Everything a request's launches would have written - q, its cache slot's K / V rows, its V^T columns, its attention rows - must
+    be bit-identical, arbitrary (non-consecutive) cache slots, nothing else touched."""
+    HD, L, T = 128, 2, P + S + 40
+    li = 1
+    ld = (T + 63) // 64 * 64
+    nq = (Hq + 2 * Hkv) * HD
+    slots_total = k + 3
+    slots = torch.randperm(slots_total, generator=torch.Generator().manual_seed(729 + k))[:k].tolist()   # arbitrary, distinct
+    qkv = _randn((k * S, nq), device, 730)
+    g = torch.Generator().manual_seed(731)
+    ang = torch.rand((S, HD // 2), generator=g) * 6.28
+    emb = torch.cat((ang, ang), -1)
+    cos, sin = emb.cos().to(device).contiguous(), emb.sin().to(device).contiguous()
+    kc0 = _randn((slots_total, L, Hkv, T, HD), device, 732)
+    vc0 = _randn((slots_total, L, Hkv, T, HD), device, 733)
+    vt0 = _randn((k, L, Hkv, HD, ld), device, 734)
+    work = hip.make_attn_pairs(P, P + S, device)
+    scale = HD ** -0.5
+    # per request
+    kc1, vc1, vt1 = kc0.clone(), vc0.clone(), vt0.clone()
+    q1 = torch.zeros((k, Hq, S, HD), dtype=torch.bfloat16, device=device)
+    o1 = torch.zeros((k * S, Hq * HD), dtype=torch.bfloat16, device=device)
+    for j, sl in enumerate(slots):
+        rows = slice(j * S, (j + 1) * S)
+        hip.qkv_rope_split(qkv[rows], cos, sin, q1[j], kc1[sl][li], vc1[sl][li], vt1[j][li], Hq, Hkv, HD, k_pos0=P, vt_col0=P // 64 * 64)
+        hip.attn_prefill_pairs(q1[j], kc1[sl][li], vt1[j][li], o1[rows], work, scale, q_row0=P)
+    # one launch each
+    kc2, vc2, vt2 = kc0.clone(), vc0.clone(), vt0.clone()
+    q2 = torch.zeros_like(q1)
+    o2 = torch.zeros_like(o1)
+    kv_off = [sl * kc2.stride(0) + li * kc2.stride(1) for sl in slots]
+    hip.qkv_rope_split_many(qkv, cos, sin, q2, kc2, vc2, vt2[:, li], Hq, Hkv, HD, kv_off, T, k_pos0=P, vt_col0=P // 64 * 64)
+    hip.attn_prefill_pairs_many(q2, kc2, vt2[:, li], o2, work, scale, kv_off, T, q_row0=P)
+    assert torch.equal(q1, q2), "q differs"
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), "cache rows differ (or a foreign slot / layer was touched)"
+    assert torch.equal(vt1, vt2), "V^T differs"
+    assert torch.isfinite(o1.float()).all() and torch.equal(o1, o2), "attention rows differ"
+    with pytest.raises(hip.HipLibraryError):
+        hip.attn_prefill_pairs_many(q2, kc2, vt2[:, li], o2, work, scale, [o + 4 for o in kv_off], T, q_row0=P)   # offsets are x 8
+    with pytest.raises(hip.HipLibraryError):
+        hip.qkv_rope_split_many(qkv, cos, sin, q2, kc2, vc2, vt2[:, li], Hq, Hkv, HD, [kc2.numel()] * k, T, k_pos0=P)   # outside the cache

@@ -58,6 +58,9 @@ struct AttnArgs {
   int* ws_count;
   float* ws_part;
   int n_pairs;
+  // attn_prefill_pair_kernel only (vis_attn_prefill_pairs_many): request blockIdx.z reads Q + z * q_bs, K + kv[z], Vt + z * vt_bs
+  // and writes O + z * o_bs
+  ReqOffsets req;
 #ifdef VIT_VARIANTS_STAMPS
   unsigned long long* stamps;   // tools/probes/attn_vit_variants.hip only: s_memtime stamps of workgroup (0, 0)
 #endif
@@ -858,6 +861,12 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
   const int l15 = lane & 15, h = lane >> 4;
   const int head = blockIdx.x, hkv = head / p.group;
   const int4 wk = p.work[blockIdx.y];
+  // (locals, not updates of `p`: writing to a by-value kernel argument makes the compiler keep the whole struct in scratch)
+  const int z = blockIdx.z;
+  const bf16_t* const r_Q = p.Q + z * p.req.q_bs;
+  const bf16_t* const r_K = p.K + req_kv(p.req, z);
+  const bf16_t* const r_Vt = p.Vt + z * p.req.vt_bs;
+  bf16_t* const r_O = p.O + z * p.req.o_bs;
   // q-block 0 = heavy block B, q-block 1 = light block A
   const int qblk0[2] = {wk.x, wk.z}, qblkn[2] = {wk.y, wk.w};
   const int kend[2] = {min(p.k_tokens, wk.x + wk.y), min(p.k_tokens, wk.z + wk.w)};   // one past the last key of a block
@@ -865,14 +874,14 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
   const int wrow0[2] = {wk.x + wave * 16, wk.z + wave * 16};            // first row of this wave in each block
   const bool have[2] = {wave * 16 < wk.y, wk.w > 0 && wave * 16 < wk.w};
 
-  const bf16_t* Kh = p.K + (size_t)hkv * p.k_tokens * HD;
-  const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
+  const bf16_t* Kh = r_K + (size_t)hkv * p.k_tokens * HD;
+  const bf16_t* Vh = r_Vt + (size_t)hkv * HD * p.vt_ld;
 
   bf16x8 qf[2][DKF];
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = min(max(wrow0[qb] + l15, p.q_row0), p.q_row0 + p.Sq - 1) - p.q_row0;
-    const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
+    const bf16_t* qp = r_Q + ((size_t)head * p.Sq + qrow) * HD;
 #pragma unroll
     for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = att_scaled_q8(qp + ds * 32 + 8 * h, p.scale_log2);
   }
@@ -1055,7 +1064,7 @@ __global__ __launch_bounds__(512, 2) void attn_prefill_pair_kernel(AttnArgs p) {
       const int q = wrow0[qb] + row;
       if (q < qblk0[qb] + qblkn[qb]) {
         const u32x4 o = *(const u32x4*)(ost + row * OROW + c * 16);
-        *(u32x4*)(p.O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
+        *(u32x4*)(r_O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
       }
     }
   }
@@ -1076,8 +1085,40 @@ extern "C" int vis_attn_prefill_pairs(const void* Q, const void* K, const void* 
   p.scale_log2 = scale * 1.4426950408889634f;
   p.q_row0 = q_row0;
   p.ws_count = nullptr; p.ws_part = nullptr; p.n_pairs = 0;
+  req_offsets_none(p.req);
   vis_clear_error();
   hipLaunchKernelGGL(attn_prefill_pair_kernel, dim3(Hq, n_work), dim3(512), 0, stream, p);
+  return vis_check_launch();
+}
+
+// vis_attn_prefill_pairs for the `nreq` (<= 8) requests of a prompt-pass group in ONE launch (same work list: the requests share
+// their prompt structure): request r reads Q + r * q_bs, K + kv_off[r] (element offset of its cache slot; host array), Vt + r * vt_bs
+// and writes O + r * o_bs.  Rows are computed exactly as by vis_attn_prefill_pairs; what changes is the grid: a suffix pass of 1289
+// rows is 28 x 6 = 168 workgroups - a third of the 512 the device holds - and four of them in a row took 4 x 60 us.
+extern "C" int vis_attn_prefill_pairs_many(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
+                                           int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, float scale,
+                                           int q_row0, int nreq, long long q_bs, long long vt_bs, long long o_bs,
+                                           const long long* kv_off, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || q_row0 < 0) return VIS_ERR_ARG;
+  if (HD != 128 || nreq < 1 || nreq > VIS_MAX_REQ || !kv_off) return VIS_ERR_ARG;
+  if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * HD || n_work > 65535) return VIS_ERR_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
+  if (q_bs < 0 || vt_bs < 0 || o_bs < 0 || (q_bs | vt_bs | o_bs) % 8) return VIS_ERR_ARG;
+  AttnArgs p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.work = (const int4*)work;
+  p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.q_row0 = q_row0;
+  p.ws_count = nullptr; p.ws_part = nullptr; p.n_pairs = 0;
+  req_offsets_none(p.req);
+  for (int r = 0; r < nreq; ++r) {
+    if (kv_off[r] < 0 || kv_off[r] % 8) return VIS_ERR_ARG;
+    p.req.kv[r] = kv_off[r];
+  }
+  p.req.q_bs = q_bs; p.req.vt_bs = vt_bs; p.req.o_bs = o_bs;
+  vis_clear_error();
+  hipLaunchKernelGGL(attn_prefill_pair_kernel, dim3(Hq, n_work, nreq), dim3(512), 0, stream, p);
   return vis_check_launch();
 }
 
@@ -1108,6 +1149,7 @@ extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* V
   p.scale_log2 = scale * 1.4426950408889634f;
   p.q_row0 = q_row0;
   p.ws_count = nullptr; p.ws_part = nullptr; p.n_pairs = 0;
+  req_offsets_none(p.req);
   if (n_work > 65535) return VIS_ERR_ARG;
   const dim3 grid(Hq, n_work), block(256);
   // head_dim 80 is built for three workgroups per CU (768 slots, <= 168 VGPRs).  VIS_ATTN_OCC=2 caps residency at two

@@ -52,6 +52,25 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
   return v;
 }
 
+// Several requests of a prompt-pass group in ONE launch (vis_qkv_rope_split_many / vis_attn_prefill_pairs_many): blockIdx.z is the
+// request; its tensors sit at uniform strides except the KV cache, whose slot is arbitrary (element offsets from the first pointer).
+#define VIS_MAX_REQ 8
+struct ReqOffsets {
+  long long kv[VIS_MAX_REQ];   // k / v cache of request r = base + kv[r]
+  long long qkv_bs, q_bs, vt_bs, o_bs;
+};
+// kv[z] by a chain of scalar selects: a dynamically indexed kernel-argument array is copied to scratch first
+__device__ __forceinline__ long long req_kv(const ReqOffsets& r, int z) {
+  long long o = r.kv[0];
+#pragma unroll
+  for (int i = 1; i < VIS_MAX_REQ; ++i) o = (z == i) ? r.kv[i] : o;
+  return o;
+}
+static inline void req_offsets_none(ReqOffsets& r) {
+  for (int i = 0; i < VIS_MAX_REQ; ++i) r.kv[i] = 0;
+  r.qkv_bs = r.q_bs = r.vt_bs = r.o_bs = 0;
+}
+
 // One column of a finalised split-K projection row: the fixed-order sum `a` of its f32 partials, times the e4m3 scales
 // (fp8 form: sxb * swn), plus the bias - the arithmetic of skinny_finalize_kernel's plain mode, shared with the decode attention
 // kernels that finalise the qkv row themselves (vis_decode_attn_parts), so both produce the same bits.  Contraction is off:

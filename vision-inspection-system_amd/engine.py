@@ -208,6 +208,9 @@ class Qwen2VLEngine:
         # batched decode: the self-attention launch finalises the qkv projection's partial slabs itself (vis_decode_attn_parts,
         # bit-identical to skinny_finalize + decode_attn); VIS_QKV_FOLD=0 keeps the two launches (A/B)
         self.fold_qkv = os.environ.get("VIS_QKV_FOLD", "1") == "1"
+        # stacked suffix pass: rope / KV write / attention of the group's requests as ONE launch each (vis_*_many, per request
+        # bit-identical to the per-request launches); VIS_GROUP_ATTN=0 keeps one launch per request (A/B)
+        self.group_attn = os.environ.get("VIS_GROUP_ATTN", "1") == "1"
         if self.fused_proj:
             self.b_xw = torch.empty((Bm, H), dtype=bf, device=dev)        # x * ln1_w of the next layer (A operand of qkv / lm_head)
             self.b_x2w = torch.empty((Bm, H), dtype=bf, device=dev)       # x2 * ln2_w (A operand of gate/up)
@@ -758,7 +761,18 @@ class Qwen2VLEngine:
         splitk_work = torch.empty(2 * k * n * H, dtype=torch.float32, device=dev) \
             if (cfg.intermediate >= 8192 and H % 8 == 0 and self.prefill_dtype != "fp8") else None
 
+        slots = [it[0] for it in items]
+        T = self.kcache_b.shape[3]
+        many = self.group_attn and k > 1 and k <= hip.MAX_GROUP_REQUESTS and self.kcache_b.is_contiguous()
+
         def attend(li):        # rope / KV write / attention: per request, on its rows, cache slot and V^T buffer
+            if many:           # ... as ONE launch each for the whole group (r05: a 1289-row suffix alone fills a third of the chip)
+                kv_off = [sl * self.kcache_b.stride(0) + li * self.kcache_b.stride(1) for sl in slots]
+                vt_l = vt_all[:, li]
+                hip.qkv_rope_split_many(qkv, cos, sin, q, self.kcache_b, self.vcache_b, vt_l, Hq, Hkv, D, kv_off, T,
+                                        k_pos0=P, vt_col0=P)
+                hip.attn_prefill_pairs_many(q, self.kcache_b, vt_l, att, work, scale, kv_off, T, q_row0=P)
+                return
             for j, (slot, _, _, _) in enumerate(items):
                 rows = slice(j * n, (j + 1) * n)
                 kc, vc, vt = self.kcache_b[slot][li], self.vcache_b[slot][li], vt_all[j][li]

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from typing import Optional
+from typing import Optional, Sequence
 
 import torch  # imported BEFORE the library is dlopen-ed: libvis_hip.so must bind to the HIP runtime torch loaded
 
@@ -31,9 +31,11 @@ _SIGS = {
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
+    "vis_qkv_rope_split_many": "ppppppp" + "iiiiiiii" + "i" + "lll" + "p" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_attn_prefill_rows": "ppppp" + "iiiiiiiii" + "f" + "i" + "p",
     "vis_attn_prefill_pairs": "ppppp" + "iiiiiiii" + "f" + "i" + "p",
+    "vis_attn_prefill_pairs_many": "ppppp" + "iiiiiiii" + "f" + "i" + "i" + "lll" + "p" + "p",
     "vis_attn_split_ws_bytes": "ii",
     "vis_attn_prefill_split": "ppppp" + "iiiiiiii" + "f" + "i" + "p" + "l" + "p",
     "vis_gemv_bf16": "pppppp" + "iiiii" + "f" + "p",
@@ -400,6 +402,69 @@ def qkv_rope_split(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional
                                    S, qkv.stride(0), n_q, n_kv, head_dim, k.shape[1] if k is not None else 0,
                                    k_pos0, vt_ld, _stream())
     _check(rc, "vis_qkv_rope_split")
+
+
+MAX_GROUP_REQUESTS = 8      # VIS_MAX_REQ of csrc/common.hip.h
+
+
+def _kv_offsets(name: str, base: torch.Tensor, kv_off: Sequence[int], need: int):
+    import ctypes
+    n = len(kv_off)
+    if not 1 <= n <= MAX_GROUP_REQUESTS:
+        raise HipLibraryError(f"{name}: 1..{MAX_GROUP_REQUESTS} requests per launch")
+    if not base.is_contiguous() or any(o < 0 or o % 8 or o + need > base.numel() for o in kv_off):
+        raise HipLibraryError(f"{name}: cache offsets must be multiples of 8 inside the (contiguous) cache tensor")
+    return (ctypes.c_longlong * n)(*[int(o) for o in kv_off])
+
+
+def qkv_rope_split_many(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, q: torch.Tensor, k_base: torch.Tensor,
+                        v_base: torch.Tensor, vt: torch.Tensor, n_q: int, n_kv: int, head_dim: int, kv_off: Sequence[int],
+                        k_tokens: int, k_pos0: int = 0, vt_col0: int = 0) -> None:
+    """``qkv_rope_split`` for the k requests of a prompt-pass group in ONE launch: qkv [k * S, nq] (request r = rows r S ..), one
+    cos / sin [S, D] for all, q [k, Hq, S, D], the caches as whole tensors with ``kv_off[r]`` = element offset of request r's
+    [Hkv, k_tokens, D] block (same for k and v), vt [k, Hkv, D, ld] (any stride between requests)."""
+    import ctypes
+    _bf16(qkv, "qkv"); _bf16(q, "q"); _bf16(k_base, "k"); _bf16(v_base, "v"); _bf16(vt, "vt")
+    k = len(kv_off)
+    S = cos.shape[0]
+    if cos.dtype != torch.float32 or cos.shape != (S, head_dim) or sin.shape != cos.shape or not (cos.is_contiguous() and sin.is_contiguous()):
+        raise HipLibraryError("qkv_rope_split_many: cos/sin must be contiguous f32 [S, head_dim]")
+    if qkv.shape[0] != k * S or qkv.stride(1) != 1 or q.shape != (k, n_q, S, head_dim) or not q.is_contiguous():
+        raise HipLibraryError("qkv_rope_split_many: bad qkv / q shape")
+    if vt.dim() != 4 or vt.shape[:3] != (k, n_kv, head_dim) or not vt[0].is_contiguous() or v_base.shape != k_base.shape:
+        raise HipLibraryError("qkv_rope_split_many: bad vt / cache shape")
+    vt_ld = vt.shape[3]
+    if vt_col0 % 64 or vt_col0 + (S + 63) // 64 * 64 > vt_ld or k_pos0 + S > k_tokens:
+        raise HipLibraryError("qkv_rope_split_many: bad offsets")
+    offs = _kv_offsets("qkv_rope_split_many", k_base, kv_off, n_kv * k_tokens * head_dim)
+    rc = load().vis_qkv_rope_split_many(_ptr(qkv), _ptr(cos), _ptr(sin), _ptr(q), _ptr(k_base), _ptr(v_base),
+                                        _ptr(vt) + 2 * vt_col0, S, qkv.stride(0), n_q, n_kv, head_dim, k_tokens, k_pos0, vt_ld,
+                                        k, S * qkv.stride(0), q.stride(0), vt.stride(0) if k > 1 else 0,
+                                        ctypes.cast(offs, ctypes.c_void_p), _stream())
+    _check(rc, "vis_qkv_rope_split_many")
+
+
+def attn_prefill_pairs_many(q: torch.Tensor, k_base: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
+                            scale: float, kv_off: Sequence[int], k_tokens: int, q_row0: int = 0) -> torch.Tensor:
+    """``attn_prefill_pairs`` for the k requests of a prompt-pass group in ONE launch (same work list): q [k, Hq, S, D], the K cache
+    as a whole tensor + ``kv_off`` (as qkv_rope_split_many), vt [k, Hkv, D, ld], out [k * S, >= Hq * D] (request r = rows r S ..)."""
+    import ctypes
+    _bf16(q, "q"); _bf16(k_base, "k"); _bf16(vt, "vt"); _bf16(out, "out")
+    k, Hq, S, HD = q.shape
+    if len(kv_off) != k or not q.is_contiguous() or HD != 128:
+        raise HipLibraryError("attn_prefill_pairs_many: bad q shape")
+    Hkv = vt.shape[1]
+    if vt.dim() != 4 or vt.shape[0] != k or vt.shape[2] != HD or not vt[0].is_contiguous() or out.shape[0] != k * S or out.stride(1) != 1:
+        raise HipLibraryError("attn_prefill_pairs_many: bad vt / out shape")
+    if work.dtype != torch.int32 or work.dim() != 2 or work.shape[1] != 4 or not work.is_contiguous():
+        raise HipLibraryError("attn_prefill_pairs_many: work must be int32 [n,4]")
+    offs = _kv_offsets("attn_prefill_pairs_many", k_base, kv_off, Hkv * k_tokens * HD)
+    rc = load().vis_attn_prefill_pairs_many(_ptr(q), _ptr(k_base), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
+                                            S, k_tokens, vt.shape[3], out.stride(0), scale, int(q_row0), k, q.stride(0),
+                                            vt.stride(0) if k > 1 else 0, S * out.stride(0),
+                                            ctypes.cast(offs, ctypes.c_void_p), _stream())
+    _check(rc, "vis_attn_prefill_pairs_many")
+    return out
 
 
 # --------------------------------------------------------------------------- K6 / K7
