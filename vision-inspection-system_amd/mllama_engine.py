@@ -534,6 +534,8 @@ class MllamaEngine:
             else:
                 hip.gemm(a, wt, residual=x, out=x)
 
+        Tc = self.kcache_b.shape[3]
+        many = os.environ.get("VIS_GROUP_ATTN", "1") == "1" and 1 < k <= hip.MAX_GROUP_REQUESTS and self.kcache_b.is_contiguous()
         si = ci = 0
         for lw in w.layers:
             if lw.cross:
@@ -565,11 +567,16 @@ class MllamaEngine:
                     hip.gemm_splitk(y, lw.qkv_w, swork, ks_qkv, out=qkv)
                 else:
                     hip.gemm(y, lw.qkv_w, out=qkv)
-                for j, (slot, _, _, _) in enumerate(items):
-                    rows = slice(j * S, (j + 1) * S)
-                    kc, vc = self.kcache_b[slot][si], self.vcache_b[slot][si]
-                    hip.qkv_rope_split(qkv[rows], cos, sin, q[j], kc, vc, vt[j], Hq, Hkv, D, k_pos0=0)
-                    hip.attn_prefill_pairs(q[j], kc, vt[j], att[rows], work, scale)
+                if many:           # the group's requests as ONE launch each (per request bit-identical; see Qwen2VLEngine._prefill_group)
+                    kv_off = [it[0] * self.kcache_b.stride(0) + si * self.kcache_b.stride(1) for it in items]
+                    hip.qkv_rope_split_many(qkv, cos, sin, q, self.kcache_b, self.vcache_b, vt, Hq, Hkv, D, kv_off, Tc, k_pos0=0)
+                    hip.attn_prefill_pairs_many(q, self.kcache_b, vt, att, work, scale, kv_off, Tc)
+                else:
+                    for j, (slot, _, _, _) in enumerate(items):
+                        rows = slice(j * S, (j + 1) * S)
+                        kc, vc = self.kcache_b[slot][si], self.vcache_b[slot][si]
+                        hip.qkv_rope_split(qkv[rows], cos, sin, q[j], kc, vc, vt[j], Hq, Hkv, D, k_pos0=0)
+                        hip.attn_prefill_pairs(q[j], kc, vt[j], att[rows], work, scale)
                 proj(att, lw.o_w, ks_o)
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
