@@ -6,10 +6,19 @@
 
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_GELU_ERF = 2, ACT_SWIGLU = 3 };
 
-// exact-erf GELU (merger only: 1225 x 5120 elements per image).  Deliberately NOT inlined: erff expands to ~60
-// instructions, and the epilogues instantiate the activation up to 128 times per kernel.
-__device__ __attribute__((noinline)) float gelu_erf(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+// erf-GELU, 0.5 x (1 + erf(x / sqrt 2)) (TF "gelu": the Qwen2-VL merger and every MLP of the mllama vision tower).  r01-r04 called
+// libm's erff out of line (~60 instructions per element): the Auditor's tower fc1 - 131.7 M outputs per four images - spent ~200 of its
+// 438 us in this epilogue (r05: 0.77 PFLOP/s where the same shape with QuickGELU ran 1.14).  Now Abramowitz & Stegun 7.1.26 in the
+// erfc form: e = poly(t) exp(-z^2), t = 1 / (1 + p z), z = |x| / sqrt 2, |erfc error| <= 1.5e-7, and
+//   x >= 0: x (1 - e / 2)      x < 0: x e / 2        (no 1 - erf cancellation on the negative side)
+// = 11 VALU + v_rcp_f32 + v_exp_f32.  Against the f64 function over [-12, 12]: max abs error 6.4e-7 (torch's own f32 gelu: 1.3e-6),
+// bf16-rounded results differ in 5e-5 of the cases where |gelu| > 0.01, by one bf16 ulp (torch f32: 5.9e-5).
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+  const float p = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float e = p * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+  return x * (x >= 0.f ? 1.0f - 0.5f * e : 0.5f * e);
 }
 
 __device__ __forceinline__ float act_apply(float x, int act) {

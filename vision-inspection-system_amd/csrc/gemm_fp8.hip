@@ -55,7 +55,7 @@ struct GemmF8Args {
 
 __device__ __forceinline__ float f8_act(float x, int act) {
   if (act == F8_ACT_QUICKGELU) return quickgelu_fast(x);
-  if (act == F8_ACT_GELU_ERF) return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+  if (act == F8_ACT_GELU_ERF) return gelu_erf(x);
   return x;
 }
 
