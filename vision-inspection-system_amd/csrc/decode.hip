@@ -587,11 +587,14 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
     for (int e = 0; e < 4; ++e) sv[e] = (k0 + 4 * h + e < ctx) ? acc[e] * p.scale_log2 : -1.0e30f;
     const float mx = hmax4(fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])));
     const float m_new = fmaxf(m_run, mx);
-    const float al = exp2f(m_run - m_new);
+    // (v_exp_f32 itself: libm's exp2f wraps it in a compare, two selects, an add and a v_ldexp for results below 2^-126 - 25 of the
+    // step's ~250 vector instructions - which here are probabilities that round to zero weight either way; measured: no change
+    // at 64 sequences, 5.255 vs 5.258 ms per step - the launch reads its K / V bytes at 6.1 TB/s and that is its bound)
+    const float al = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float pe[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) pe[e] = exp2f(sv[e] - m_new);
+    for (int e = 0; e < 4; ++e) pe[e] = __builtin_amdgcn_exp2f(sv[e] - m_new);
     // r05: P * V on v_dot2_f32_bf16 - the probabilities are rounded to bf16 (as the prefill attention's P is; exact products,
     // f32 accumulation) and two keys go through one instruction: 112 dot2 + 16 v_perm per step and wave instead of 224 FMAs + 32
     // unpacking shifts / masks.  This kernel is bound by its instruction stream, not by memory: with every key of every sequence
