@@ -447,7 +447,8 @@ def test_gemm_splitk(hip, device, M, N, K, ks):
 
 
 # ----------------------------------------------------------------------------- fp8 MFMA GEMM + activation quantiser
-@pytest.mark.parametrize("M,K,norm", [(37, 256, True), (300, 3584, True), (300, 3584, False), (64, 18944, False)])
+@pytest.mark.parametrize("M,K,norm", [(37, 256, True), (300, 3584, True), (300, 3584, False), (64, 18944, False), (101, 5120, False),
+                                      (50, 10240, False), (33, 1280, False), (7, 24576, False)])
 def test_quant_rows_fp8(hip, device, M, K, norm):
     x = _randn((M, K), device, 170, 2.0)
     nw = _randn((K,), device, 171) if norm else None

@@ -732,13 +732,17 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   if (nch <= 64 * QR_MAX_CHUNKS) {  // the row lives in registers (uniform branch)
     float v[QR_MAX_CHUNKS][8];
     float ss = 0.f;
+    {   // r05: every load unconditional (clamped chunk) and issued before the first use - a guarded load drains the queue
+      u32x4 raw[QR_MAX_CHUNKS];
 #pragma unroll
-    for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
-      const int c = lane + i * 64;
-      if (c < nch) {
-        unpack8(*(const u32x4*)(xr + c * 8), v[i]);
+      for (int i = 0; i < QR_MAX_CHUNKS; ++i) raw[i] = *(const u32x4*)(xr + min(lane + i * 64, nch - 1) * 8);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+        if (lane + i * 64 < nch) {
+          unpack8(raw[i], v[i]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+        }
       }
     }
     if (nw && nb) {   // LayerNorm (ViT): same arithmetic and single bf16 rounding as norm_rows_kernel<true>
@@ -825,6 +829,45 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   }
 }
 
+// Rows without a fused norm, up to 64 * 8 * NCH elements (r05): the row stays in registers as packed bf16 - NCH 16-byte loads per
+// lane, all issued before the first use - so it is read ONCE; the streaming path of quant_rows_fp8_kernel read it twice through a
+// load-per-iteration loop and ran the activation rows of the fp8 prompt pass (ViT fc1 output 19600 x 5120, SwiGLU output
+// 5156 x 18944: ~300 MB each) at 2.7 TB/s.  Same arithmetic and bytes as that path.
+template <int NCH>
+__global__ __launch_bounds__(256) void quant_rows_fp8_wide_kernel(const bf16_t* __restrict__ x, uint8_t* __restrict__ q,
+                                                                  float* __restrict__ scale, int rows, int K, int ldx, int ldq) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = K >> 3;
+  const bf16_t* xr = x + (size_t)row * ldx;
+  uint8_t* qr = q + (size_t)row * ldq;
+  u32x4 raw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) raw[i] = *(const u32x4*)(xr + min(lane + i * 64, nch - 1) * 8);   // (a clamped duplicate changes no maximum)
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    float f[8];
+    unpack8(raw[i], f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(f[e]));
+  }
+  amax = wave_max(amax);
+  const float sc = fmaxf(amax / 448.0f, 1e-12f);
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = lane + i * 64;
+    if (c < nch) {
+      float f[8];
+      unpack8(raw[i], f);
+      *(u32x2*)(qr + c * 8) = qr_pack8(f, inv);
+    }
+  }
+}
+
 extern "C" int vis_quant_rows_fp8(const void* x, const void* norm_w, const void* norm_b, void* q, void* scale,
                                   int rows, int K, int ldx, int ldq, float eps, hipStream_t stream) {
   if (!x || !q || !scale || rows <= 0 || K <= 0) return VIS_ERR_ARG;
@@ -834,7 +877,19 @@ extern "C" int vis_quant_rows_fp8(const void* x, const void* norm_w, const void*
   if (((uintptr_t)x | (uintptr_t)norm_w | (uintptr_t)norm_b) & 15 || ((uintptr_t)q & 7) || ((uintptr_t)scale & 3))
     return VIS_ERR_ARG;
   vis_clear_error();
-  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x,
+  static const int wide_env = [] { const char* e = getenv("VIS_QUANT_WIDE"); return e ? atoi(e) : 1; }();   // 0: r04 kernel (A/B)
+  const int nch_lane = (K / 8 + 63) / 64;   // 16-byte chunks per lane
+  const dim3 grid((rows + 3) / 4), block(256);
+  if (!norm_w && wide_env && nch_lane > 4 && nch_lane <= 40) {
+#define QR_WIDE(N) hipLaunchKernelGGL(quant_rows_fp8_wide_kernel<N>, grid, block, 0, stream, (const bf16_t*)x, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq)
+    if (nch_lane <= 8) QR_WIDE(8);
+    else if (nch_lane <= 12) QR_WIDE(12);
+    else if (nch_lane <= 24) QR_WIDE(24);
+    else QR_WIDE(40);
+#undef QR_WIDE
+    return vis_check_launch();
+  }
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, grid, block, 0, stream, (const bf16_t*)x,
                      (const bf16_t*)norm_w, (const bf16_t*)norm_b, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
   return vis_check_launch();
 }
