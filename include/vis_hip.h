@@ -54,6 +54,12 @@ int vis_gemm_bf16(const void* A, const void* W, const void* bias, const void* R,
 int vis_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int N, int ldx, int ldy,
                      float eps, vis_stream_t stream);
 
+/* K3 over the heads of a packed row: x [tokens][ldx] holds `heads` consecutive head_dim (= 128) wide heads per token; every
+ * (token, head) slice is normalised with the one weight w [128] (mllama k_norm on the cross-attention keys, TF:models/mllama/
+ * modeling_mllama.py:411-440).  Per slice bit-identical to vis_rmsnorm_bf16 on x[:, 128 h ..]; one launch instead of `heads`. */
+int vis_rmsnorm_heads_bf16(const void* x, const void* w, void* y, int tokens, int heads, int head_dim, int ldx, int ldy,
+                           float eps, vis_stream_t stream);
+
 /* K5  y = (x - mean) * rsqrt(var + eps) * w + b         TF modeling_qwen2_vl.py:281,:428-429 */
 int vis_layernorm_bf16(const void* x, const void* w, const void* b, void* y, int rows, int N,
                        int ldx, int ldy, float eps, vis_stream_t stream);
@@ -94,6 +100,14 @@ int vis_attn_prefill(const void* Q, const void* K, const void* Vt, void* O, cons
 int vis_attn_prefill_rows(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
                           int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
                           float scale, int q_row0, vis_stream_t stream);
+
+/* vis_attn_prefill_rows (HD = 128) for the nreq (<= 8) requests of one prompt-pass group as ONE launch: request r reads Q + r * q_bs,
+ * K + kv_off[r] (HOST array, element offsets), Vt + r * vt_bs and work items [r * n_work, (r + 1) * n_work) - one list per request
+ * (the mllama cross-attention's key counts differ per image) - and writes O + r * o_bs.  Per request bit-identical. */
+int vis_attn_prefill_rows_many(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work, int Hq,
+                               int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal, float scale, int q_row0,
+                               int nreq, long long q_bs, long long vt_bs, long long o_bs, const long long* kv_off,
+                               vis_stream_t stream);
 
 /* K7, balanced form (HD = 128, causal, keys from 0): work = n_work x int4 {qB0, qBn, qA0, qAn}, a late and an early
  * 128-row query block of one sequence per 512-thread workgroup (qAn = 0: none), so that every workgroup of the causal

@@ -1482,3 +1482,49 @@ def test_group_rope_split_and_pair_attention_equal_per_request_launches(hip, dev
         hip.attn_prefill_pairs_many(q2, kc2, vt2[:, li], o2, work, scale, [o + 4 for o in kv_off], T, q_row0=P)   # offsets are x 8
     with pytest.raises(hip.HipLibraryError):
         hip.qkv_rope_split_many(qkv, cos, sin, q2, kc2, vc2, vt2[:, li], Hq, Hkv, HD, [kc2.numel()] * k, T, k_pos0=P)   # outside the cache
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tokens,heads,extra", [(6432, 8, 8), (37, 4, 0), (5, 6, 2), (1, 16, 16)])
+def test_rmsnorm_heads_equals_rmsnorm_per_head(hip, device, tokens, heads, extra):
+    """vis_rmsnorm_heads_bf16 (r05): mllama's k_norm over the key heads of a packed [k | v] projection row in one launch - every
+    (token, head) slice bit-identical to vis_rmsnorm_bf16 on the strided slice, the columns behind the heads untouched."""
+    D = 128
+    x = _randn((tokens, (heads + extra) * D), device, 740, 1.7)
+    w = _randn((D,), device, 741)
+    ref = x.clone()
+    for h in range(heads):
+        hip.rmsnorm(x[:, h * D:(h + 1) * D], w, 1e-5, out=ref[:, h * D:(h + 1) * D])
+    got = x.clone()
+    hip.rmsnorm_heads(got, w, heads, 1e-5)
+    assert torch.equal(got, ref)
+    if extra:
+        assert torch.equal(got[:, heads * D:], x[:, heads * D:])
+    with pytest.raises(hip.HipLibraryError):
+        hip.rmsnorm_heads(got, w, heads + extra + 1, 1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,Hq,Hkv,S,causal", [(4, 32, 8, 300, False), (3, 8, 2, 200, True), (8, 4, 4, 77, False)])
+def test_group_attention_rows_equal_per_request_launches(hip, device, k, Hq, Hkv, S, causal):
+    """vis_attn_prefill_rows_many (r05): the generic head_dim-128 kernel over the requests of a group, one work list PER request
+    (different key counts - the Auditor's cross-attention over 1..4 tiles), arbitrary cache blocks: rows bit-identical."""
+    HD, L, T = 128, 3, 1700
+    li = 2
+    ld = (T + 63) // 64 * 64
+    slots_total = k + 2
+    slots = torch.randperm(slots_total, generator=torch.Generator().manual_seed(750 + k))[:k].tolist()
+    q = _randn((k, Hq, S, HD), device, 751)
+    kc = _randn((slots_total, L, Hkv, T, HD), device, 752)
+    vt = _randn((k, Hkv, HD, ld), device, 753)
+    nkeys = [max(S, T - 300 * j) for j in range(k)]
+    items = [[(q0, min(128, S - q0), 0, nkeys[j]) for q0 in range(0, S, 128)] for j in range(k)]
+    work = torch.tensor(items, dtype=torch.int32, device=device).reshape(k, -1, 4).contiguous()
+    scale = HD ** -0.5
+    o1 = torch.zeros((k * S, Hq * HD), dtype=torch.bfloat16, device=device)
+    for j, sl in enumerate(slots):
+        hip.attn_prefill(q[j], kc[sl][li], vt[j], o1[j * S:(j + 1) * S], work[j], causal, scale)
+    o2 = torch.zeros_like(o1)
+    kv_off = [sl * kc.stride(0) + li * kc.stride(1) for sl in slots]
+    hip.attn_prefill_many(q, kc, vt, o2, work, causal, scale, kv_off, T)
+    assert torch.isfinite(o1.float()).all() and torch.equal(o1, o2)

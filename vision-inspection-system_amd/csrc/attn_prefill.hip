@@ -150,7 +150,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
   const int head = blockIdx.x, hkv = head / p.group;
-  const int4 wk = p.work[blockIdx.y];
+  // request blockIdx.z of vis_attn_prefill_rows_many (locals, not updates of the by-value argument struct: see the pair kernel)
+  const int z = blockIdx.z;
+  const bf16_t* const r_Q = p.Q + z * p.req.q_bs;
+  const bf16_t* const r_K = p.K + req_kv(p.req, z);
+  const bf16_t* const r_Vt = p.Vt + z * p.req.vt_bs;
+  bf16_t* const r_O = p.O + z * p.req.o_bs;
+  const int4 wk = p.work[blockIdx.y + z * p.req.work_bs];
   const int q0 = wk.x, qn = wk.y, k0 = wk.z;
   const int k1 = CAUSAL ? min(wk.w, q0 + qn) : wk.w;
   const int kt_begin = k0 & ~63;
@@ -161,8 +167,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
   const int wrows = 16 * nqb;
   const int wq0 = q0 + wave * wrows;        // first query row of this wave
 
-  const bf16_t* Kh = p.K + (size_t)hkv * p.k_tokens * HD;
-  const bf16_t* Vh = p.Vt + (size_t)hkv * HD * p.vt_ld;
+  const bf16_t* Kh = r_K + (size_t)hkv * p.k_tokens * HD;
+  const bf16_t* Vh = r_Vt + (size_t)hkv * HD * p.vt_ld;
 
   // ---- Q^T fragments (B operand), kept in registers
   // head_dim 80 = two 32-wide k-steps + one 16-wide tail on v_mfma_f32_16x16x16_bf16 (lane: row l&15, k = 4(l>>4)+j):
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int qrow = min(wq0 + qb * 16 + l15, p.q_row0 + p.Sq - 1) - p.q_row0;
-    const bf16_t* qp = p.Q + ((size_t)head * p.Sq + qrow) * HD;
+    const bf16_t* qp = r_Q + ((size_t)head * p.Sq + qrow) * HD;
 #pragma unroll
     for (int ds = 0; ds < DKF; ++ds) qf[qb][ds] = att_scaled_q8(qp + ds * 32 + 8 * h, p.scale_log2);
     if constexpr (TAIL16) {
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnArgs p) {
     const int q = wq0 + row;
     if (q < q0 + qn) {
       const u32x4 o = *(const u32x4*)(ost + row * OROW + c * 16);
-      *(u32x4*)(p.O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
+      *(u32x4*)(r_O + (size_t)(q - p.q_row0) * p.ldo + head * HD + c * 8) = o;
     }
   }
 }
@@ -1167,6 +1173,39 @@ extern "C" int vis_attn_prefill_rows(const void* Q, const void* K, const void* V
     else if (wide) hipLaunchKernelGGL(attn_vit32_kernel, grid, block, 0, stream, p);
     else hipLaunchKernelGGL((attn_prefill_kernel<80, false>), grid, block, pad_lds, stream, p);
   }
+  return vis_check_launch();
+}
+
+// vis_attn_prefill_rows (head_dim 128) for the `nreq` (<= 8) requests of a prompt-pass group in ONE launch: request r reads
+// Q + r * q_bs, K + kv_off[r] (host array, element offsets), Vt + r * vt_bs, work items [r * n_work, (r + 1) * n_work) of `work`
+// (one list per request: the mllama cross-attention's key counts differ per image) and writes O + r * o_bs.  Per request
+// bit-identical to vis_attn_prefill_rows.
+extern "C" int vis_attn_prefill_rows_many(const void* Q, const void* K, const void* Vt, void* O, const void* work, int n_work,
+                                          int Hq, int Hkv, int HD, int Sq, int k_tokens, int vt_ld, int ldo, int causal,
+                                          float scale, int q_row0, int nreq, long long q_bs, long long vt_bs, long long o_bs,
+                                          const long long* kv_off, hipStream_t stream) {
+  if (!Q || !K || !Vt || !O || !work || n_work <= 0 || Hq <= 0 || Hkv <= 0 || Hq % Hkv != 0 || q_row0 < 0) return VIS_ERR_ARG;
+  if (HD != 128 || nreq < 1 || nreq > VIS_MAX_REQ || !kv_off) return VIS_ERR_ARG;
+  if (Sq <= 0 || k_tokens <= 0 || vt_ld % 64 != 0 || ldo % 8 != 0 || ldo < Hq * HD || n_work > 65535) return VIS_ERR_ARG;
+  if (((uintptr_t)Q | (uintptr_t)K | (uintptr_t)Vt | (uintptr_t)O | (uintptr_t)work) & 15) return VIS_ERR_ARG;
+  if (q_bs < 0 || vt_bs < 0 || o_bs < 0 || (q_bs | vt_bs | o_bs) % 8) return VIS_ERR_ARG;
+  AttnArgs p;
+  p.Q = (const bf16_t*)Q; p.K = (const bf16_t*)K; p.Vt = (const bf16_t*)Vt; p.O = (bf16_t*)O;
+  p.work = (const int4*)work;
+  p.Sq = Sq; p.k_tokens = k_tokens; p.vt_ld = vt_ld; p.ldo = ldo; p.group = Hq / Hkv;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.q_row0 = q_row0;
+  p.ws_count = nullptr; p.ws_part = nullptr; p.n_pairs = 0;
+  req_offsets_none(p.req);
+  for (int r = 0; r < nreq; ++r) {
+    if (kv_off[r] < 0 || kv_off[r] % 8) return VIS_ERR_ARG;
+    p.req.kv[r] = kv_off[r];
+  }
+  p.req.q_bs = q_bs; p.req.vt_bs = vt_bs; p.req.o_bs = o_bs; p.req.work_bs = n_work;
+  const dim3 grid(Hq, n_work, nreq), block(256);
+  vis_clear_error();
+  if (causal) hipLaunchKernelGGL((attn_prefill_kernel<128, true>), grid, block, 0, stream, p);
+  else hipLaunchKernelGGL((attn_prefill_kernel<128, false>), grid, block, 0, stream, p);
   return vis_check_launch();
 }
 

@@ -58,6 +58,7 @@ __device__ __forceinline__ u32x4 pack8(const float* f) {
 struct ReqOffsets {
   long long kv[VIS_MAX_REQ];   // k / v cache of request r = base + kv[r]
   long long qkv_bs, q_bs, vt_bs, o_bs;
+  int work_bs;                 // work items between two requests' lists (0: one list for all)
 };
 // kv[z] by a chain of scalar selects: a dynamically indexed kernel-argument array is copied to scratch first
 __device__ __forceinline__ long long req_kv(const ReqOffsets& r, int z) {
@@ -69,6 +70,7 @@ __device__ __forceinline__ long long req_kv(const ReqOffsets& r, int z) {
 static inline void req_offsets_none(ReqOffsets& r) {
   for (int i = 0; i < VIS_MAX_REQ; ++i) r.kv[i] = 0;
   r.qkv_bs = r.q_bs = r.vt_bs = r.o_bs = 0;
+  r.work_bs = 0;
 }
 
 // One column of a finalised split-K projection row: the fixed-order sum `a` of its f32 partials, times the e4m3 scales

@@ -369,6 +369,57 @@ static int norm_launch(bool ln, const void* x, const void* w, const void* b, voi
   return vis_check_launch();
 }
 
+// RMSNorm over every 128-wide head of a packed row (mllama's k_norm on the cross-attention keys, TF:models/mllama/modeling_mllama.py:
+// 411-440): x [tokens][ldx] holds `heads` consecutive 128-element heads per token; one wave per token, a head per 16-lane DPP row,
+// four heads per pass.  Head h of token t gets exactly what vis_rmsnorm_bf16 on the [tokens, 128] slice x[:, 128 h ..] computes - the
+// same lane <-> chunk map, and wave_sum's first four DPP steps ARE the 16-lane row sum (its last step adds three rows of zeros there) -
+// in one launch instead of `heads`.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += VIS_DPP(v, 0xB1);   // quad_perm [1,0,3,2]
+  v += VIS_DPP(v, 0x4E);   // quad_perm [2,3,0,1]
+  v += VIS_DPP(v, 0x141);  // row_half_mirror
+  v += VIS_DPP(v, 0x140);  // row_mirror
+  return v;
+}
+
+__global__ __launch_bounds__(256) void rmsnorm_heads_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                            bf16_t* __restrict__ y, int tokens, int heads, int ldx, int ldy,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= tokens) return;
+  const int c = lane & 15, hrow = lane >> 4;
+  float wv[8];
+  unpack8(*(const u32x4*)(w + c * 8), wv);
+  const bf16_t* xr = x + (size_t)t * ldx + c * 8;
+  bf16_t* yr = y + (size_t)t * ldy + c * 8;
+  for (int h0 = 0; h0 < heads; h0 += 4) {
+    const int h = min(h0 + hrow, heads - 1);
+    float v[8];
+    unpack8(*(const u32x4*)(xr + h * 128), v);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+    ss = row16_sum(ss);
+    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + eps);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(v[e] * rstd)) * wv[e];
+    if (h0 + hrow < heads) *(u32x4*)(yr + h * 128) = pack8(o);
+  }
+}
+
+extern "C" int vis_rmsnorm_heads_bf16(const void* x, const void* w, void* y, int tokens, int heads, int head_dim, int ldx,
+                                      int ldy, float eps, hipStream_t stream) {
+  if (!x || !w || !y || tokens <= 0 || heads <= 0 || head_dim != 128) return VIS_ERR_ARG;
+  if (ldx % 8 != 0 || ldy % 8 != 0 || ldx < heads * 128 || ldy < heads * 128) return VIS_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) return VIS_ERR_ARG;
+  vis_clear_error();
+  hipLaunchKernelGGL(rmsnorm_heads_kernel, dim3((tokens + 3) / 4), dim3(256), 0, stream, (const bf16_t*)x, (const bf16_t*)w,
+                     (bf16_t*)y, tokens, heads, ldx, ldy, eps);
+  return vis_check_launch();
+}
+
 extern "C" int vis_rmsnorm_bf16(const void* x, const void* w, void* y, int rows, int N, int ldx, int ldy,
                                 float eps, hipStream_t stream) {
   return norm_launch(false, x, w, nullptr, y, rows, N, ldx, ldy, eps, stream);

@@ -29,11 +29,13 @@ _SIGS = {
     "vis_gemm_fp8": "pppppppp" + "iiiiiiiii" + "p",
     "vis_quant_rows_fp8": "ppppp" + "iiii" + "f" + "p",
     "vis_rmsnorm_bf16": "ppp" + "iiii" + "f" + "p",
+    "vis_rmsnorm_heads_bf16": "ppp" + "iiiii" + "f" + "p",
     "vis_layernorm_bf16": "pppp" + "iiii" + "f" + "p",
     "vis_qkv_rope_split": "ppppppp" + "iiiiiiii" + "p",
     "vis_qkv_rope_split_many": "ppppppp" + "iiiiiiii" + "i" + "lll" + "p" + "p",
     "vis_attn_prefill": "ppppp" + "iiiiiiiii" + "f" + "p",
     "vis_attn_prefill_rows": "ppppp" + "iiiiiiiii" + "f" + "i" + "p",
+    "vis_attn_prefill_rows_many": "ppppp" + "iiiiiiiii" + "f" + "i" + "i" + "lll" + "p" + "p",
     "vis_attn_prefill_pairs": "ppppp" + "iiiiiiii" + "f" + "i" + "p",
     "vis_attn_prefill_pairs_many": "ppppp" + "iiiiiiii" + "f" + "i" + "i" + "lll" + "p" + "p",
     "vis_attn_split_ws_bytes": "ii",
@@ -355,6 +357,19 @@ def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float, out: Optional[torch.Te
     return out
 
 
+def rmsnorm_heads(x: torch.Tensor, w: torch.Tensor, heads: int, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RMSNorm of every 128-wide head slice x[:, 128 h : 128 (h + 1)], h < heads, with the one weight w [128] - ``rmsnorm`` on each
+    slice (bit-identical), one launch.  x [tokens, >= heads * 128] (columns beyond are left alone); in place unless ``out``."""
+    _bf16(x, "rmsnorm_heads x"); _bf16(w, "rmsnorm_heads w")
+    if out is None:
+        out = x
+    if x.dim() != 2 or x.stride(1) != 1 or out.shape != x.shape or out.stride(1) != 1 or w.numel() != 128 or x.shape[1] < heads * 128:
+        raise HipLibraryError("rmsnorm_heads: bad shapes")
+    rc = load().vis_rmsnorm_heads_bf16(_ptr(x), _ptr(w), _ptr(out), x.shape[0], heads, 128, x.stride(0), out.stride(0), eps, _stream())
+    _check(rc, "vis_rmsnorm_heads_bf16")
+    return out
+
+
 def layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _bf16(x, "layernorm x")
@@ -660,6 +675,30 @@ def attn_prefill(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.
     rc = load().vis_attn_prefill_rows(_ptr(q), _ptr(k), _ptr(vt), _ptr(out), _ptr(work), work.shape[0], Hq, Hkv, HD,
                                       S, T, vt.shape[2], out.stride(0), 1 if causal else 0, scale, int(q_row0), _stream())
     _check(rc, "vis_attn_prefill_rows")
+    return out
+
+
+def attn_prefill_many(q: torch.Tensor, k_base: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, work: torch.Tensor,
+                      causal: bool, scale: float, kv_off: Sequence[int], k_tokens: int, q_row0: int = 0) -> torch.Tensor:
+    """``attn_prefill`` (head_dim 128) for the k requests of a prompt-pass group in ONE launch: q [k, Hq, S, D], the K tensor as a
+    whole + ``kv_off[r]`` = element offset of request r's [Hkv, k_tokens, D] block, vt [k, Hkv, D, ld], work int32 [k, n, 4] (one
+    list per request), out [k * S, >= Hq * D] (request r = rows r S ..)."""
+    import ctypes
+    _bf16(q, "q"); _bf16(k_base, "k"); _bf16(vt, "vt"); _bf16(out, "out")
+    k, Hq, S, HD = q.shape
+    if len(kv_off) != k or not q.is_contiguous() or HD != 128:
+        raise HipLibraryError("attn_prefill_many: bad q shape")
+    Hkv = vt.shape[1]
+    if vt.dim() != 4 or vt.shape[0] != k or vt.shape[2] != HD or not vt[0].is_contiguous() or out.shape[0] != k * S or out.stride(1) != 1:
+        raise HipLibraryError("attn_prefill_many: bad vt / out shape")
+    if work.dtype != torch.int32 or work.dim() != 3 or work.shape[0] != k or work.shape[2] != 4 or not work.is_contiguous():
+        raise HipLibraryError("attn_prefill_many: work must be int32 [k, n, 4]")
+    offs = _kv_offsets("attn_prefill_many", k_base, kv_off, Hkv * k_tokens * HD)
+    rc = load().vis_attn_prefill_rows_many(_ptr(q), _ptr(k_base), _ptr(vt), _ptr(out), _ptr(work), work.shape[1], Hq, Hkv, HD,
+                                           S, k_tokens, vt.shape[3], out.stride(0), 1 if causal else 0, scale, int(q_row0), k,
+                                           q.stride(0), vt.stride(0) if k > 1 else 0, S * out.stride(0),
+                                           ctypes.cast(offs, ctypes.c_void_p), _stream())
+    _check(rc, "vis_attn_prefill_rows_many")
     return out
 
 

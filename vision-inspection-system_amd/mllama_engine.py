@@ -434,8 +434,7 @@ class MllamaEngine:
                     ci += 1
                     continue                      # text-only prompt: cross layers are skipped (TF:...:1128-1138)
                 hip.gemm(cross, lw.kv_w, out=kvbuf)
-                for h in range(Hkv):              # k_norm per kv head (rows of 128, strided view)
-                    hip.rmsnorm(kvbuf[:, h * D:(h + 1) * D], lw.k_norm, cfg.rms_eps, out=kvbuf[:, h * D:(h + 1) * D])
+                hip.rmsnorm_heads(kvbuf, lw.k_norm, Hkv, cfg.rms_eps)     # k_norm on the Hkv key heads of every row (one launch)
                 hip.qkv_rope_split(kvbuf, None, None, None, xk[ci], xv[ci], xvt, 0, Hkv, D, k_pos0=0)
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, out=q2)
@@ -507,8 +506,11 @@ class MllamaEngine:
             self.nkeys_b[slot:slot + 1].fill_(nR - 1)
             xitems = [(q0, min(128, nm - q0), 0, TP) for q0 in range(0, nm, 128)] + \
                      [(q0, min(128, S - q0), 0, nR) for q0 in range(nm, S, 128)]
-            xworks.append(torch.tensor(xitems, dtype=torch.int32, device=dev).reshape(-1, 4).contiguous())
-            xvts.append(torch.empty((Hkv, D, self.Tk), dtype=bf, device=dev))
+            xworks.append(xitems)
+        xvt_all = torch.empty((k, Hkv, D, self.Tk), dtype=bf, device=dev)
+        xvts = [xvt_all[j] for j in range(k)]
+        xwork_all = torch.tensor(xworks, dtype=torch.int32, device=dev).reshape(k, -1, 4).contiguous()   # same item count: same S, nm
+        xworks = [xwork_all[j] for j in range(k)]
         kvbuf = torch.empty((TP, 2 * Hkv * D), dtype=bf, device=dev)
         q2 = torch.empty((M, Hq * D), dtype=bf, device=dev)
         cos, sin = self.cos_t[:S], self.sin_t[:S]
@@ -541,17 +543,22 @@ class MllamaEngine:
             if lw.cross:
                 for j, (slot, _, cross, _) in enumerate(items):
                     hip.gemm(cross, lw.kv_w, out=kvbuf)
-                    for h in range(Hkv):
-                        hip.rmsnorm(kvbuf[:, h * D:(h + 1) * D], lw.k_norm, cfg.rms_eps, out=kvbuf[:, h * D:(h + 1) * D])
+                    hip.rmsnorm_heads(kvbuf, lw.k_norm, Hkv, cfg.rms_eps)
                     hip.qkv_rope_split(kvbuf, None, None, None, self.xk_b[slot][ci], self.xv_b[slot][ci], xvts[j], 0, Hkv, D,
                                        k_pos0=0)
                 hip.rmsnorm(x, lw.ln1_w, cfg.rms_eps, out=y)
                 hip.gemm(y, lw.qkv_w, out=q2)
                 hip.rmsnorm(q2.view(M * Hq, D), lw.q_norm, cfg.rms_eps, out=q2.view(M * Hq, D))
-                for j, (slot, _, _, _) in enumerate(items):
-                    rows = slice(j * S, (j + 1) * S)
-                    hip.qkv_rope_split(q2[rows], None, None, q[j], None, None, None, Hq, 0, D)
-                    hip.attn_prefill(q[j], self.xk_b[slot][ci], xvts[j], att[rows], xworks[j], False, scale)
+                if many and self.xk_b.is_contiguous():
+                    xoff = [it[0] * self.xk_b.stride(0) + ci * self.xk_b.stride(1) for it in items]
+                    for j in range(k):
+                        hip.qkv_rope_split(q2[j * S:(j + 1) * S], None, None, q[j], None, None, None, Hq, 0, D)
+                    hip.attn_prefill_many(q, self.xk_b, xvt_all, att, xwork_all, False, scale, xoff, self.Tk)
+                else:
+                    for j, (slot, _, _, _) in enumerate(items):
+                        rows = slice(j * S, (j + 1) * S)
+                        hip.qkv_rope_split(q2[rows], None, None, q[j], None, None, None, Hq, 0, D)
+                        hip.attn_prefill(q[j], self.xk_b[slot][ci], xvts[j], att[rows], xworks[j], False, scale)
                 proj(att, lw.o_w, ks_o)
                 keep = [x[j * S:j * S + nm].clone() for j in range(k)] if nm > 0 else None
                 hip.rmsnorm(x, lw.ln2_w, cfg.rms_eps, out=y)
