@@ -1439,7 +1439,12 @@ static int gemm_dispatch(GemmArgs p, hipStream_t stream) {
   const float cost4 = (float)((t4 + 255) / 256) * (1.41f * nk64 + 4.3f);
   bool huge = forced ? (forced == 4 || forced == 7) : (K >= 256 && M > 128 && N > 128 && cost4 < cost1);
   int cols4 = tn4;  // 256-wide tile columns given to the 256x256 kernel
-  if (!forced && K >= 1024 && M >= 1024 && t4 >= 512 && last != 0 && last < 128) {   // >= 2 whole rounds + a thin remainder
+  // ... and (r05) ONE whole round + a remainder of fewer than 64 tiles: the second round of a 294-tile grid (LLM o at four images)
+  // or a 264-tile one (the Auditor's qkv) costs almost a full round for 15 % / 3 % of the tiles - 155 -> 141 us and 162 -> 141 us
+  // with the remainder columns on half-tiles (tools/probes/gemm_mix_probe.py, launches alone; inside `dual` at 32 per step the
+  // difference is within run-to-run noise, 9.93 vs 9.93 images/s; VIS_GEMM_MIX1=0: off, A/B)
+  static const int mix1 = [] { const char* e = getenv("VIS_GEMM_MIX1"); return e ? atoi(e) : 64; }();
+  if (!forced && K >= 1024 && M >= 1024 && last != 0 && ((t4 >= 512 && last < 128) || (t4 > 256 && t4 < 512 && last < mix1))) {   // whole rounds + a thin remainder
     cols4 = (t4 / 256) * 256 / tm4;  // whole rounds only; the ragged remainder columns go through this function again
     huge = cols4 > 0;
   }
