@@ -30,9 +30,10 @@ def run_i():
     res["i"] = insp.generate_batch([(q_ids, [frame])] * B, max_new_tokens=new, ignore_eos=True)
 def run_a():
     res["a"] = aud.generate_batch([(m_ids, raw)] * B, max_new_tokens=new, stop_on_eos=False)
+PRIO = os.environ.get("DUAL_PRIO") == "1"      # the Auditor's thread on a high-priority stream (another hardware queue pool)
 def on_stream(fn):
     def body():
-        st = torch.cuda.Stream(device=dev)
+        st = torch.cuda.Stream(device=dev, priority=-1 if (PRIO and fn is run_a) else 0)
         st.wait_stream(torch.cuda.default_stream(dev))
         with torch.cuda.stream(st):
             fn()
