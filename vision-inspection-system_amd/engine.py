@@ -816,9 +816,18 @@ class Qwen2VLEngine:
                 hip.gemm(act, lw.down_w, residual=x, out=x)
                 if nxt is not None:
                     hip.rmsnorm(x, nxt, cfg.rms_eps, out=y)
+        # lm_head over the last rows of the whole group in ONE pass over its 1.09 GB (vis_gemv_bf16_rows: every row bit-identical to
+        # the single-row GEMV) instead of one pass per request; VIS_GROUP_ATTN=0 keeps the per-request calls
+        grouped = self.group_attn and 1 < k <= 4 and H * 2 * (2 if k <= 2 else 4) <= 152 * 1024
+        if grouped:
+            lg = torch.empty((k, self.logits_b.shape[1]), dtype=torch.float32, device=dev)
+            hip.gemv_rows(x[n - 1::n], w.lm_head, lg, norm_w=w.final_norm_w, eps=cfg.rms_eps)
         for j, (slot, _, _, _) in enumerate(items):
             logits = self.logits_b[slot]
-            hip.gemv(x[(j + 1) * n - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
+            if grouped:
+                logits.copy_(lg[j])
+            else:
+                hip.gemv(x[(j + 1) * n - 1], w.lm_head, logits, norm_w=w.final_norm_w, eps=cfg.rms_eps)
             self.step_b[slot:slot + 1].fill_(S - 1)
             hip.argmax(logits, self.ws_val[256 * slot:256 * (slot + 1)], self.ws_idx[256 * slot:256 * (slot + 1)],
                        self.tokens_b[slot], self.cur_b[slot:slot + 1], self.step_b[slot:slot + 1], self.temperature,

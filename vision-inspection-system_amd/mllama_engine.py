@@ -589,9 +589,16 @@ class MllamaEngine:
                 hip.gemm(y, lw.gateup_w, act=hip.ACT_SWIGLU, out=act)
                 proj(act, lw.down_w, ks_down)
                 si += 1
+        grouped = many and k <= 4 and H * 2 * (2 if k <= 2 else 4) <= 152 * 1024   # one pass over the lm_head for the group's last rows
+        if grouped:
+            lg = torch.empty((k, self.logits_b.shape[1]), dtype=torch.float32, device=dev)
+            hip.gemv_rows(x[S - 1::S], w.lm_head, lg, norm_w=w.norm_w, eps=cfg.rms_eps)
         for j, (slot, _, _, _) in enumerate(items):
             logits = self.logits_b[slot]
-            hip.gemv(x[(j + 1) * S - 1], w.lm_head, logits, norm_w=w.norm_w, eps=cfg.rms_eps)
+            if grouped:
+                logits.copy_(lg[j])
+            else:
+                hip.gemv(x[(j + 1) * S - 1], w.lm_head, logits, norm_w=w.norm_w, eps=cfg.rms_eps)
             self.step_b[slot:slot + 1].fill_(S - 1)
             hip.argmax(logits, self.ws_val[256 * slot:256 * (slot + 1)], self.ws_idx[256 * slot:256 * (slot + 1)],
                        self.tokens_b[slot], self.cur_b[slot:slot + 1], self.step_b[slot:slot + 1], self.temperature,
