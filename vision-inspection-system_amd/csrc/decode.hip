@@ -482,7 +482,7 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   __shared__ __attribute__((aligned(16))) uint32_t pbuf[NW][G][8];   // wave-private probabilities of the current step: bf16 pairs
                                                                      // (keys 2 j, 2 j + 1) - the B operand of v_dot2_f32_bf16
   __shared__ float pal[NW][G];                                     // wave-private rescale factors of the current step
-  __shared__ float red_o[NW][G][HD];
+  __shared__ __attribute__((aligned(16))) float red_o[NW][G][HD];
   __shared__ float red_ml[NW][G][2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, h = lane >> 4;
@@ -499,7 +499,12 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   bf16_t* Kh = p.k_cache + (size_t)hkv * p.cache_tokens * HD;
   bf16_t* Vh = p.v_cache + (size_t)hkv * p.cache_tokens * HD;
 
-  struct StepRegs { u32x4 k[4]; uint32_t v[16]; };
+  // V (r05): a lane holds EIGHT dims (8 l15 ..) of FOUR keys (4 h ..) as four 16-byte loads - an instruction moves four whole
+  // 256-byte rows - instead of two dims of all sixteen keys as sixteen 4-byte loads (an instruction moved one row): the same
+  // bytes and the same arithmetic per (head, key, dim) in a quarter of the V requests; the four key groups' partial sums meet once,
+  // after the last step.  Measured (64 sequences, same box, three alternating pairs): 5.245 -> 5.228 ms per decode step - the launch
+  // is not bound by its V request count either.
+  struct StepRegs { u32x4 k[4]; u32x4 v[4]; };
   auto load_step = [&](StepRegs& r, int j) {          // keys 16 j .. 16 j + 15 (rows clamped: addresses are always valid)
     const int k0 = j * 16;
     const bool sh = k0 < p.shared_len;             // (wave-uniform; shared_len is a multiple of 16)
@@ -509,9 +514,9 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) r.k[ds] = *(const u32x4*)(Kb + (size_t)krow * HD + ds * 32 + 8 * h);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int row = min(k0 + i, p.cache_tokens - 1);
-      r.v[i] = *(const uint32_t*)(Vb + (size_t)row * HD + 2 * lane);
+    for (int i = 0; i < 4; ++i) {
+      const int row = min(k0 + 4 * h + i, p.cache_tokens - 1);
+      r.v[i] = *(const u32x4*)(Vb + (size_t)row * HD + 8 * l15);
     }
   };
   // Two register sets.  (Negative, r05: FOUR sets - three steps = 24 KB per wave in flight instead of one - on the theory that
@@ -564,10 +569,12 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   bf16x8 qf[4];
 #pragma unroll
   for (int ds = 0; ds < 4; ++ds) qf[ds] = *(const bf16x8*)(&q_s[l15][ds * 32 + 8 * h]);
-  const uint32_t vnew = *(const uint32_t*)(&vnew_s[2 * lane]);
-  float acc0[G], acc1[G];
+  const u32x4 vnew = *(const u32x4*)(&vnew_s[8 * l15]);
+  float oacc[G][8];                        // O[g][8 l15 + e] over this lane's keys (4 h .. 4 h + 3 of every step)
 #pragma unroll
-  for (int g = 0; g < G; ++g) { acc0[g] = 0.f; acc1[g] = 0.f; }
+  for (int g = 0; g < G; ++g)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) oacc[g][e] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;     // of head l15 (identical in the four lanes l15, l15 + 16, + 32, + 48)
 
   auto step = [&](StepRegs& r, int j) {
@@ -603,33 +610,44 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
     const uint32_t p01 = pack2bf(pe[0], pe[1]), p23 = pack2bf(pe[2], pe[3]);
     l_run = l_run * al + hsum4((__uint_as_float(p01 << 16) + __uint_as_float(p01 & 0xffff0000u)) +
                                (__uint_as_float(p23 << 16) + __uint_as_float(p23 & 0xffff0000u)));
+    // the rescale is skipped while no head's running maximum moved (wave-uniform; after the first steps it rarely does)
+    const bool resc = __any((l15 < G) && (al != 1.0f));
     if (l15 < G) {
       *(u32x2*)(&pbuf[wave][l15][2 * h]) = (u32x2){p01, p23};     // keys 4 h .. 4 h + 3 = pairs 2 h, 2 h + 1
       if (h == 0) pal[wave][l15] = al;
     }
-    // ---- O[g][d] = O[g][d] * alpha[g] + sum_key p[g][key] V[key][d]; lane owns d = 2 lane, 2 lane + 1
-    bf16x2 va[8], vb[8];     // per key pair: dim 2 lane of both keys / dim 2 lane + 1 of both keys
+    // other LANES' probabilities are read next: the hardware keeps a wave's DS operations in order, the COMPILER must not move the
+    // reads of rows this thread did not write above the writes (single-thread semantics would let it)
+    asm volatile("" ::: "memory");
+    // ---- O[g][d] = O[g][d] * alpha[g] + sum_key p[g][key] V[key][d]; lane owns d = 8 l15 .. + 7 over keys 4 h .. 4 h + 3
+    bf16x2 va[2][8];     // [key pair (4 h + 2 q, 4 h + 2 q + 1)][dim 8 l15 + e]: that dim of both keys
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const uint32_t r0 = (k0 + 2 * j == new_row) ? vnew : r.v[2 * j];
-      const uint32_t r1 = (k0 + 2 * j + 1 == new_row) ? vnew : r.v[2 * j + 1];
-      va[j] = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(r1, r0, 0x05040100u));   // {r0.lo, r1.lo}
-      vb[j] = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(r1, r0, 0x07060302u));   // {r0.hi, r1.hi}
+    for (int q = 0; q < 2; ++q) {
+      const u32x4 r0 = (k0 + 4 * h + 2 * q == new_row) ? vnew : r.v[2 * q];
+      const u32x4 r1 = (k0 + 4 * h + 2 * q + 1 == new_row) ? vnew : r.v[2 * q + 1];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        va[q][2 * m] = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(r1[m], r0[m], 0x05040100u));       // {r0.lo, r1.lo}
+        va[q][2 * m + 1] = __builtin_bit_cast(bf16x2, __builtin_amdgcn_perm(r1[m], r0[m], 0x07060302u));   // {r0.hi, r1.hi}
+      }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const float ag = pal[wave][g];
-      float a0 = acc0[g] * ag, a1 = acc1[g] * ag;
-      const u32x4 pq0 = *(const u32x4*)(&pbuf[wave][g][0]), pq1 = *(const u32x4*)(&pbuf[wave][g][4]);   // broadcast reads
+      // this lane's two key pairs of head g, as two scalar reads: the 8-byte vector read `u32x2 pq = *(const u32x2*)&pbuf[..][2 h]`
+      // followed by pq[0] / pq[1] came out of hipcc 7.2 with BOTH dot products on element 0 (the IR holds a single extractelement:
+      // tools/probes/decode_attn_forms.py shows a one-key context at exactly twice its value) - test_decode_attn_streaming_form caught it
+      const uint32_t pw0 = pbuf[wave][g][2 * h], pw1 = pbuf[wave][g][2 * h + 1];
+      const bf16x2 pp0 = __builtin_bit_cast(bf16x2, pw0), pp1 = __builtin_bit_cast(bf16x2, pw1);
+      if (resc) {
+        const float ag = pal[wave][g];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {       // keys past the context carry p = 0 (masked scores)
-        const bf16x2 pp = __builtin_bit_cast(bf16x2, j < 4 ? pq0[j] : pq1[j - 4]);
-        a0 = __builtin_amdgcn_fdot2_f32_bf16(va[j], pp, a0, false);
-        a1 = __builtin_amdgcn_fdot2_f32_bf16(vb[j], pp, a1, false);
+        for (int e = 0; e < 8; ++e) oacc[g][e] *= ag;
       }
-      acc0[g] = a0;
-      acc1[g] = a1;
-      __builtin_amdgcn_sched_barrier(0);   // one head at a time: hoisting all heads' p reads costs 100+ VGPRs (spills)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {       // keys past the context carry p = 0 (masked scores)
+        const float a0 = __builtin_amdgcn_fdot2_f32_bf16(va[0][e], pp0, oacc[g][e], false);
+        oacc[g][e] = __builtin_amdgcn_fdot2_f32_bf16(va[1][e], pp1, a0, false);
+      }
     }
   };
 
@@ -647,8 +665,13 @@ __global__ __launch_bounds__(512) void decode_attn_stream_kernel(DecAttnArgs p, 
   // ---- merge the eight waves
 #pragma unroll
   for (int g = 0; g < G; ++g) {
-    red_o[wave][g][2 * lane] = acc0[g];
-    red_o[wave][g][2 * lane + 1] = acc1[g];
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = hsum4(oacc[g][e]);           // the four key groups of the wave (lanes l15, + 16, + 32, + 48)
+    if (h == 0) {
+      *(f32x4*)(&red_o[wave][g][8 * l15]) = (f32x4){t[0], t[1], t[2], t[3]};
+      *(f32x4*)(&red_o[wave][g][8 * l15 + 4]) = (f32x4){t[4], t[5], t[6], t[7]};
+    }
   }
   if (h == 0 && l15 < G) { red_ml[wave][l15][0] = m_run; red_ml[wave][l15][1] = l_run; }
   __syncthreads();
