@@ -719,6 +719,8 @@ __device__ __forceinline__ u32x2 qr_pack8(const float* f, float inv) {
   return (u32x2){(uint32_t)w0, (uint32_t)w1};
 }
 
+template <int QCH>   // 16-byte chunks per lane the register path holds: 3 (rows up to 1536 elements: the ViT's LayerNorm rows at a third of
+                     // the registers, r05) or QR_MAX_CHUNKS
 __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ nw,
                                                              const bf16_t* __restrict__ nb, uint8_t* __restrict__ q,
                                                              float* __restrict__ scale, int rows, int K, int ldx,
@@ -729,15 +731,15 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
   const int nch = K >> 3;
   const bf16_t* xr = x + (size_t)row * ldx;
   uint8_t* qr = q + (size_t)row * ldq;
-  if (nch <= 64 * QR_MAX_CHUNKS) {  // the row lives in registers (uniform branch)
-    float v[QR_MAX_CHUNKS][8];
+  if (nch <= 64 * QCH) {  // the row lives in registers (uniform branch)
+    float v[QCH][8];
     float ss = 0.f;
     {   // r05: every load unconditional (clamped chunk) and issued before the first use - a guarded load drains the queue
-      u32x4 raw[QR_MAX_CHUNKS];
+      u32x4 raw[QCH];
 #pragma unroll
-      for (int i = 0; i < QR_MAX_CHUNKS; ++i) raw[i] = *(const u32x4*)(xr + min(lane + i * 64, nch - 1) * 8);
+      for (int i = 0; i < QCH; ++i) raw[i] = *(const u32x4*)(xr + min(lane + i * 64, nch - 1) * 8);
 #pragma unroll
-      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      for (int i = 0; i < QCH; ++i) {
         if (lane + i * 64 < nch) {
           unpack8(raw[i], v[i]);
 #pragma unroll
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     if (nw && nb) {   // LayerNorm (ViT): same arithmetic and single bf16 rounding as norm_rows_kernel<true>
       float sm = 0.f;
 #pragma unroll
-      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      for (int i = 0; i < QCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
 #pragma unroll
@@ -758,7 +760,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
       const float mean = wave_sum(sm) / (float)K;
       float d2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      for (int i = 0; i < QCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
 #pragma unroll
@@ -767,7 +769,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
       }
       const float rstd = rsqrtf(wave_sum(d2) / (float)K + eps);
 #pragma unroll
-      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      for (int i = 0; i < QCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
           float w[8], b[8];
@@ -781,7 +783,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
       ss = wave_sum(ss);
       const float rstd = rsqrtf(ss / (float)K + eps);
 #pragma unroll
-      for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+      for (int i = 0; i < QCH; ++i) {
         const int c = lane + i * 64;
         if (c < nch) {
           float w[8];
@@ -793,7 +795,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     }
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < QCH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) {
 #pragma unroll
@@ -805,7 +807,7 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     const float inv = 1.0f / sc;
     if (lane == 0) scale[row] = sc;
 #pragma unroll
-    for (int i = 0; i < QR_MAX_CHUNKS; ++i) {
+    for (int i = 0; i < QCH; ++i) {
       const int c = lane + i * 64;
       if (c < nch) *(u32x2*)(qr + c * 8) = qr_pack8(v[i], inv);
     }
@@ -934,7 +936,11 @@ extern "C" int vis_quant_rows_fp8(const void* x, const void* norm_w, const void*
 #undef QR_WIDE
     return vis_check_launch();
   }
-  hipLaunchKernelGGL(quant_rows_fp8_kernel, grid, block, 0, stream, (const bf16_t*)x,
-                     (const bf16_t*)norm_w, (const bf16_t*)norm_b, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
+  if (wide_env && nch_lane <= 3)
+    hipLaunchKernelGGL(quant_rows_fp8_kernel<3>, grid, block, 0, stream, (const bf16_t*)x,
+                       (const bf16_t*)norm_w, (const bf16_t*)norm_b, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
+  else
+    hipLaunchKernelGGL(quant_rows_fp8_kernel<QR_MAX_CHUNKS>, grid, block, 0, stream, (const bf16_t*)x,
+                       (const bf16_t*)norm_w, (const bf16_t*)norm_b, (uint8_t*)q, (float*)scale, rows, K, ldx, ldq, eps);
   return vis_check_launch();
 }
